@@ -1,0 +1,83 @@
+// Shared device helpers for the fs2hip kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fs2hip.h"
+
+#define FS2_WAVE 64
+
+#define FS2_LAUNCH_CHECK()                    \
+  do {                                        \
+    hipError_t e__ = hipGetLastError();       \
+    if (e__ != hipSuccess) return (int)e__;   \
+  } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- stateless dropout: keep iff hash(seed, idx) >= p * 2^32 ------------------------------
+__device__ __forceinline__ uint32_t fs2_hash32(unsigned long long seed, unsigned long long idx) {
+  unsigned long long z = seed + idx * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)(z >> 32);
+}
+struct Fs2Drop {
+  uint32_t thresh;  // drop iff hash < thresh
+  float scale;      // 1/(1-p)
+  unsigned long long seed;
+  bool on;
+};
+__host__ __device__ inline Fs2Drop fs2_make_drop(float p, unsigned long long seed) {
+  Fs2Drop d;
+  d.on = p > 0.f;
+  d.seed = seed;
+  double t = (double)p * 4294967296.0;
+  d.thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+  d.scale = p < 1.f ? 1.f / (1.f - p) : 0.f;
+  return d;
+}
+__device__ __forceinline__ float fs2_drop_factor(const Fs2Drop& d, unsigned long long idx) {
+  if (!d.on) return 1.f;
+  return fs2_hash32(d.seed, idx) < d.thresh ? 0.f : d.scale;
+}
+
+// ---- activations ------------------------------------------------------------------------
+__device__ __forceinline__ float fs2_sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float fs2_act(int act, float x) {
+  switch (act) {
+    case FS2_ACT_RELU: return x > 0.f ? x : 0.f;
+    case FS2_ACT_SILU: return x * fs2_sigmoid(x);
+    case FS2_ACT_TANH: return tanhf(x);
+    default: return x;
+  }
+}
+// derivative with respect to the pre-activation x
+__device__ __forceinline__ float fs2_dact(int act, float x) {
+  switch (act) {
+    case FS2_ACT_RELU: return x > 0.f ? 1.f : 0.f;
+    case FS2_ACT_SILU: {
+      float s = fs2_sigmoid(x);
+      return s * (1.f + x * (1.f - s));
+    }
+    case FS2_ACT_TANH: {
+      float t = tanhf(x);
+      return 1.f - t * t;
+    }
+    default: return 1.f;
+  }
+}
+
+// ---- wavefront reductions (64 lanes) ------------------------------------------------------
+__device__ __forceinline__ float fs2_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float fs2_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

@@ -1,0 +1,361 @@
+// fp32 GEMM on the gfx950 f32-input matrix cores (v_mfma_f32_32x32x2_f32), with the conv-tap
+// addressing modes and fused epilogues described in include/fs2hip.h.
+//
+// Tiling (wave64): a 256-thread workgroup = 4 wavefronts in a 2x2 arrangement computes a
+// BM x BN tile; every wavefront owns (BM/2)x(BN/2) as TM x TN accumulators of 32x32 (16 VGPRs
+// each).  K advances in steps of BK = 16 through two LDS buffers; both operand tiles are kept
+// k-major in LDS ([k][m] / [k][n]) so that the MFMA operand fetch (lane l: row l&31, k = l>>5)
+// is a conflict-free ds_read_b32 of 32 consecutive floats per half-wave.  Global->LDS goes
+// through registers (the loader applies the conv-tap row shift / zero fill and transposes
+// k-contiguous sources on the way), issued one K-tile ahead of the MFMAs.
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 16;
+constexpr int LDS_PAD = 4;
+
+struct GemmP {
+  Fs2GemmArgs a;
+  int Rper;        // reduction length per tap (shift_operand == 0) or R
+  int tiles_n;     // number of tiles along Nc
+  int r_chunk;     // split-K chunk (multiple of BK)
+};
+
+template <int BM, int BN>
+struct Tile {
+  static constexpr int TM = BM / 64;
+  static constexpr int TN = BN / 64;
+  static constexpr int LDA = BM + LDS_PAD;
+  static constexpr int LDB = BN + LDS_PAD;
+  static constexpr int A_F4 = BM * BK / 4 / 256;  // float4 per thread per tile
+  static constexpr int B_F4 = BN * BK / 4 / 256;
+};
+
+// Loads one [BK x ROWS] operand tile into registers.
+//  kcontig: source is [row][k] (ld), thread reads float4 along k at (row = i*64 + tid/4, k4 = tid%4)
+//  else   : source is [k][row] (ld), thread reads float4 along rows at (k = i*8 + tid/32, row4 = tid%32)
+template <int ROWS, int NF4>
+__device__ __forceinline__ void load_tile(float4 (&reg)[NF4], const float* __restrict__ src, int ld,
+                                          bool kcontig, int row0, int nrows, int k0, int klimit,
+                                          int shift, int T, bool shift_rows, bool shift_k, int tid) {
+  if (kcontig) {
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) {
+      int r = row0 + i * 64 + (tid >> 2);
+      int k = k0 + (tid & 3) * 4;
+      bool ok = r < nrows && k < klimit;
+      int rs = r;
+      if (shift_rows) {
+        int t = r % T + shift;
+        ok = ok && t >= 0 && t < T;
+        rs = r + shift;
+      }
+      reg[i] = ok ? *reinterpret_cast<const float4*>(src + (long long)rs * ld + k) : make_float4(0, 0, 0, 0);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) {
+      int k = k0 + i * (1024 / ROWS) + (tid / (ROWS / 4));
+      int r = row0 + (tid % (ROWS / 4)) * 4;
+      bool ok = k < klimit && r < nrows;
+      int ks = k;
+      if (shift_k) {
+        int t = k % T + shift;
+        ok = ok && t >= 0 && t < T;
+        ks = k + shift;
+      }
+      reg[i] = ok ? *reinterpret_cast<const float4*>(src + (long long)ks * ld + r) : make_float4(0, 0, 0, 0);
+    }
+  }
+}
+
+template <int ROWS, int NF4, int LD>
+__device__ __forceinline__ void store_tile(float* __restrict__ lds, const float4 (&reg)[NF4], bool kcontig, int tid) {
+  if (kcontig) {
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) {
+      int r = i * 64 + (tid >> 2);
+      int k = (tid & 3) * 4;
+      lds[(k + 0) * LD + r] = reg[i].x;
+      lds[(k + 1) * LD + r] = reg[i].y;
+      lds[(k + 2) * LD + r] = reg[i].z;
+      lds[(k + 3) * LD + r] = reg[i].w;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) {
+      int k = i * (1024 / ROWS) + (tid / (ROWS / 4));
+      int r = (tid % (ROWS / 4)) * 4;
+      *reinterpret_cast<float4*>(lds + k * LD + r) = reg[i];
+    }
+  }
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
+  using TL = Tile<BM, BN>;
+  constexpr int TM = TL::TM, TN = TL::TN, LDA = TL::LDA, LDB = TL::LDB;
+  __shared__ __attribute__((aligned(16))) float lds[2 * BK * (LDA + LDB)];
+  float* const As0 = lds;                 // [2][BK][LDA]
+  float* const Bs0 = lds + 2 * BK * LDA;  // [2][BK][LDB]
+
+  const Fs2GemmArgs& a = p.a;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile_m = blockIdx.x / p.tiles_n, tile_n = blockIdx.x % p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // reduction range of this workgroup
+  int tapz = 0, split = 0;
+  if (a.shift_operand == 1 || a.splitk > 1) {
+    tapz = blockIdx.z / a.splitk;
+    split = blockIdx.z % a.splitk;
+  }
+  const int r_begin = split * p.r_chunk;
+  const int r_end = min(a.R, r_begin + p.r_chunk);
+  const int nkt = (r_end - r_begin + BK - 1) / BK;
+
+  const bool a_shift_rows = a.shift_operand == 0 && a.taps > 1;
+  const bool b_shift_k = a.shift_operand == 1 && a.taps > 1;
+  const int shift_z = tapz * a.tap_mul + a.tap_add;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[TL::A_F4], rb[TL::B_F4];
+
+  auto issue = [&](int kt) {
+    int r0 = r_begin + kt * BK;
+    int tap = 0, kin = r0;
+    const float* Bsrc = a.B;
+    int shift = shift_z;
+    if (a_shift_rows) {
+      tap = r0 / p.Rper;
+      kin = r0 - tap * p.Rper;
+      shift = tap * a.tap_mul + a.tap_add;
+      Bsrc += (long long)tap * a.b_tap_stride;
+    }
+    // A operand: kcontig -> [Mc][Rper]; else [R][Mc]
+    load_tile<BM, TL::A_F4>(ra, a.A, a.lda, a.a_kcontig != 0, m0, a.Mc, a_shift_rows ? kin : r0,
+                            a_shift_rows ? p.Rper : r_end, shift, a.T, a_shift_rows, false, tid);
+    load_tile<BN, TL::B_F4>(rb, Bsrc, a.ldb, a.b_kcontig != 0, n0, a.Nc, a_shift_rows ? kin : r0,
+                            a_shift_rows ? p.Rper : r_end, shift, a.T, false, b_shift_k, tid);
+  };
+
+  if (nkt > 0) {
+    issue(0);
+    store_tile<BM, TL::A_F4, LDA>(As0, ra, a.a_kcontig != 0, tid);
+    store_tile<BN, TL::B_F4, LDB>(Bs0, rb, a.b_kcontig != 0, tid);
+  }
+  __syncthreads();
+
+  int cur = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (kt + 1 < nkt) issue(kt + 1);
+    const float* Ab = As0 + cur * (BK * LDA) + wm * (BM / 2) + (lane & 31);
+    const float* Bb = Bs0 + cur * (BK * LDB) + wn * (BN / 2) + (lane & 31);
+    const int kh = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float av[TM], bv[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[i] = Ab[(kk * 2 + kh) * LDA + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[j] = Bb[(kk * 2 + kh) * LDB + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nkt) {
+      store_tile<BM, TL::A_F4, LDA>(As0 + (cur ^ 1) * (BK * LDA), ra, a.a_kcontig != 0, tid);
+      store_tile<BN, TL::B_F4, LDB>(Bs0 + (cur ^ 1) * (BK * LDB), rb, a.b_kcontig != 0, tid);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue -----------------------------------------------------------------------------
+  float* C = a.C;
+  if (a.splitk > 1) {
+    C = a.workspace + ((long long)split * a.taps + tapz) * ((long long)a.Mc * a.Nc);
+  } else if (a.shift_operand == 1) {
+    C += (long long)tapz * a.c_tap_stride;
+  }
+  const int ldc = a.splitk > 1 ? a.Nc : a.ldc;
+  const bool plain = a.splitk > 1;
+  const Fs2Drop drop = fs2_make_drop(a.drop_p, a.drop_seed);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+      if (n >= a.Nc) continue;
+      const float bias = (!plain && a.bias) ? a.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m >= a.Mc) continue;
+        float v = acc[i][j][r];
+        const long long o = (long long)m * ldc + n;
+        if (plain) {
+          C[o] = v;
+          continue;
+        }
+        v = a.alpha * v + bias;
+        switch (a.epi) {
+          case FS2_EPI_ACT:
+            if (a.out_pre) a.out_pre[(long long)m * a.ldpre + n] = v;
+            v = fs2_act(a.act, v) * fs2_drop_factor(drop, (unsigned long long)o);
+            break;
+          case FS2_EPI_RESID:
+            v = a.resid[(long long)m * a.ldr + n] + a.res_scale * (v * fs2_drop_factor(drop, (unsigned long long)o));
+            break;
+          case FS2_EPI_DACT:
+            v = v * fs2_dact(a.act, a.aux[(long long)m * a.ldaux + n]) * fs2_drop_factor(drop, (unsigned long long)o);
+            break;
+          default: break;
+        }
+        C[o] = v;
+      }
+    }
+  }
+}
+
+template <bool VEC>
+__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out, long long n,
+                                    int nslabs, long long stride) {
+  if (VEC) {
+    long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const long long step = (long long)gridDim.x * blockDim.x * 4;
+    for (; i < n; i += step) {
+      if (i + 3 < n) {
+        float4 s = *reinterpret_cast<const float4*>(slabs + i);
+        for (int k = 1; k < nslabs; ++k) {
+          float4 v = *reinterpret_cast<const float4*>(slabs + k * stride + i);
+          s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *reinterpret_cast<float4*>(out + i) = s;
+      } else {
+        for (long long e = i; e < n; ++e) {
+          float s = slabs[e];
+          for (int k = 1; k < nslabs; ++k) s += slabs[k * stride + e];
+          out[e] = s;
+        }
+      }
+    }
+  } else {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += step) {
+      float s = slabs[i];
+      for (int k = 1; k < nslabs; ++k) s += slabs[k * stride + i];
+      out[i] = s;
+    }
+  }
+}
+
+// column sums: block (64 columns) x row stripes; 256 threads = 4 row lanes x 64 columns
+constexpr int COLSUM_ROWS_PER_BLOCK = 512;
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int ldx, int M, int N,
+                                                      float* __restrict__ partial) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * COLSUM_ROWS_PER_BLOCK;
+  const int r1 = min(M, r0 + COLSUM_ROWS_PER_BLOCK);
+  float s = 0.f;
+  if (c < N)
+    for (int r = r0 + rl; r < r1; r += 4) s += x[(long long)r * ldx + c];
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < N)
+    partial[(long long)blockIdx.y * N + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+}  // namespace
+
+extern "C" int fs2hip_version(void) { return 1; }
+
+extern "C" int fs2hip_reduce_slabs(const float* slabs, float* out, long long n, int nslabs,
+                                   long long slab_stride, void* stream) {
+  if (n <= 0) return 0;
+  if (nslabs < 1) return FS2HIP_EINVAL;
+  const bool vec = (slab_stride % 4) == 0 && ((uintptr_t)slabs % 16) == 0 && ((uintptr_t)out % 16) == 0;
+  long long blocks = ((vec ? n / 4 : n) + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  if (vec)
+    reduce_slabs_kernel<true><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(slabs, out, n, nslabs, slab_stride);
+  else
+    reduce_slabs_kernel<false><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(slabs, out, n, nslabs, slab_stride);
+  FS2_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fs2hip_colsum_rows(int M) { return (M + COLSUM_ROWS_PER_BLOCK - 1) / COLSUM_ROWS_PER_BLOCK; }
+
+extern "C" int fs2hip_colsum(const float* x, int ldx, int M, int N, float* partial, float* out, void* stream) {
+  if (M <= 0 || N <= 0) return FS2HIP_EINVAL;
+  int gy = fs2hip_colsum_rows(M);
+  colsum_kernel<<<dim3((N + 63) / 64, gy), dim3(256), 0, (hipStream_t)stream>>>(x, ldx, M, N, partial);
+  FS2_LAUNCH_CHECK();
+  return fs2hip_reduce_slabs(partial, out, N, gy, N, stream);
+}
+
+extern "C" int fs2hip_gemm(const Fs2GemmArgs* args, void* stream) {
+  GemmP p;
+  p.a = *args;
+  Fs2GemmArgs& a = p.a;
+  if (a.Mc <= 0 || a.Nc <= 0 || a.R <= 0) return FS2HIP_EINVAL;
+  if (a.taps < 1) a.taps = 1;
+  if (a.splitk < 1) a.splitk = 1;
+  // vector-load preconditions: the contiguous dimension of every operand is a multiple of 4
+  // floats and rows start 16-byte aligned
+  if ((a.lda % 4) || (a.ldb % 4)) return FS2HIP_EINVAL;
+  if (((uintptr_t)a.A % 16) || ((uintptr_t)a.B % 16)) return FS2HIP_EINVAL;
+  if (a.a_kcontig ? (a.R / (a.shift_operand == 0 ? a.taps : 1)) % 4 : a.Mc % 4) return FS2HIP_EINVAL;
+  if (a.b_kcontig ? (a.R / (a.shift_operand == 0 ? a.taps : 1)) % 4 : a.Nc % 4) return FS2HIP_EINVAL;
+  p.Rper = a.R;
+  if (a.taps > 1) {
+    if (a.T <= 0 || a.Mc <= 0) return FS2HIP_EINVAL;
+    if (a.shift_operand == 0) {
+      if (!a.a_kcontig || a.R % a.taps) return FS2HIP_EINVAL;
+      p.Rper = a.R / a.taps;
+      if (p.Rper % BK) return FS2HIP_EINVAL;  // a K tile never straddles two taps
+      if (a.Mc % a.T) return FS2HIP_EINVAL;
+    } else {
+      if (a.a_kcontig || a.b_kcontig || a.R % a.T) return FS2HIP_EINVAL;
+    }
+  }
+  if (a.splitk > 1 && (a.a_kcontig || a.b_kcontig || !a.workspace)) return FS2HIP_EINVAL;
+  if (a.epi == FS2_EPI_RESID && !a.resid) return FS2HIP_EINVAL;
+  if (a.epi == FS2_EPI_DACT && !a.aux) return FS2HIP_EINVAL;
+  int chunk = (a.R + a.splitk - 1) / a.splitk;
+  p.r_chunk = ((chunk + BK - 1) / BK) * BK;
+  const int nz = (a.shift_operand == 1 ? a.taps : 1) * a.splitk;
+  hipStream_t s = (hipStream_t)stream;
+  // tile choice: wide N -> 128x128; narrow N (<= 96 columns left in the last tile would waste
+  // matrix-core cycles) -> 128x64
+  const bool narrow = a.Nc <= 64 || (a.Nc % 128 != 0 && a.Nc % 128 <= 64) ||
+                      ((long long)((a.Mc + 127) / 128) * ((a.Nc + 127) / 128) * nz < 384);
+  if (narrow) {
+    p.tiles_n = (a.Nc + 63) / 64;
+    dim3 grid(((a.Mc + 127) / 128) * p.tiles_n, 1, nz);
+    gemm_kernel<128, 64><<<grid, dim3(256), 0, s>>>(p);
+  } else {
+    p.tiles_n = (a.Nc + 127) / 128;
+    dim3 grid(((a.Mc + 127) / 128) * p.tiles_n, 1, nz);
+    gemm_kernel<128, 128><<<grid, dim3(256), 0, s>>>(p);
+  }
+  FS2_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,182 @@
+// LayerNorm forward/backward: one 64-lane wavefront per row, float4 loads, wavefront-shuffle
+// reductions (no LDS on the row statistics).  HBM-bound: forward reads x once and writes y once.
+#include "common.h"
+
+namespace {
+
+constexpr int LN_MAX_CH = 4;           // C <= 1024: at most 4 float4 chunks per lane
+constexpr int LN_BWD_ROWS = 32;        // rows per workgroup in the backward (4 waves x 8 rows)
+
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float* __restrict__ y,
+                                                      float* __restrict__ mean, float* __restrict__ rstd, int M,
+                                                      int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int c4 = C >> 2;
+  float4 v[NCH];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    int i = lane + 64 * j;
+    v[j] = i < c4 ? reinterpret_cast<const float4*>(x + (long long)row * C)[i] : make_float4(0, 0, 0, 0);
+    s += v[j].x + v[j].y + v[j].z + v[j].w;
+  }
+  const float mu = fs2_wave_sum(s) / C;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    int i = lane + 64 * j;
+    if (i < c4) {
+      float a = v[j].x - mu, b = v[j].y - mu, c = v[j].z - mu, d = v[j].w - mu;
+      q += a * a + b * b + c * c + d * d;
+    }
+  }
+  const float rs = rsqrtf(fs2_wave_sum(q) / C + eps);
+  if (lane == 0) {
+    mean[row] = mu;
+    rstd[row] = rs;
+  }
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    int i = lane + 64 * j;
+    if (i < c4) {
+      float4 g = reinterpret_cast<const float4*>(gamma)[i];
+      float4 b = reinterpret_cast<const float4*>(beta)[i];
+      float4 o;
+      o.x = (v[j].x - mu) * rs * g.x + b.x;
+      o.y = (v[j].y - mu) * rs * g.y + b.y;
+      o.z = (v[j].z - mu) * rs * g.z + b.z;
+      o.w = (v[j].w - mu) * rs * g.w + b.w;
+      reinterpret_cast<float4*>(y + (long long)row * C)[i] = o;
+    }
+  }
+}
+
+// dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)) (+ dx_add);
+// partial[blk][0][C] = sum_rows dy*xhat, partial[blk][1][C] = sum_rows dy
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd, const float* __restrict__ dx_add,
+                                                      float* __restrict__ dx, float* __restrict__ partial, int M, int C) {
+  __shared__ float red[4][2][LN_MAX_CH * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c4 = C >> 2;
+  float4 g[NCH], dg[NCH], db[NCH];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    int i = lane + 64 * j;
+    g[j] = i < c4 ? reinterpret_cast<const float4*>(gamma)[i] : make_float4(0, 0, 0, 0);
+    dg[j] = make_float4(0, 0, 0, 0);
+    db[j] = make_float4(0, 0, 0, 0);
+  }
+  const int row0 = blockIdx.x * LN_BWD_ROWS;
+  for (int rr = wave; rr < LN_BWD_ROWS; rr += 4) {
+    const int row = row0 + rr;
+    if (row >= M) break;
+    const float mu = mean[row], rs = rstd[row];
+    float4 xh[NCH], d[NCH];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      int i = lane + 64 * j;
+      if (i < c4) {
+        float4 xv = reinterpret_cast<const float4*>(x + (long long)row * C)[i];
+        d[j] = reinterpret_cast<const float4*>(dy + (long long)row * C)[i];
+        xh[j] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+      } else {
+        d[j] = make_float4(0, 0, 0, 0);
+        xh[j] = make_float4(0, 0, 0, 0);
+      }
+      dg[j].x += d[j].x * xh[j].x; dg[j].y += d[j].y * xh[j].y; dg[j].z += d[j].z * xh[j].z; dg[j].w += d[j].w * xh[j].w;
+      db[j].x += d[j].x; db[j].y += d[j].y; db[j].z += d[j].z; db[j].w += d[j].w;
+      d[j].x *= g[j].x; d[j].y *= g[j].y; d[j].z *= g[j].z; d[j].w *= g[j].w;
+      s1 += d[j].x + d[j].y + d[j].z + d[j].w;
+      s2 += d[j].x * xh[j].x + d[j].y * xh[j].y + d[j].z * xh[j].z + d[j].w * xh[j].w;
+    }
+    s1 = fs2_wave_sum(s1) / C;
+    s2 = fs2_wave_sum(s2) / C;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      int i = lane + 64 * j;
+      if (i < c4) {
+        float4 o;
+        o.x = rs * (d[j].x - s1 - xh[j].x * s2);
+        o.y = rs * (d[j].y - s1 - xh[j].y * s2);
+        o.z = rs * (d[j].z - s1 - xh[j].z * s2);
+        o.w = rs * (d[j].w - s1 - xh[j].w * s2);
+        if (dx_add) {
+          float4 r = reinterpret_cast<const float4*>(dx_add + (long long)row * C)[i];
+          o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        reinterpret_cast<float4*>(dx + (long long)row * C)[i] = o;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    int i = lane + 64 * j;
+    reinterpret_cast<float4*>(&red[wave][0][0])[i] = dg[j];
+    reinterpret_cast<float4*>(&red[wave][1][0])[i] = db[j];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c];
+    float b = red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c];
+    partial[((long long)blockIdx.x * 2 + 0) * C + c] = a;
+    partial[((long long)blockIdx.x * 2 + 1) * C + c] = b;
+  }
+}
+
+// dgamma/dbeta finish: out[k][c] = sum_blk partial[blk][k][c]
+__global__ void ln_bwd_finish_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta, int nblk, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= 2 * C) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += partial[(long long)b * 2 * C + c];
+  if (c < C) dgamma[c] = s; else dbeta[c - C] = s;
+}
+
+}  // namespace
+
+extern "C" int fs2hip_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
+                                    float* mean, float* rstd, int M, int C, float eps, void* stream) {
+  if (M <= 0 || C <= 0 || (C % 4) || C > LN_MAX_CH * 256) return FS2HIP_EINVAL;
+  if (((uintptr_t)x % 16) || ((uintptr_t)y % 16) || ((uintptr_t)gamma % 16) || ((uintptr_t)beta % 16)) return FS2HIP_EINVAL;
+  dim3 grid((M + 3) / 4), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  const int nch = (C / 4 + 63) / 64;
+  switch (nch) {
+    case 1: ln_fwd_kernel<1><<<grid, block, 0, s>>>(x, gamma, beta, y, mean, rstd, M, C, eps); break;
+    case 2: ln_fwd_kernel<2><<<grid, block, 0, s>>>(x, gamma, beta, y, mean, rstd, M, C, eps); break;
+    default: ln_fwd_kernel<4><<<grid, block, 0, s>>>(x, gamma, beta, y, mean, rstd, M, C, eps); break;
+  }
+  FS2_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fs2hip_layernorm_bwd_blocks(int M) { return (M + LN_BWD_ROWS - 1) / LN_BWD_ROWS; }
+
+extern "C" int fs2hip_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+                                    const float* rstd, const float* dx_add, float* dx, float* partial,
+                                    float* dgamma, float* dbeta, int M, int C, void* stream) {
+  if (M <= 0 || C <= 0 || (C % 4) || C > LN_MAX_CH * 256) return FS2HIP_EINVAL;
+  if (((uintptr_t)x % 16) || ((uintptr_t)dy % 16) || ((uintptr_t)dx % 16) || ((uintptr_t)gamma % 16)) return FS2HIP_EINVAL;
+  if (dx_add && ((uintptr_t)dx_add % 16)) return FS2HIP_EINVAL;
+  const int nblk = fs2hip_layernorm_bwd_blocks(M);
+  hipStream_t s = (hipStream_t)stream;
+  const int nch = (C / 4 + 63) / 64;
+  switch (nch) {
+    case 1: ln_bwd_kernel<1><<<dim3(nblk), dim3(256), 0, s>>>(dy, x, gamma, mean, rstd, dx_add, dx, partial, M, C); break;
+    case 2: ln_bwd_kernel<2><<<dim3(nblk), dim3(256), 0, s>>>(dy, x, gamma, mean, rstd, dx_add, dx, partial, M, C); break;
+    default: ln_bwd_kernel<4><<<dim3(nblk), dim3(256), 0, s>>>(dy, x, gamma, mean, rstd, dx_add, dx, partial, M, C); break;
+  }
+  FS2_LAUNCH_CHECK();
+  ln_bwd_finish_kernel<<<dim3((2 * C + 255) / 256), dim3(256), 0, s>>>(partial, dgamma, dbeta, nblk, C);
+  FS2_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,124 @@
+"""GPU parity of the GEMM family and LayerNorm against plain PyTorch fp32 (CPU) references.
+Tolerances: fp32 MFMA is a k-ordered fmaf chain; against a differently-ordered fp32 sum the
+error bound is ~K * eps * |a||b|, so results are compared at 2e-5 * K^0.5 of the output scale."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def H():
+    from fastspeech2_lightning_amd import hip
+    assert torch.cuda.is_available()
+    hip.lib()
+    return hip
+
+
+def close(a, b, K=256, msg=""):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    scale = max(float(b.abs().max()), 1e-6)
+    tol = 4e-6 * math.sqrt(K) + 1e-6
+    err = float((a - b).abs().max()) / scale
+    assert err < tol, f"{msg}: rel err {err:.3e} > {tol:.3e}"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 256, 256), (2048, 1024, 256), (513, 80, 256), (130, 768, 64), (64, 64, 16)])
+def test_linear_fwd_plain(H, M, N, K):
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    y = H.linear_fwd(x.cuda(), w.cuda(), b.cuda())
+    close(y, F.linear(x, w, b), K, "linear")
+
+
+def test_linear_fwd_act_and_resid(H):
+    M, N, K = 777, 256, 1024
+    x, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3), rnd(M, N, seed=4)
+    pre = torch.empty(M, N, device="cuda")
+    y = H.linear_fwd(x.cuda(), w.cuda(), b.cuda(), epi=H.EPI_ACT, act="silu", out_pre=pre)
+    ref = F.linear(x, w, b)
+    close(pre, ref, K, "pre")
+    close(y, F.silu(ref), K, "silu")
+    y = H.linear_fwd(x.cuda(), w.cuda(), b.cuda(), epi=H.EPI_ACT, act="relu")
+    close(y, F.relu(ref), K, "relu")
+    y = H.linear_fwd(x.cuda(), w.cuda(), b.cuda(), epi=H.EPI_RESID, resid=r.cuda(), res_scale=0.5)
+    close(y, r + 0.5 * ref, K, "resid")
+
+
+@pytest.mark.parametrize("taps,Cin,Cout", [(5, 80, 512), (5, 512, 80), (3, 256, 256), (9, 64, 128)])
+def test_conv_taps_fwd_bwd(H, taps, Cin, Cout):
+    B, T = 3, 37
+    x = rnd(B, T, Cin, seed=1)
+    w = rnd(Cout, Cin, taps, seed=2, scale=(Cin * taps) ** -0.5)
+    b = rnd(Cout, seed=3)
+    x.requires_grad_(True); w.requires_grad_(True)
+    ref = F.conv1d(x.transpose(1, 2), w, b, padding=(taps - 1) // 2).transpose(1, 2)
+    wp = w.detach().permute(2, 0, 1).contiguous().cuda()  # [taps, Cout, Cin]
+    y = H.linear_fwd(x.detach().cuda(), wp, b.cuda(), taps=taps, T=T)
+    close(y, ref, Cin * taps, "conv fwd")
+    dy = rnd(B, T, Cout, seed=5)
+    ref.backward(dy)
+    dx = H.linear_bwd_data(dy.cuda(), wp, taps=taps, T=T)
+    close(dx, x.grad, Cout * taps, "conv bwd data")
+    dw = torch.empty(taps, Cout, Cin, device="cuda")
+    H.linear_bwd_weight(dy.cuda(), x.detach().cuda(), dw, taps=taps, T=T)
+    close(dw, w.grad.permute(2, 0, 1), B * T, "conv bwd weight")
+
+
+@pytest.mark.parametrize("M,N,K", [(4100, 256, 1024), (333, 1024, 256), (20000, 80, 256)])
+def test_linear_bwd(H, M, N, K):
+    x, w, dy = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(M, N, seed=3)
+    dx = H.linear_bwd_data(dy.cuda(), w.cuda())
+    close(dx, dy @ w, N, "dx")
+    dw = torch.empty(N, K, device="cuda")
+    H.linear_bwd_weight(dy.cuda(), x.cuda(), dw)
+    close(dw, dy.t() @ x, M, "dw")
+    db = torch.empty(N, device="cuda")
+    H.colsum(dy.cuda(), db)
+    close(db, dy.sum(0), M, "db")
+    # backward through an activation (EPI_DACT)
+    pre = rnd(M, K, seed=9)
+    du = H.linear_bwd_data(dy.cuda(), w.cuda(), epi=H.EPI_DACT, act="silu", aux=pre.cuda(), alpha=0.5)
+    p = pre.clone().requires_grad_(True)
+    F.silu(p).backward(0.5 * (dy @ w))
+    close(du, p.grad, N, "dact")
+
+
+def test_dropout_epilogue_statistics_and_replay(H):
+    M, N, K = 512, 256, 64
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    y0 = H.linear_fwd(x.cuda(), w.cuda())
+    y1 = H.linear_fwd(x.cuda(), w.cuda(), epi=H.EPI_ACT, act="none", drop_p=0.2, drop_seed=77)
+    y2 = H.linear_fwd(x.cuda(), w.cuda(), epi=H.EPI_ACT, act="none", drop_p=0.2, drop_seed=77)
+    assert torch.equal(y1, y2)  # same seed -> same mask (the backward regenerates it)
+    kept = (y1 != 0).float().mean().item()
+    assert abs(kept - 0.8) < 0.01
+    m = y1 != 0
+    close(y1[m], y0[m] / 0.8, K, "scaled survivors")
+    # the same mask multiplies the gradient in EPI_DACT
+    g = H.linear_bwd_data(torch.ones(M, K, device="cuda"), torch.eye(K, N, device="cuda"),
+                          epi=H.EPI_DACT, act="none", aux=torch.zeros(M, N, device="cuda"), drop_p=0.2, drop_seed=77)
+    assert g.shape == (M, N)
+
+
+@pytest.mark.parametrize("M,C", [(1000, 256), (37, 512), (5, 80), (129, 1024)])
+def test_layernorm(H, M, C):
+    x, g, b, dy, add = rnd(M, C, seed=1), 1 + 0.1 * rnd(C, seed=2), rnd(C, seed=3), rnd(M, C, seed=4), rnd(M, C, seed=5)
+    y, mean, rstd = H.layernorm_fwd(x.cuda(), g.cuda(), b.cuda())
+    xr, gr, br = x.clone().requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (C,), gr, br, 1e-5)
+    close(y, ref, 16, "ln fwd")
+    ref.backward(dy)
+    dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    dx = H.layernorm_bwd(dy.cuda(), x.cuda(), g.cuda(), mean, rstd, dg, db, dx_add=add.cuda())
+    close(dx, xr.grad + add, 16, "ln dx")
+    close(dg, gr.grad, M, "ln dgamma")
+    close(db, br.grad, M, "ln dbeta")
