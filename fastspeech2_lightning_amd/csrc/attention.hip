@@ -1,0 +1,362 @@
+// Multi-head self-attention with key-padding mask, flash-style (scores never reach HBM), fp32
+// on v_mfma_f32_16x16x4_f32.  Replaces nn.MultiheadAttention's softmax(QK^T/sqrt(d) + mask)V
+// inside torchaudio's ConformerLayer (call sites fs2/model.py:193, :241) forward and backward.
+//
+// Layout: qkv is the in_proj output [B*T][3*D] (q | k | v, head h = columns h*HD..), o is [B*T][D].
+// A workgroup (4 wavefronts) owns 64 rows of one (batch, head); each wavefront owns 16 of them and
+// walks the other sequence in tiles of 64 staged in LDS.  All products are computed TRANSPOSED
+// (S^T = K Q^T, O^T = V^T P^T, ...) so that the owned row index sits on the MFMA column
+// (lane & 15): softmax statistics and rescales are then lane-local, and an accumulator tile is
+// directly the B operand of the next MFMA (any k-order is a valid reduction order for fp32).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float xor_max16_32(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float xor_sum16_32(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+struct AttnP {
+  const float* qkv;
+  const int* lens;
+  int B, T, H;
+  float scale;
+  Fs2Drop drop;
+};
+
+// stage 64 rows x HD columns (starting at column `col`) of the [*, ld] matrix into LDS [64][HD+4]
+template <int HD>
+__device__ __forceinline__ void stage_rows(float* __restrict__ dst, const float* __restrict__ src, int ld, int col,
+                                           int row0, int nrows, int tid) {
+  constexpr int LDT = HD + 4, F4 = HD / 4;
+#pragma unroll
+  for (int it = 0; it < (64 * F4 + 255) / 256; ++it) {
+    int idx = tid + it * 256;
+    if (idx < 64 * F4) {
+      int r = idx / F4, c4 = idx % F4;
+      int row = row0 + r;
+      float4 v = row < nrows ? *reinterpret_cast<const float4*>(src + (long long)row * ld + col + c4 * 4)
+                             : make_float4(0, 0, 0, 0);
+      *reinterpret_cast<float4*>(dst + r * LDT + c4 * 4) = v;
+    }
+  }
+}
+
+// X^T[rows of tile][own] = sum_d tile[row][d] * own_reg[d]   (tile rows 16*kt + (lane&15))
+template <int HD>
+__device__ __forceinline__ f32x4 dot_tile(const float* __restrict__ tile, const float4 (&own)[HD / 16], int kt, int c, int g) {
+  constexpr int LDT = HD + 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < HD / 16; ++j) {
+    float4 t = *reinterpret_cast<const float4*>(tile + (16 * kt + c) * LDT + 16 * j + 4 * g);
+    acc = mfma16(t.x, own[j].x, acc);
+    acc = mfma16(t.y, own[j].y, acc);
+    acc = mfma16(t.z, own[j].z, acc);
+    acc = mfma16(t.w, own[j].w, acc);
+  }
+  return acc;
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p, float* __restrict__ o, float* __restrict__ lse) {
+  constexpr int LDT = HD + 4, NJ = HD / 16;
+  __shared__ __attribute__((aligned(16))) float Ks[64 * LDT];
+  __shared__ __attribute__((aligned(16))) float Vs[64 * LDT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+  const int h = blockIdx.y, b = blockIdx.z, T = p.T, D = p.H * HD, ld = 3 * D;
+  const int q = blockIdx.x * 64 + wave * 16 + c;
+  const int len = p.lens[b];
+  const Fs2Drop drop = fs2_resolve_drop(p.drop);
+  const float* base = p.qkv + (long long)b * T * ld;
+  float4 qr[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    float4 v = q < T ? *reinterpret_cast<const float4*>(base + (long long)q * ld + h * HD + 16 * j + 4 * g)
+                     : make_float4(0, 0, 0, 0);
+    qr[j] = make_float4(v.x * p.scale, v.y * p.scale, v.z * p.scale, v.w * p.scale);
+  }
+  f32x4 oacc[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) oacc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m = -INFINITY, l = 0.f;
+  const int kend = min(T, len);
+  const unsigned long long rowidx = ((unsigned long long)(b * p.H + h) * T + q) * T;
+  for (int key0 = 0; key0 < kend; key0 += 64) {
+    __syncthreads();
+    stage_rows<HD>(Ks, base, ld, D + h * HD, key0, T, tid);
+    stage_rows<HD>(Vs, base, ld, 2 * D + h * HD, key0, T, tid);
+    __syncthreads();
+    f32x4 s[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      s[kt] = dot_tile<HD>(Ks, qr, kt, c, g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int key = key0 + 16 * kt + 4 * g + r;
+        if (key >= len) s[kt][r] = -INFINITY;
+        mx = fmaxf(mx, s[kt][r]);
+      }
+    }
+    mx = xor_max16_32(mx);
+    const float mnew = fmaxf(m, mx);
+    const float alpha = expf(m - mnew);
+    float rs = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float pv = expf(s[kt][r] - mnew);
+        rs += pv;
+        s[kt][r] = pv * fs2_drop_factor(drop, rowidx + (unsigned long long)(key0 + 16 * kt + 4 * g + r));
+      }
+    rs = xor_sum16_32(rs);
+    l = l * alpha + rs;
+    m = mnew;
+#pragma unroll
+    for (int dt = 0; dt < NJ; ++dt) {
+      oacc[dt] *= alpha;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          oacc[dt] = mfma16(Vs[(16 * kt + 4 * g + r) * LDT + 16 * dt + c], s[kt][r], oacc[dt]);
+    }
+  }
+  if (q < T) {
+    const float inv = 1.f / l;
+    float* orow = o + ((long long)b * T + q) * D + h * HD;
+#pragma unroll
+    for (int dt = 0; dt < NJ; ++dt)
+      *reinterpret_cast<float4*>(orow + 16 * dt + 4 * g) =
+          make_float4(oacc[dt][0] * inv, oacc[dt][1] * inv, oacc[dt][2] * inv, oacc[dt][3] * inv);
+    if (g == 0) lse[((long long)b * p.H + h) * T + q] = m + logf(l);
+  }
+}
+
+// delta[b][h][t] = sum_d dO * O over the head's columns; one wavefront per row
+__global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ dout, const float* __restrict__ o,
+                                                          float* __restrict__ delta, int B, int T, int H, int HD) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B * T) return;
+  const int D = H * HD, f4 = D / 4, per_head = HD / 4;
+  const int b = row / T, t = row % T;
+  for (int i0 = 0; i0 < f4; i0 += 64) {
+    int i = i0 + lane;
+    float s = 0.f;
+    if (i < f4) {
+      float4 a = reinterpret_cast<const float4*>(dout + (long long)row * D)[i];
+      float4 c = reinterpret_cast<const float4*>(o + (long long)row * D)[i];
+      s = a.x * c.x + a.y * c.y + a.z * c.z + a.w * c.w;
+    }
+    for (int w = 1; w < per_head && w < 64; w <<= 1) s += __shfl_xor(s, w, 64);
+    if (i < f4 && (i % per_head) == 0) delta[((long long)b * H + i / per_head) * T + t] = s;
+  }
+}
+
+// dQ: same walk as the forward (own = queries, tiles = keys)
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p, const float* __restrict__ dout,
+                                                           const float* __restrict__ lse, const float* __restrict__ delta,
+                                                           float* __restrict__ dqkv) {
+  constexpr int LDT = HD + 4, NJ = HD / 16;
+  __shared__ __attribute__((aligned(16))) float Ks[64 * LDT];
+  __shared__ __attribute__((aligned(16))) float Vs[64 * LDT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+  const int h = blockIdx.y, b = blockIdx.z, T = p.T, D = p.H * HD, ld = 3 * D;
+  const int q = blockIdx.x * 64 + wave * 16 + c;
+  const int len = p.lens[b];
+  const Fs2Drop drop = fs2_resolve_drop(p.drop);
+  const float* base = p.qkv + (long long)b * T * ld;
+  float4 qr[NJ], dor[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    float4 v = q < T ? *reinterpret_cast<const float4*>(base + (long long)q * ld + h * HD + 16 * j + 4 * g)
+                     : make_float4(0, 0, 0, 0);
+    qr[j] = make_float4(v.x * p.scale, v.y * p.scale, v.z * p.scale, v.w * p.scale);
+    dor[j] = q < T ? *reinterpret_cast<const float4*>(dout + ((long long)b * T + q) * D + h * HD + 16 * j + 4 * g)
+                   : make_float4(0, 0, 0, 0);
+  }
+  const float lse_q = q < T ? lse[((long long)b * p.H + h) * T + q] : INFINITY;
+  const float delta_q = q < T ? delta[((long long)b * p.H + h) * T + q] : 0.f;
+  f32x4 dq[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) dq[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int kend = min(T, len);
+  const unsigned long long rowidx = ((unsigned long long)(b * p.H + h) * T + q) * T;
+  for (int key0 = 0; key0 < kend; key0 += 64) {
+    __syncthreads();
+    stage_rows<HD>(Ks, base, ld, D + h * HD, key0, T, tid);
+    stage_rows<HD>(Vs, base, ld, 2 * D + h * HD, key0, T, tid);
+    __syncthreads();
+    f32x4 ds[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      f32x4 s = dot_tile<HD>(Ks, qr, kt, c, g);
+      f32x4 dp = dot_tile<HD>(Vs, dor, kt, c, g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int key = key0 + 16 * kt + 4 * g + r;
+        float pv = key < len ? expf(s[r] - lse_q) : 0.f;
+        float f = fs2_drop_factor(drop, rowidx + (unsigned long long)key);
+        ds[kt][r] = pv * (dp[r] * f - delta_q);
+      }
+    }
+#pragma unroll
+    for (int dt = 0; dt < NJ; ++dt)
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          dq[dt] = mfma16(Ks[(16 * kt + 4 * g + r) * LDT + 16 * dt + c], ds[kt][r], dq[dt]);
+  }
+  if (q < T) {
+    float* row = dqkv + ((long long)b * T + q) * ld + h * HD;
+#pragma unroll
+    for (int dt = 0; dt < NJ; ++dt)
+      *reinterpret_cast<float4*>(row + 16 * dt + 4 * g) =
+          make_float4(dq[dt][0] * p.scale, dq[dt][1] * p.scale, dq[dt][2] * p.scale, dq[dt][3] * p.scale);
+  }
+}
+
+// dK, dV: own = keys (registers), tiles = queries (Q and dO staged in LDS)
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p, const float* __restrict__ dout,
+                                                            const float* __restrict__ lse, const float* __restrict__ delta,
+                                                            float* __restrict__ dqkv) {
+  constexpr int LDT = HD + 4, NJ = HD / 16;
+  __shared__ __attribute__((aligned(16))) float Qs[64 * LDT];
+  __shared__ __attribute__((aligned(16))) float Os[64 * LDT];
+  __shared__ float lse_s[64], delta_s[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+  const int h = blockIdx.y, b = blockIdx.z, T = p.T, D = p.H * HD, ld = 3 * D;
+  const int key = blockIdx.x * 64 + wave * 16 + c;
+  const int len = p.lens[b];
+  const Fs2Drop drop = fs2_resolve_drop(p.drop);
+  const float* base = p.qkv + (long long)b * T * ld;
+  float* krow = dqkv + ((long long)b * T + key) * ld + D + h * HD;
+  float* vrow = krow + D;
+  if (blockIdx.x * 64 >= len) {  // every key of this workgroup is padding: gradients are zero
+    if (key < T) {
+#pragma unroll
+      for (int dt = 0; dt < NJ; ++dt) {
+        *reinterpret_cast<float4*>(krow + 16 * dt + 4 * g) = make_float4(0, 0, 0, 0);
+        *reinterpret_cast<float4*>(vrow + 16 * dt + 4 * g) = make_float4(0, 0, 0, 0);
+      }
+    }
+    return;
+  }
+  float4 kr[NJ], vr[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    float4 v = key < T ? *reinterpret_cast<const float4*>(base + (long long)key * ld + D + h * HD + 16 * j + 4 * g)
+                       : make_float4(0, 0, 0, 0);
+    kr[j] = make_float4(v.x * p.scale, v.y * p.scale, v.z * p.scale, v.w * p.scale);
+    vr[j] = key < T ? *reinterpret_cast<const float4*>(base + (long long)key * ld + 2 * D + h * HD + 16 * j + 4 * g)
+                    : make_float4(0, 0, 0, 0);
+  }
+  f32x4 dk[NJ], dv[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    dk[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    dv[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const bool key_ok = key < len;
+  const unsigned long long headidx = (unsigned long long)(b * p.H + h) * T;
+  for (int q0 = 0; q0 < T; q0 += 64) {
+    __syncthreads();
+    stage_rows<HD>(Qs, base, ld, h * HD, q0, T, tid);
+    stage_rows<HD>(Os, dout + (long long)b * T * D, D, h * HD, q0, T, tid);
+    if (tid < 64) {
+      int qq = q0 + tid;
+      lse_s[tid] = qq < T ? lse[((long long)b * p.H + h) * T + qq] : INFINITY;
+      delta_s[tid] = qq < T ? delta[((long long)b * p.H + h) * T + qq] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      f32x4 s = dot_tile<HD>(Qs, kr, qt, c, g);
+      f32x4 dp = dot_tile<HD>(Os, vr, qt, c, g);
+      f32x4 pd, ds;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int ql = 16 * qt + 4 * g + r;
+        float pv = key_ok ? expf(s[r] - lse_s[ql]) : 0.f;
+        float f = fs2_drop_factor(drop, (headidx + (unsigned long long)(q0 + ql)) * T + (unsigned long long)key);
+        pd[r] = pv * f;
+        ds[r] = pv * (dp[r] * f - delta_s[ql]);
+      }
+#pragma unroll
+      for (int dt = 0; dt < NJ; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dv[dt] = mfma16(Os[(16 * qt + 4 * g + r) * LDT + 16 * dt + c], pd[r], dv[dt]);
+          dk[dt] = mfma16(Qs[(16 * qt + 4 * g + r) * LDT + 16 * dt + c], ds[r], dk[dt]);
+        }
+    }
+  }
+  if (key < T) {
+#pragma unroll
+    for (int dt = 0; dt < NJ; ++dt) {
+      *reinterpret_cast<float4*>(krow + 16 * dt + 4 * g) =
+          make_float4(dk[dt][0] * p.scale, dk[dt][1] * p.scale, dk[dt][2] * p.scale, dk[dt][3] * p.scale);
+      *reinterpret_cast<float4*>(vrow + 16 * dt + 4 * g) = make_float4(dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]);
+    }
+  }
+}
+
+bool attn_args_ok(const void* qkv, int B, int T, int H, int HD) {
+  if (B <= 0 || T <= 0 || H <= 0) return false;
+  if (HD != 16 && HD != 32 && HD != 64 && HD != 128) return false;
+  if ((uintptr_t)qkv % 16) return false;
+  return true;
+}
+
+}  // namespace
+
+#define ATTN_DISPATCH(HD_, CALL)           \
+  switch (HD_) {                           \
+    case 16: { constexpr int HDc = 16; CALL; } break;   \
+    case 32: { constexpr int HDc = 32; CALL; } break;   \
+    case 64: { constexpr int HDc = 64; CALL; } break;   \
+    default: { constexpr int HDc = 128; CALL; } break;  \
+  }
+
+extern "C" int fs2hip_attention_fwd(const float* qkv, const int* lens, float* o, float* lse, int B, int T, int H,
+                                    int HD, float drop_p, unsigned long long drop_seed,
+                                    const unsigned long long* drop_step, void* stream) {
+  if (!attn_args_ok(qkv, B, T, H, HD) || ((uintptr_t)o % 16)) return FS2HIP_EINVAL;
+  AttnP p{qkv, lens, B, T, H, 1.f / sqrtf((float)HD), fs2_make_drop(drop_p, drop_seed, drop_step)};
+  dim3 grid((T + 63) / 64, H, B);
+  ATTN_DISPATCH(HD, (attn_fwd_kernel<HDc><<<grid, dim3(256), 0, (hipStream_t)stream>>>(p, o, lse)));
+  FS2_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fs2hip_attention_bwd(const float* qkv, const int* lens, const float* o, const float* dout,
+                                    const float* lse, float* delta, float* dqkv, int B, int T, int H, int HD,
+                                    float drop_p, unsigned long long drop_seed,
+                                    const unsigned long long* drop_step, void* stream) {
+  if (!attn_args_ok(qkv, B, T, H, HD) || ((uintptr_t)o % 16) || ((uintptr_t)dout % 16) || ((uintptr_t)dqkv % 16))
+    return FS2HIP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  attn_delta_kernel<<<dim3((B * T + 3) / 4), dim3(256), 0, s>>>(dout, o, delta, B, T, H, HD);
+  FS2_LAUNCH_CHECK();
+  AttnP p{qkv, lens, B, T, H, 1.f / sqrtf((float)HD), fs2_make_drop(drop_p, drop_seed, drop_step)};
+  dim3 grid((T + 63) / 64, H, B);
+  ATTN_DISPATCH(HD, (attn_bwd_dq_kernel<HDc><<<grid, dim3(256), 0, s>>>(p, dout, lse, delta, dqkv)));
+  FS2_LAUNCH_CHECK();
+  ATTN_DISPATCH(HD, (attn_bwd_dkv_kernel<HDc><<<grid, dim3(256), 0, s>>>(p, dout, lse, delta, dqkv)));
+  FS2_LAUNCH_CHECK();
+  return 0;
+}

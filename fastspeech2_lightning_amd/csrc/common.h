@@ -28,15 +28,23 @@ struct Fs2Drop {
   uint32_t thresh;  // drop iff hash < thresh
   float scale;      // 1/(1-p)
   unsigned long long seed;
+  const unsigned long long* step;  // device-resident step counter mixed into the seed (may be null):
+                                   // kernel arguments are frozen when a captured hipGraph replays
   bool on;
 };
-__host__ __device__ inline Fs2Drop fs2_make_drop(float p, unsigned long long seed) {
+inline Fs2Drop fs2_make_drop(float p, unsigned long long seed, const unsigned long long* step = nullptr) {
   Fs2Drop d;
   d.on = p > 0.f;
   d.seed = seed;
+  d.step = step;
   double t = (double)p * 4294967296.0;
   d.thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
   d.scale = p < 1.f ? 1.f / (1.f - p) : 0.f;
+  return d;
+}
+// call once at kernel entry
+__device__ __forceinline__ Fs2Drop fs2_resolve_drop(Fs2Drop d) {
+  if (d.on && d.step) d.seed += (*d.step) * 0xD1B54A32D192ED03ull;
   return d;
 }
 __device__ __forceinline__ float fs2_drop_factor(const Fs2Drop& d, unsigned long long idx) {
@@ -45,7 +53,7 @@ __device__ __forceinline__ float fs2_drop_factor(const Fs2Drop& d, unsigned long
 }
 
 // ---- activations ------------------------------------------------------------------------
-__device__ __forceinline__ float fs2_sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float fs2_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
 __device__ __forceinline__ float fs2_act(int act, float x) {
   switch (act) {
     case FS2_ACT_RELU: return x > 0.f ? x : 0.f;

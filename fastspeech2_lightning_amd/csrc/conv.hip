@@ -1,0 +1,196 @@
+// Depthwise Conv1d over time on the dense (B, T, C) layout, optionally fused with the GLU that
+// precedes it and with the per-channel sum / sum-of-squares BatchNorm needs after it.
+// Replaces: torchaudio Conformer conv module's GLU + depthwise Conv1d(k) (+ the statistics pass of
+// BatchNorm1d) (call sites fs2/model.py:193, :241) and the depthwise half of
+// DepthwiseSeparableConv1d (fs2/blocks.py:8-13).  HBM-bound: each input element is read once
+// (+ halo from L2), lanes run along channels so every row access is a contiguous 256-byte line.
+#include "common.h"
+
+namespace {
+
+constexpr int RUN = 16;  // consecutive time steps per thread
+
+// x: [B*T][ldx]; value at column c, gate (GLU) at column C + c
+template <int K, bool GLU, bool STATS>
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict__ x, int ldx,
+                                                          const float* __restrict__ w, const float* __restrict__ bias,
+                                                          float* __restrict__ y, float* __restrict__ partial, int B,
+                                                          int T, int C) {
+  constexpr int PAD = (K - 1) / 2, WIN = RUN + K - 1;
+  __shared__ float red[4][2][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int t0 = blockIdx.y * (4 * RUN) + wave * RUN;
+  const int b = blockIdx.z;
+  const bool cok = c < C;
+  float wk[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) wk[k] = cok ? w[k * C + c] : 0.f;
+  const float bs = (cok && bias) ? bias[c] : 0.f;
+  float a[WIN];
+#pragma unroll
+  for (int i = 0; i < WIN; ++i) {
+    int t = t0 - PAD + i;
+    float v = 0.f;
+    if (cok && t >= 0 && t < T) {
+      const float* row = x + ((long long)b * T + t) * ldx;
+      v = row[c];
+      if (GLU) v *= fs2_sigmoid(row[C + c]);
+    }
+    a[i] = v;
+  }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int o = 0; o < RUN; ++o) {
+    int t = t0 + o;
+    if (cok && t < T) {
+      float acc = bs;
+#pragma unroll
+      for (int k = 0; k < K; ++k) acc = fmaf(wk[k], a[o + k], acc);
+      y[((long long)b * T + t) * C + c] = acc;
+      s1 += acc;
+      s2 += acc * acc;
+    }
+  }
+  if (STATS) {
+    red[wave][0][lane] = s1;
+    red[wave][1][lane] = s2;
+    __syncthreads();
+    if (wave == 0 && cok) {
+      long long blk = (long long)b * gridDim.y + blockIdx.y;
+      partial[(blk * 2 + 0) * C + c] = red[0][0][lane] + red[1][0][lane] + red[2][0][lane] + red[3][0][lane];
+      partial[(blk * 2 + 1) * C + c] = red[0][1][lane] + red[1][1][lane] + red[2][1][lane] + red[3][1][lane];
+    }
+  }
+}
+
+// dy [B*T][C]; x as in the forward; dx has the layout of x.  partial [blk][K+1][C]: dw taps, dbias.
+template <int K, bool GLU>
+__global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                          int ldx, const float* __restrict__ w, float* __restrict__ dx,
+                                                          float* __restrict__ partial, int B, int T, int C) {
+  constexpr int PAD = (K - 1) / 2, WIN = RUN + K - 1;
+  __shared__ float red[4][K + 1][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int t0 = blockIdx.y * (4 * RUN) + wave * RUN;
+  const int b = blockIdx.z;
+  const bool cok = c < C;
+  float wk[K], dwk[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    wk[k] = cok ? w[k * C + c] : 0.f;
+    dwk[k] = 0.f;
+  }
+  float a[WIN], g[WIN], vc[RUN], sc[RUN];
+#pragma unroll
+  for (int i = 0; i < WIN; ++i) {
+    int t = t0 - PAD + i;
+    float v = 0.f, d = 0.f, vv = 0.f, sg = 0.f;
+    if (cok && t >= 0 && t < T) {
+      const float* row = x + ((long long)b * T + t) * ldx;
+      vv = row[c];
+      v = vv;
+      if (GLU) {
+        sg = fs2_sigmoid(row[C + c]);
+        v = vv * sg;
+      }
+      d = dy[((long long)b * T + t) * C + c];
+    }
+    a[i] = v;
+    g[i] = d;
+    if (i >= PAD && i < PAD + RUN) {
+      vc[i - PAD] = vv;
+      sc[i - PAD] = sg;
+    }
+  }
+  float db = 0.f;
+#pragma unroll
+  for (int o = 0; o < RUN; ++o) {
+    int t = t0 + o;
+    // da[t] = sum_k w[k] * dy[t - k + PAD]
+    float da = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) da = fmaf(wk[k], g[o + (K - 1 - k)], da);
+    const float gy = g[o + PAD];
+    db += gy;
+#pragma unroll
+    for (int k = 0; k < K; ++k) dwk[k] = fmaf(gy, a[o + k], dwk[k]);
+    if (cok && t < T) {
+      float* row = dx + ((long long)b * T + t) * ldx;
+      if (GLU) {
+        row[c] = da * sc[o];
+        row[C + c] = da * vc[o] * sc[o] * (1.f - sc[o]);
+      } else {
+        row[c] = da;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) red[wave][k][lane] = dwk[k];
+  red[wave][K][lane] = db;
+  __syncthreads();
+  if (wave == 0 && cok) {
+    long long blk = (long long)b * gridDim.y + blockIdx.y;
+#pragma unroll
+    for (int k = 0; k <= K; ++k)
+      partial[(blk * (K + 1) + k) * C + c] = red[0][k][lane] + red[1][k][lane] + red[2][k][lane] + red[3][k][lane];
+  }
+}
+
+}  // namespace
+
+extern "C" int fs2hip_dwconv_blocks(int B, int T) { return B * ((T + 4 * RUN - 1) / (4 * RUN)); }
+
+#define DW_FWD(KK)                                                                                              \
+  if (glu && stats) dwconv_fwd_kernel<KK, true, true><<<grid, dim3(256), 0, s>>>(x, ldx, w, bias, y, partial, B, T, C); \
+  else if (glu) dwconv_fwd_kernel<KK, true, false><<<grid, dim3(256), 0, s>>>(x, ldx, w, bias, y, partial, B, T, C);   \
+  else if (stats) dwconv_fwd_kernel<KK, false, true><<<grid, dim3(256), 0, s>>>(x, ldx, w, bias, y, partial, B, T, C); \
+  else dwconv_fwd_kernel<KK, false, false><<<grid, dim3(256), 0, s>>>(x, ldx, w, bias, y, partial, B, T, C);
+
+extern "C" int fs2hip_dwconv_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, float* partial,
+                                 int B, int T, int C, int K, int glu, int stats, void* stream) {
+  if (B <= 0 || T <= 0 || C <= 0 || ldx < (glu ? 2 * C : C)) return FS2HIP_EINVAL;
+  if (stats && !partial) return FS2HIP_EINVAL;
+  dim3 grid((C + 63) / 64, (T + 4 * RUN - 1) / (4 * RUN), B);
+  hipStream_t s = (hipStream_t)stream;
+  switch (K) {
+    case 3: DW_FWD(3) break;
+    case 5: DW_FWD(5) break;
+    case 7: DW_FWD(7) break;
+    case 9: DW_FWD(9) break;
+    case 15: DW_FWD(15) break;
+    case 31: DW_FWD(31) break;
+    default: return FS2HIP_EINVAL;
+  }
+  FS2_LAUNCH_CHECK();
+  return 0;
+}
+
+#define DW_BWD(KK)                                                                                   \
+  if (glu) dwconv_bwd_kernel<KK, true><<<grid, dim3(256), 0, s>>>(dy, x, ldx, w, dx, partial, B, T, C); \
+  else dwconv_bwd_kernel<KK, false><<<grid, dim3(256), 0, s>>>(dy, x, ldx, w, dx, partial, B, T, C);
+
+// partial: [fs2hip_dwconv_blocks(B,T)][K+1][C]; dw [K][C], dbias [C] are finished here
+extern "C" int fs2hip_dwconv_bwd(const float* dy, const float* x, int ldx, const float* w, float* dx, float* partial,
+                                 float* dw, float* dbias, int B, int T, int C, int K, int glu, void* stream) {
+  if (B <= 0 || T <= 0 || C <= 0 || ldx < (glu ? 2 * C : C) || !partial) return FS2HIP_EINVAL;
+  dim3 grid((C + 63) / 64, (T + 4 * RUN - 1) / (4 * RUN), B);
+  hipStream_t s = (hipStream_t)stream;
+  switch (K) {
+    case 3: DW_BWD(3) break;
+    case 5: DW_BWD(5) break;
+    case 7: DW_BWD(7) break;
+    case 9: DW_BWD(9) break;
+    case 15: DW_BWD(15) break;
+    case 31: DW_BWD(31) break;
+    default: return FS2HIP_EINVAL;
+  }
+  FS2_LAUNCH_CHECK();
+  const int nblk = fs2hip_dwconv_blocks(B, T);
+  const long long stride = (long long)(K + 1) * C;
+  int rc = fs2hip_reduce_slabs(partial, dw, (long long)K * C, nblk, stride, stream);
+  if (rc) return rc;
+  if (dbias) rc = fs2hip_reduce_slabs(partial + (long long)K * C, dbias, C, nblk, stride, stream);
+  return rc;
+}

@@ -20,6 +20,7 @@ struct GemmP {
   int Rper;        // reduction length per tap (shift_operand == 0) or R
   int tiles_n;     // number of tiles along Nc
   int r_chunk;     // split-K chunk (multiple of BK)
+  Fs2Drop drop;
 };
 
 template <int BM, int BN>
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   }
   const int ldc = a.splitk > 1 ? a.Nc : a.ldc;
   const bool plain = a.splitk > 1;
-  const Fs2Drop drop = fs2_make_drop(a.drop_p, a.drop_seed);
+  const Fs2Drop drop = fs2_resolve_drop(p.drop);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -339,6 +340,7 @@ extern "C" int fs2hip_gemm(const Fs2GemmArgs* args, void* stream) {
   if (a.splitk > 1 && (a.a_kcontig || a.b_kcontig || !a.workspace)) return FS2HIP_EINVAL;
   if (a.epi == FS2_EPI_RESID && !a.resid) return FS2HIP_EINVAL;
   if (a.epi == FS2_EPI_DACT && !a.aux) return FS2HIP_EINVAL;
+  p.drop = fs2_make_drop(a.drop_p, a.drop_seed, a.drop_step);
   int chunk = (a.R + a.splitk - 1) / a.splitk;
   p.r_chunk = ((chunk + BK - 1) / BK) * BK;
   const int nz = (a.shift_operand == 1 ? a.taps : 1) * a.splitk;

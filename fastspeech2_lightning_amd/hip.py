@@ -21,9 +21,6 @@ ACT_NONE, ACT_RELU, ACT_SILU, ACT_TANH = 0, 1, 2, 3
 EPI_STORE, EPI_ACT, EPI_RESID, EPI_DACT = 0, 1, 2, 3
 _ACT = {None: 0, "none": 0, "relu": 1, "silu": 2, "tanh": 3}
 
-_f32p = C.c_void_p
-_i32p = C.c_void_p
-
 
 class GemmArgs(C.Structure):
     _fields_ = [
@@ -40,9 +37,51 @@ class GemmArgs(C.Structure):
         ("resid", C.c_void_p), ("ldr", C.c_int), ("res_scale", C.c_float),
         ("aux", C.c_void_p), ("ldaux", C.c_int),
         ("out_pre", C.c_void_p), ("ldpre", C.c_int),
-        ("drop_p", C.c_float), ("drop_seed", C.c_ulonglong),
+        ("drop_p", C.c_float), ("drop_seed", C.c_ulonglong), ("drop_step", C.c_void_p),
         ("splitk", C.c_int), ("workspace", C.c_void_p),
     ]
+
+
+_T = {"p": C.c_void_p, "i": C.c_int, "f": C.c_float, "q": C.c_longlong, "Q": C.c_ulonglong}
+
+#: every symbol include/fs2hip.h declares -> argument type codes (checked by tests/test_abi.py)
+SIGNATURES = {
+    "fs2hip_version": "",
+    "fs2hip_gemm": None,  # (const Fs2GemmArgs*, stream)
+    "fs2hip_reduce_slabs": "ppqiqp",
+    "fs2hip_colsum_rows": "i",
+    "fs2hip_colsum": "piiippp",
+    "fs2hip_layernorm_fwd": "ppppppiifp",
+    "fs2hip_layernorm_bwd_blocks": "i",
+    "fs2hip_layernorm_bwd": "ppppppppppiip",
+    "fs2hip_attention_fwd": "ppppiiiifQpp",
+    "fs2hip_attention_bwd": "pppppppiiiifQpp",
+    "fs2hip_dwconv_blocks": "ii",
+    "fs2hip_dwconv_fwd": "pippppiiiiiip",
+    "fs2hip_dwconv_bwd": "ppipppppiiiiip",
+    "fs2hip_colstats_parts": "i",
+    "fs2hip_colstats": "piipp",
+    "fs2hip_bn_finalize": "piqppppffipip",
+    "fs2hip_bn_act_fwd": "pppiiifQpp",
+    "fs2hip_bn_act_bwd": "ppppppppiiifQpip",
+    "fs2hip_posenc_table": "ppiip",
+    "fs2hip_add_posenc": "ppppiiip",
+    "fs2hip_embedding_fwd": "pppiiip",
+    "fs2hip_embedding_bwd": "pppiiiip",
+    "fs2hip_bucket_embed_add": "pfpippppiip",
+    "fs2hip_length_regulate_fwd": "pppppppiiiip",
+    "fs2hip_length_regulate_bwd": "pppiiiip",
+    "fs2hip_rowdot_fwd": "pppppiiip",
+    "fs2hip_rowdot_blocks": "i",
+    "fs2hip_rowdot_bwd": "ppppppppiiip",
+    "fs2hip_masked_loss": "ppppiiiifpppp",
+    "fs2hip_step_advance": "pffffp",
+    "fs2hip_grad_clip_coef": "pqffppp",
+    "fs2hip_adamw_step": "ppppqpffffp",
+    "fs2hip_axpby": "pppqfffQpp",
+    "fs2hip_add_rowvec": "pppiiip",
+}
+EXPORTS = list(SIGNATURES)
 
 
 def lib():
@@ -53,16 +92,15 @@ def lib():
             raise RuntimeError(
                 f"{_LIB_PATH} is missing: build it with `python -m fastspeech2_lightning_amd.build` "
                 "(hipcc --offload-arch=gfx950). There is no fallback path.")
-        _lib = C.CDLL(str(_LIB_PATH))
-        _declare(_lib)
+        L = C.CDLL(str(_LIB_PATH))
+        for name, sig in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = C.c_int
+            if sig is not None:
+                fn.argtypes = [_T[c] for c in sig]
+        L.fs2hip_gemm.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
+        _lib = L
     return _lib
-
-
-def _declare(L):
-    L.fs2hip_version.restype = C.c_int
-    for name in EXPORTS:
-        getattr(L, name).restype = C.c_int
-    L.fs2hip_gemm.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
 
 
 def _stream() -> int:
@@ -70,6 +108,8 @@ def _stream() -> int:
 
 
 def _chk(t: torch.Tensor, dtype=torch.float32, name="tensor"):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"fs2hip: {name} must be a tensor")
     if not t.is_cuda:
         raise RuntimeError(f"fs2hip: {name} must live in GPU memory (got {t.device}); there is no CPU path")
     if t.dtype != dtype:
@@ -93,6 +133,45 @@ def _rows(t: torch.Tensor) -> int:
     return t.numel() // t.shape[-1]
 
 
+def _req(cond: bool, msg: str):
+    if not cond:
+        raise ValueError("fs2hip: " + msg)
+
+
+class Drop:
+    """Dropout spec: probability, per-op seed, device step counter (uint64 tensor or None)."""
+    __slots__ = ("p", "seed", "step")
+
+    def __init__(self, p: float = 0.0, seed: int = 0, step: Optional[torch.Tensor] = None):
+        self.p, self.seed, self.step = float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, step
+
+    @property
+    def step_ptr(self):
+        return None if self.step is None else self.step.data_ptr()
+
+
+NO_DROP = Drop()
+
+# ------------------------------------------------------------------------------------------
+# workspace (split-K slabs and partial sums): stream-ordered reuse
+# ------------------------------------------------------------------------------------------
+_WS = {}
+
+
+def reserve_workspace(n: int, device) -> torch.Tensor:
+    """Pre-size the scratch buffer (do this before capturing a hipGraph)."""
+    key = str(device)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < n:
+        ws = torch.empty(max(n, 1 << 22), device=device, dtype=torch.float32)
+        _WS[key] = ws
+    return ws
+
+
+def _workspace(n: int, device) -> torch.Tensor:
+    return reserve_workspace(n, device)
+
+
 # ------------------------------------------------------------------------------------------
 # GEMM family
 # ------------------------------------------------------------------------------------------
@@ -101,93 +180,72 @@ def _gemm(**kw):
     a.taps, a.alpha, a.res_scale, a.splitk = 1, 1.0, 1.0, 1
     for k, v in kw.items():
         setattr(a, k, v)
-    _ok(lib().fs2hip_gemm(C.byref(a), C.c_void_p(_stream())), "gemm")
+    _ok(lib().fs2hip_gemm(C.byref(a), _stream()), "gemm")
 
 
 def linear_fwd(x, w, bias=None, *, epi=EPI_STORE, act=None, resid=None, res_scale=1.0, out_pre=None,
-               drop_p=0.0, drop_seed=0, taps=1, T=0, out=None):
+               drop: Drop = NO_DROP, taps=1, T=0, out=None):
     """y[M, N] = epi(x[M, K*] @ w^T + bias).  ``w`` is [N, K] (taps == 1) or
     [taps, N, Kper] for a k-tap convolution over time (rows of x are (b, t), 'same' padding)."""
     _chk(x, name="x"); _chk(w, name="w")
     M, Kper = _rows(x), x.shape[-1]
     if taps == 1:
-        N, K = w.shape
-        if K != Kper:
-            raise ValueError(f"linear_fwd: x has {Kper} columns, w has {K}")
+        _req(w.dim() == 2 and w.shape[1] == Kper, f"linear_fwd: x has {Kper} columns, w is {tuple(w.shape)}")
+        N = w.shape[0]
     else:
-        if w.dim() != 3 or w.shape[0] != taps or w.shape[2] != Kper or M % T:
-            raise ValueError("linear_fwd: conv weight must be [taps, N, Kper] and rows a multiple of T")
+        _req(w.dim() == 3 and w.shape[0] == taps and w.shape[2] == Kper and T > 0 and M % T == 0,
+             "linear_fwd: conv weight must be [taps, N, Kper] and rows a multiple of T")
         N = w.shape[1]
     if out is None:
         out = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
     _chk(out, name="out")
-    if _rows(out) != M or out.shape[-1] != N:
-        raise ValueError("linear_fwd: bad output shape")
+    _req(_rows(out) == M and out.shape[-1] == N, "linear_fwd: bad output shape")
     kw = dict(A=_p(x), B=_p(w), C=_p(out), Mc=M, Nc=N, R=Kper * taps, lda=Kper, ldb=Kper, ldc=N,
               a_kcontig=1, b_kcontig=1, taps=taps, T=T, tap_mul=1, tap_add=-((taps - 1) // 2), shift_operand=0,
-              b_tap_stride=N * Kper, epi=epi, act=_ACT[act], drop_p=float(drop_p), drop_seed=int(drop_seed))
+              b_tap_stride=N * Kper, epi=epi, act=_ACT[act], drop_p=drop.p, drop_seed=drop.seed,
+              drop_step=drop.step_ptr)
     if bias is not None:
         _chk(bias, name="bias")
-        if bias.numel() != N:
-            raise ValueError("linear_fwd: bias size")
+        _req(bias.numel() == N, "linear_fwd: bias size")
         kw["bias"] = _p(bias)
     if epi == EPI_RESID:
         _chk(resid, name="resid")
-        if resid.shape != out.shape:
-            raise ValueError("linear_fwd: residual shape")
+        _req(resid.shape == out.shape, "linear_fwd: residual shape")
         kw.update(resid=_p(resid), ldr=N, res_scale=float(res_scale))
     if out_pre is not None:
         _chk(out_pre, name="out_pre")
-        if out_pre.shape != out.shape:
-            raise ValueError("linear_fwd: out_pre shape")
+        _req(out_pre.shape == out.shape, "linear_fwd: out_pre shape")
         kw.update(out_pre=_p(out_pre), ldpre=N)
     _gemm(**kw)
     return out
 
 
-def linear_bwd_data(dy, w, *, epi=EPI_STORE, act=None, aux=None, alpha=1.0, drop_p=0.0, drop_seed=0,
+def linear_bwd_data(dy, w, *, epi=EPI_STORE, act=None, aux=None, alpha=1.0, drop: Drop = NO_DROP,
                     taps=1, T=0, out=None):
     """dx[M, K] = epi(alpha * dy[M, N] @ w) with w [N, K] (or [taps, N, Kper], transposed conv)."""
     _chk(dy, name="dy"); _chk(w, name="w")
     M, N = _rows(dy), dy.shape[-1]
     if taps == 1:
-        if w.shape[0] != N:
-            raise ValueError("linear_bwd_data: dy columns != w rows")
+        _req(w.dim() == 2 and w.shape[0] == N, "linear_bwd_data: dy columns != w rows")
         K = w.shape[1]
     else:
-        if w.dim() != 3 or w.shape[0] != taps or w.shape[1] != N or M % T:
-            raise ValueError("linear_bwd_data: conv weight must be [taps, N, Kper]")
+        _req(w.dim() == 3 and w.shape[0] == taps and w.shape[1] == N and T > 0 and M % T == 0,
+             "linear_bwd_data: conv weight must be [taps, N, Kper]")
         K = w.shape[2]
     if out is None:
         out = torch.empty(*dy.shape[:-1], K, device=dy.device, dtype=torch.float32)
     _chk(out, name="out")
-    if _rows(out) != M or out.shape[-1] != K:
-        raise ValueError("linear_bwd_data: bad output shape")
+    _req(_rows(out) == M and out.shape[-1] == K, "linear_bwd_data: bad output shape")
     kw = dict(A=_p(dy), B=_p(w), C=_p(out), Mc=M, Nc=K, R=N * taps, lda=N, ldb=K, ldc=K,
               a_kcontig=1, b_kcontig=0, taps=taps, T=T, tap_mul=-1, tap_add=(taps - 1) // 2, shift_operand=0,
               b_tap_stride=N * K, epi=epi, act=_ACT[act], alpha=float(alpha),
-              drop_p=float(drop_p), drop_seed=int(drop_seed))
+              drop_p=drop.p, drop_seed=drop.seed, drop_step=drop.step_ptr)
     if epi == EPI_DACT:
         _chk(aux, name="aux")
-        if aux.shape != out.shape:
-            raise ValueError("linear_bwd_data: aux shape")
+        _req(aux.shape == out.shape, "linear_bwd_data: aux shape")
         kw.update(aux=_p(aux), ldaux=K)
     _gemm(**kw)
     return out
-
-
-_WS = {}
-
-
-def _workspace(n: int, device) -> torch.Tensor:
-    """Split-K slab workspace, grown on demand and reused (stream-ordered reuse is safe: every
-    user finishes with a reduce on the same stream before the next GEMM writes it)."""
-    key = (device, torch.cuda.current_stream().cuda_stream)
-    ws = _WS.get(key)
-    if ws is None or ws.numel() < n:
-        ws = torch.empty(max(n, 1 << 22), device=device, dtype=torch.float32)
-        _WS[key] = ws
-    return ws
 
 
 def pick_splitk(Mc: int, Nc: int, R: int, taps: int = 1) -> int:
@@ -203,23 +261,19 @@ def linear_bwd_weight(dy, x, out, *, taps=1, T=0):
     Written into ``out`` (a view of the flat gradient buffer)."""
     _chk(dy, name="dy"); _chk(x, name="x"); _chk(out, name="out")
     M, N, K = _rows(dy), dy.shape[-1], x.shape[-1]
-    if _rows(x) != M:
-        raise ValueError("linear_bwd_weight: row mismatch")
-    if out.numel() != taps * N * K:
-        raise ValueError("linear_bwd_weight: bad gradient shape")
-    if taps > 1 and M % T:
-        raise ValueError("linear_bwd_weight: rows must be a multiple of T")
+    _req(_rows(x) == M, "linear_bwd_weight: row mismatch")
+    _req(out.numel() == taps * N * K, "linear_bwd_weight: bad gradient shape")
+    _req(taps == 1 or (T > 0 and M % T == 0), "linear_bwd_weight: rows must be a multiple of T")
     S = pick_splitk(N, K, M, taps)
     kw = dict(A=_p(dy), B=_p(x), C=_p(out), Mc=N, Nc=K, R=M, lda=N, ldb=K, ldc=K, a_kcontig=0, b_kcontig=0,
-              taps=taps, T=T if taps > 1 else 0, tap_mul=1, tap_add=-((taps - 1) // 2), shift_operand=1 if taps > 1 else 0,
-              c_tap_stride=N * K, splitk=S)
+              taps=taps, T=T if taps > 1 else 0, tap_mul=1, tap_add=-((taps - 1) // 2),
+              shift_operand=1 if taps > 1 else 0, c_tap_stride=N * K, splitk=S)
     if S > 1:
-        ws = _workspace(S * taps * N * K, dy.device)
+        n = taps * N * K
+        ws = _workspace(S * n, dy.device)
         kw["workspace"] = _p(ws)
         _gemm(**kw)
-        n = taps * N * K
-        _ok(lib().fs2hip_reduce_slabs(C.c_void_p(_p(ws)), C.c_void_p(_p(out)), C.c_longlong(n), C.c_int(S),
-                                      C.c_longlong(n), C.c_void_p(_stream())), "reduce_slabs")
+        _ok(lib().fs2hip_reduce_slabs(_p(ws), _p(out), n, S, n, _stream()), "reduce_slabs")
     else:
         _gemm(**kw)
     return out
@@ -229,12 +283,10 @@ def colsum(x, out):
     """out[N] = sum over rows of x[M, N] (bias gradients)."""
     _chk(x, name="x"); _chk(out, name="out")
     M, N = _rows(x), x.shape[-1]
-    if out.numel() != N:
-        raise ValueError("colsum: bad output size")
-    gy = lib().fs2hip_colsum_rows(C.c_int(M))
+    _req(out.numel() == N, "colsum: bad output size")
+    gy = lib().fs2hip_colsum_rows(M)
     ws = _workspace(gy * N, x.device)
-    _ok(lib().fs2hip_colsum(C.c_void_p(_p(x)), C.c_int(N), C.c_int(M), C.c_int(N), C.c_void_p(_p(ws)),
-                            C.c_void_p(_p(out)), C.c_void_p(_stream())), "colsum")
+    _ok(lib().fs2hip_colsum(_p(x), N, M, N, _p(ws), _p(out), _stream()), "colsum")
     return out
 
 
@@ -244,40 +296,322 @@ def colsum(x, out):
 def layernorm_fwd(x, gamma, beta, eps=1e-5):
     _chk(x, name="x"); _chk(gamma, name="gamma"); _chk(beta, name="beta")
     M, Cc = _rows(x), x.shape[-1]
-    if gamma.numel() != Cc or beta.numel() != Cc:
-        raise ValueError("layernorm_fwd: parameter size")
+    _req(gamma.numel() == Cc and beta.numel() == Cc, "layernorm_fwd: parameter size")
     y = torch.empty_like(x)
     mean = torch.empty(M, device=x.device, dtype=torch.float32)
     rstd = torch.empty(M, device=x.device, dtype=torch.float32)
-    _ok(lib().fs2hip_layernorm_fwd(C.c_void_p(_p(x)), C.c_void_p(_p(gamma)), C.c_void_p(_p(beta)), C.c_void_p(_p(y)),
-                                   C.c_void_p(_p(mean)), C.c_void_p(_p(rstd)), C.c_int(M), C.c_int(Cc),
-                                   C.c_float(eps), C.c_void_p(_stream())), "layernorm_fwd")
+    _ok(lib().fs2hip_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, Cc, eps, _stream()),
+        "layernorm_fwd")
     return y, mean, rstd
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dx_add=None):
     """Returns dx (+ dx_add); writes dgamma/dbeta."""
-    for n, t in (("dy", dy), ("x", x), ("gamma", gamma), ("mean", mean), ("rstd", rstd), ("dgamma", dgamma), ("dbeta", dbeta)):
+    for n, t in (("dy", dy), ("x", x), ("gamma", gamma), ("mean", mean), ("rstd", rstd), ("dgamma", dgamma),
+                 ("dbeta", dbeta)):
         _chk(t, name=n)
     M, Cc = _rows(x), x.shape[-1]
-    if dy.shape != x.shape or mean.numel() != M or rstd.numel() != M or dgamma.numel() != Cc or dbeta.numel() != Cc:
-        raise ValueError("layernorm_bwd: shape mismatch")
+    _req(dy.shape == x.shape and mean.numel() == M and rstd.numel() == M and dgamma.numel() == Cc
+         and dbeta.numel() == Cc, "layernorm_bwd: shape mismatch")
     if dx_add is not None:
         _chk(dx_add, name="dx_add")
-        if dx_add.shape != x.shape:
-            raise ValueError("layernorm_bwd: dx_add shape")
+        _req(dx_add.shape == x.shape, "layernorm_bwd: dx_add shape")
     dx = torch.empty_like(x)
-    nblk = lib().fs2hip_layernorm_bwd_blocks(C.c_int(M))
+    nblk = lib().fs2hip_layernorm_bwd_blocks(M)
     ws = _workspace(nblk * 2 * Cc, x.device)
-    _ok(lib().fs2hip_layernorm_bwd(C.c_void_p(_p(dy)), C.c_void_p(_p(x)), C.c_void_p(_p(gamma)), C.c_void_p(_p(mean)),
-                                   C.c_void_p(_p(rstd)), C.c_void_p(_p(dx_add)), C.c_void_p(_p(dx)), C.c_void_p(_p(ws)),
-                                   C.c_void_p(_p(dgamma)), C.c_void_p(_p(dbeta)), C.c_int(M), C.c_int(Cc),
-                                   C.c_void_p(_stream())), "layernorm_bwd")
+    _ok(lib().fs2hip_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx_add), _p(dx), _p(ws),
+                                   _p(dgamma), _p(dbeta), M, Cc, _stream()), "layernorm_bwd")
     return dx
 
 
-#: every symbol include/fs2hip.h declares (checked by tests/test_abi.py)
-EXPORTS = [
-    "fs2hip_version", "fs2hip_gemm", "fs2hip_reduce_slabs", "fs2hip_colsum_rows", "fs2hip_colsum",
-    "fs2hip_layernorm_fwd", "fs2hip_layernorm_bwd_blocks", "fs2hip_layernorm_bwd",
-]
+# ------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------
+def attention_fwd(qkv, lens, B, T, H, drop: Drop = NO_DROP):
+    _chk(qkv, name="qkv"); _chk(lens, torch.int32, "lens")
+    D = qkv.shape[-1] // 3
+    _req(_rows(qkv) == B * T and qkv.shape[-1] == 3 * D and D % H == 0 and lens.numel() == B,
+         "attention_fwd: shape mismatch")
+    o = torch.empty(B, T, D, device=qkv.device, dtype=torch.float32)
+    lse = torch.empty(B, H, T, device=qkv.device, dtype=torch.float32)
+    _ok(lib().fs2hip_attention_fwd(_p(qkv), _p(lens), _p(o), _p(lse), B, T, H, D // H, drop.p, drop.seed,
+                                   drop.step_ptr, _stream()), "attention_fwd")
+    return o, lse
+
+
+def attention_bwd(qkv, lens, o, dout, lse, B, T, H, drop: Drop = NO_DROP):
+    for n, t in (("qkv", qkv), ("o", o), ("dout", dout), ("lse", lse)):
+        _chk(t, name=n)
+    _chk(lens, torch.int32, "lens")
+    D = qkv.shape[-1] // 3
+    _req(_rows(qkv) == B * T and o.numel() == B * T * D and dout.numel() == B * T * D and lse.numel() == B * H * T
+         and lens.numel() == B, "attention_bwd: shape mismatch")
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty_like(lse)
+    _ok(lib().fs2hip_attention_bwd(_p(qkv), _p(lens), _p(o), _p(dout), _p(lse), _p(delta), _p(dqkv), B, T, H, D // H,
+                                   drop.p, drop.seed, drop.step_ptr, _stream()), "attention_bwd")
+    return dqkv
+
+
+# ------------------------------------------------------------------------------------------
+# depthwise conv (+GLU, +BN statistics) and BatchNorm
+# ------------------------------------------------------------------------------------------
+def dwconv_fwd(x, w, bias, B, T, *, glu=False, stats=False):
+    """x [B*T, C or 2C] -> y [B, T, C]; w [K, C].  Returns (y, partial or None, nparts)."""
+    _chk(x, name="x"); _chk(w, name="w")
+    K, Cc = w.shape
+    ldx = x.shape[-1]
+    _req(_rows(x) == B * T and ldx == (2 * Cc if glu else Cc), "dwconv_fwd: shape mismatch")
+    if bias is not None:
+        _chk(bias, name="bias")
+        _req(bias.numel() == Cc, "dwconv_fwd: bias size")
+    y = torch.empty(B, T, Cc, device=x.device, dtype=torch.float32)
+    nparts = lib().fs2hip_dwconv_blocks(B, T)
+    partial = torch.empty(nparts, 2, Cc, device=x.device, dtype=torch.float32) if stats else None
+    _ok(lib().fs2hip_dwconv_fwd(_p(x), ldx, _p(w), _p(bias), _p(y), _p(partial), B, T, Cc, K, int(glu), int(stats),
+                                _stream()), "dwconv_fwd")
+    return y, partial, nparts
+
+
+def dwconv_bwd(dy, x, w, dw, dbias, B, T, *, glu=False):
+    """Returns dx (layout of x); writes dw [K, C] and dbias [C]."""
+    _chk(dy, name="dy"); _chk(x, name="x"); _chk(w, name="w"); _chk(dw, name="dw")
+    K, Cc = w.shape
+    ldx = x.shape[-1]
+    _req(_rows(x) == B * T and ldx == (2 * Cc if glu else Cc) and dy.numel() == B * T * Cc and dw.numel() == K * Cc,
+         "dwconv_bwd: shape mismatch")
+    if dbias is not None:
+        _chk(dbias, name="dbias")
+        _req(dbias.numel() == Cc, "dwconv_bwd: dbias size")
+    dx = torch.empty_like(x)
+    nblk = lib().fs2hip_dwconv_blocks(B, T)
+    ws = _workspace(nblk * (K + 1) * Cc, x.device)
+    _ok(lib().fs2hip_dwconv_bwd(_p(dy), _p(x), ldx, _p(w), _p(dx), _p(ws), _p(dw), _p(dbias), B, T, Cc, K, int(glu),
+                                _stream()), "dwconv_bwd")
+    return dx
+
+
+def colstats(y):
+    _chk(y, name="y")
+    M, Cc = _rows(y), y.shape[-1]
+    nparts = lib().fs2hip_colstats_parts(M)
+    partial = torch.empty(nparts, 2, Cc, device=y.device, dtype=torch.float32)
+    _ok(lib().fs2hip_colstats(_p(y), M, Cc, _p(partial), _stream()), "colstats")
+    return partial, nparts
+
+
+def bn_finalize(partial, nparts, count, gamma, beta, running_mean, running_var, *, momentum=0.1, eps=1e-5,
+                training=True):
+    """Returns stats [4, C] = (scale, shift, mean, invstd); updates the running buffers when training."""
+    _chk(gamma, name="gamma"); _chk(beta, name="beta")
+    Cc = gamma.numel()
+    if training:
+        _chk(partial, name="partial")
+        _req(partial.numel() >= nparts * 2 * Cc, "bn_finalize: partial too small")
+    if running_mean is not None:
+        _chk(running_mean, name="running_mean"); _chk(running_var, name="running_var")
+        _req(running_mean.numel() == Cc and running_var.numel() == Cc, "bn_finalize: running stats size")
+    stats = torch.empty(4, Cc, device=gamma.device, dtype=torch.float32)
+    _ok(lib().fs2hip_bn_finalize(_p(partial), nparts, count, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                                 momentum, eps, int(training), _p(stats), Cc, _stream()), "bn_finalize")
+    return stats
+
+
+def bn_act_fwd(y, stats, act=None, drop: Drop = NO_DROP):
+    _chk(y, name="y"); _chk(stats, name="stats")
+    M, Cc = _rows(y), y.shape[-1]
+    _req(stats.numel() == 4 * Cc, "bn_act_fwd: stats size")
+    out = torch.empty_like(y)
+    _ok(lib().fs2hip_bn_act_fwd(_p(y), _p(stats), _p(out), M, Cc, _ACT[act], drop.p, drop.seed, drop.step_ptr,
+                                _stream()), "bn_act_fwd")
+    return out
+
+
+def bn_act_bwd(dout, y, stats, dgamma, dbeta, act=None, drop: Drop = NO_DROP, training=True):
+    for n, t in (("dout", dout), ("y", y), ("stats", stats), ("dgamma", dgamma), ("dbeta", dbeta)):
+        _chk(t, name=n)
+    M, Cc = _rows(y), y.shape[-1]
+    _req(dout.shape == y.shape and stats.numel() == 4 * Cc and dgamma.numel() == Cc and dbeta.numel() == Cc,
+         "bn_act_bwd: shape mismatch")
+    nparts = lib().fs2hip_colstats_parts(M)
+    ws = _workspace(nparts * 2 * Cc + 2 * Cc, y.device)
+    coef_ptr = ws.data_ptr() + 4 * nparts * 2 * Cc
+    dy = torch.empty_like(y)
+    _ok(lib().fs2hip_bn_act_bwd(_p(dout), _p(y), _p(stats), _p(ws), coef_ptr, _p(dgamma), _p(dbeta), _p(dy), M,
+                                Cc, _ACT[act], drop.p, drop.seed, drop.step_ptr, int(training), _stream()),
+        "bn_act_bwd")
+    return dy
+
+
+# ------------------------------------------------------------------------------------------
+# positional table, embeddings, bucketize
+# ------------------------------------------------------------------------------------------
+def posenc_table(inv_freq, T, D):
+    _chk(inv_freq, name="inv_freq")
+    _req(inv_freq.numel() == D // 2, "posenc_table: inv_freq size")
+    table = torch.empty(T, D, device=inv_freq.device, dtype=torch.float32)
+    _ok(lib().fs2hip_posenc_table(_p(inv_freq), _p(table), T, D, _stream()), "posenc_table")
+    return table
+
+
+def add_posenc(x, table, lens, B, T):
+    _chk(x, name="x"); _chk(table, name="table"); _chk(lens, torch.int32, "lens")
+    D = x.shape[-1]
+    _req(_rows(x) == B * T and table.shape[-1] == D and table.shape[0] >= T and lens.numel() == B,
+         "add_posenc: shape mismatch")
+    out = torch.empty_like(x)
+    _ok(lib().fs2hip_add_posenc(_p(x), _p(table), _p(lens), _p(out), B, T, D, _stream()), "add_posenc")
+    return out
+
+
+def embedding_fwd(idx, W):
+    _chk(idx, torch.int32, "idx"); _chk(W, name="W")
+    V, D = W.shape
+    out = torch.empty(*idx.shape, D, device=W.device, dtype=torch.float32)
+    _ok(lib().fs2hip_embedding_fwd(_p(idx), _p(W), _p(out), idx.numel(), V, D, _stream()), "embedding_fwd")
+    return out
+
+
+def embedding_bwd(idx, dy, dW, padding_idx=-1):
+    _chk(idx, torch.int32, "idx"); _chk(dy, name="dy"); _chk(dW, name="dW")
+    V, D = dW.shape
+    _req(_rows(dy) == idx.numel() and dy.shape[-1] == D, "embedding_bwd: shape mismatch")
+    _ok(lib().fs2hip_embedding_bwd(_p(idx), _p(dy), _p(dW), idx.numel(), V, D, padding_idx, _stream()),
+        "embedding_bwd")
+    return dW
+
+
+def bucket_embed_add(val, bins, W, x, control=1.0):
+    """x + W[bucketize(val * control, bins)] ; returns (out, idx int32)."""
+    _chk(val, name="val"); _chk(bins, name="bins"); _chk(W, name="W"); _chk(x, name="x")
+    M, D = _rows(x), x.shape[-1]
+    _req(val.numel() == M and W.shape[1] == D and W.shape[0] >= bins.numel() + 1, "bucket_embed_add: shape mismatch")
+    out = torch.empty_like(x)
+    idx = torch.empty(val.shape, device=x.device, dtype=torch.int32)
+    _ok(lib().fs2hip_bucket_embed_add(_p(val), control, _p(bins), bins.numel(), _p(W), _p(x), _p(out), _p(idx), M, D,
+                                      _stream()), "bucket_embed_add")
+    return out, idx
+
+
+# ------------------------------------------------------------------------------------------
+# LengthRegulator, predictor head, losses
+# ------------------------------------------------------------------------------------------
+def length_regulate_fwd(x, dur, Tm, table=None):
+    """x [B, Ts, D], dur [B, Ts] int32 -> (out [B, Tm, D], cum, out_lens [B] int32)."""
+    _chk(x, name="x"); _chk(dur, torch.int32, "dur")
+    B, Ts, D = x.shape
+    _req(dur.shape == (B, Ts) and Tm > 0, "length_regulate_fwd: shape mismatch")
+    if table is not None:
+        _chk(table, name="table")
+        _req(table.shape[0] >= Tm and table.shape[1] == D, "length_regulate_fwd: table too short")
+    out = torch.empty(B, Tm, D, device=x.device, dtype=torch.float32)
+    cum = torch.empty(B, Ts, device=x.device, dtype=torch.int32)
+    lens = torch.empty(B, device=x.device, dtype=torch.int32)
+    _ok(lib().fs2hip_length_regulate_fwd(_p(x), _p(dur), _p(table), _p(out), _p(cum), _p(lens), None, B, Ts, Tm, D,
+                                         _stream()), "length_regulate_fwd")
+    return out, cum, lens
+
+
+def length_regulate_bwd(dy, cum):
+    _chk(dy, name="dy"); _chk(cum, torch.int32, "cum")
+    B, Tm, D = dy.shape
+    Ts = cum.shape[1]
+    _req(cum.shape[0] == B, "length_regulate_bwd: shape mismatch")
+    dx = torch.empty(B, Ts, D, device=dy.device, dtype=torch.float32)
+    _ok(lib().fs2hip_length_regulate_bwd(_p(dy), _p(cum), _p(dx), B, Ts, Tm, D, _stream()), "length_regulate_bwd")
+    return dx
+
+
+def rowdot_fwd(x, w, bias, lens, B, T):
+    _chk(x, name="x"); _chk(w, name="w"); _chk(bias, name="bias"); _chk(lens, torch.int32, "lens")
+    Cc = x.shape[-1]
+    _req(_rows(x) == B * T and w.numel() == Cc and bias.numel() == 1 and lens.numel() == B, "rowdot_fwd: shape mismatch")
+    out = torch.empty(B, T, device=x.device, dtype=torch.float32)
+    _ok(lib().fs2hip_rowdot_fwd(_p(x), _p(w), _p(bias), _p(lens), _p(out), B * T, T, Cc, _stream()), "rowdot_fwd")
+    return out
+
+
+def rowdot_bwd(dout, x, w, lens, dw, dbias, B, T):
+    for n, t in (("dout", dout), ("x", x), ("w", w), ("dw", dw), ("dbias", dbias)):
+        _chk(t, name=n)
+    _chk(lens, torch.int32, "lens")
+    Cc = x.shape[-1]
+    _req(_rows(x) == B * T and dout.numel() == B * T and w.numel() == Cc and dw.numel() == Cc and dbias.numel() == 1,
+         "rowdot_bwd: shape mismatch")
+    dx = torch.empty_like(x)
+    nblk = lib().fs2hip_rowdot_blocks(B * T)
+    ws = _workspace(nblk * (Cc + 1), x.device)
+    _ok(lib().fs2hip_rowdot_bwd(_p(dout), _p(x), _p(w), _p(lens), _p(dx), _p(ws), _p(dw), _p(dbias), B * T, T, Cc,
+                                _stream()), "rowdot_bwd")
+    return dx
+
+
+def masked_loss(pred, target, lens, B, T, Cc, *, kind="mse", weight=1.0, loss_out, want_grad=True):
+    """loss_out (1-element view) = weight * mean(f((pred - target) * mask)); returns d/dpred or None.
+    An int32 ``target`` is a duration: the loss uses log(target + 1)."""
+    _chk(pred, name="pred"); _chk(lens, torch.int32, "lens"); _chk(loss_out, name="loss_out")
+    _req(pred.numel() == B * T * Cc and target.numel() == B * T * Cc and lens.numel() == B and loss_out.numel() == 1,
+         "masked_loss: shape mismatch")
+    tf = ti = None
+    if target.dtype == torch.int32:
+        ti = _chk(target, torch.int32, "target")
+    else:
+        tf = _chk(target, name="target")
+    dpred = torch.empty_like(pred) if want_grad else None
+    ws = _workspace(1024, pred.device)
+    _ok(lib().fs2hip_masked_loss(_p(pred), _p(tf), _p(ti), _p(lens), B, T, Cc, 0 if kind == "mse" else 1, weight,
+                                 _p(dpred), _p(ws), _p(loss_out), _stream()), "masked_loss")
+    return dpred
+
+
+# ------------------------------------------------------------------------------------------
+# optimizer and elementwise
+# ------------------------------------------------------------------------------------------
+def new_step_state(device) -> torch.Tensor:
+    """32-byte device record {uint64 step; float lr, bc1, bc2, clip_coef, grad_norm, pad} as 4 x int64."""
+    st = torch.zeros(4, device=device, dtype=torch.int64)
+    st.view(torch.float32)[5] = 1.0  # clip_coef
+    return st
+
+
+def step_advance(state, base_lr, warmup, beta1, beta2):
+    _chk(state, torch.int64, "state")
+    _ok(lib().fs2hip_step_advance(_p(state), base_lr, float(warmup), beta1, beta2, _stream()), "step_advance")
+
+
+def grad_clip_coef(grad, max_norm, grad_scale, state):
+    _chk(grad, name="grad"); _chk(state, torch.int64, "state")
+    ws = _workspace(1024, grad.device)
+    _ok(lib().fs2hip_grad_clip_coef(_p(grad), grad.numel(), float(max_norm), float(grad_scale), _p(ws), _p(state),
+                                    _stream()), "grad_clip_coef")
+
+
+def adamw_step(p, g, m, v, state, beta1, beta2, eps, weight_decay):
+    for n, t in (("p", p), ("g", g), ("m", m), ("v", v)):
+        _chk(t, name=n)
+    _chk(state, torch.int64, "state")
+    _req(p.numel() == g.numel() == m.numel() == v.numel(), "adamw_step: size mismatch")
+    _ok(lib().fs2hip_adamw_step(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(state), beta1, beta2, eps, weight_decay,
+                                _stream()), "adamw_step")
+
+
+def axpby(x, y=None, a=1.0, b=1.0, drop: Drop = NO_DROP, out=None):
+    _chk(x, name="x")
+    if y is not None:
+        _chk(y, name="y")
+        _req(y.numel() == x.numel(), "axpby: size mismatch")
+    if out is None:
+        out = torch.empty_like(x)
+    _chk(out, name="out")
+    _ok(lib().fs2hip_axpby(_p(x), _p(y), _p(out), x.numel(), a, b, drop.p, drop.seed, drop.step_ptr, _stream()),
+        "axpby")
+    return out
+
+
+def add_rowvec(x, e, B, T):
+    _chk(x, name="x"); _chk(e, name="e")
+    D = x.shape[-1]
+    _req(_rows(x) == B * T and e.numel() == B * D, "add_rowvec: shape mismatch")
+    out = torch.empty_like(x)
+    _ok(lib().fs2hip_add_rowvec(_p(x), _p(e), _p(out), B, T, D, _stream()), "add_rowvec")
+    return out

@@ -6,6 +6,10 @@
  * reference call site(s) (file:line, relative to the reference checkout) whose
  * ATen ops it replaces.  INTEGRATION.md shows the ctypes binding.
  *
+ * Dropout: keep-mask = hash(seed + *drop_step * c, element index) >= p * 2^32, regenerated
+ * (never stored) by the backward kernels; `drop_step` is a device-resident counter so that a
+ * captured hipGraph draws a fresh mask on every replay.
+ *
  * Conventions (all entry points):
  *   - raw device pointers into caller-owned dense row-major buffers; activations
  *     are (B, T, C) = matrices of B*T rows and C contiguous columns, fp32;
@@ -82,6 +86,7 @@ typedef struct {
   int ldpre;
   float drop_p;
   unsigned long long drop_seed;
+  const unsigned long long* drop_step; /* device step counter mixed into the seed, or NULL */
   int splitk;
   float* workspace;
 } Fs2GemmArgs;
@@ -109,6 +114,119 @@ int fs2hip_layernorm_bwd_blocks(int M);
 int fs2hip_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                          const float* rstd, const float* dx_add, float* dx, float* partial,
                          float* dgamma, float* dbeta, int M, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Multi-head self-attention with key-padding mask (flash style; fp32 MFMA 16x16x4).
+ * Replaces nn.MultiheadAttention's scaled-dot-product core inside torchaudio's
+ * ConformerLayer (call sites fs2/model.py:193, :241).
+ *   qkv  [B*T][3*H*HD]  in_proj output (q | k | v);  lens [B] int32 (keys >= lens[b] masked)
+ *   o    [B*T][H*HD];   lse [B][H][T] (log-sum-exp per query, saved for the backward)
+ *   dropout acts on the normalised probabilities (attention dropout), mask regenerated
+ *   from (seed, b, h, q, k) in the backward.  HD in {16, 32, 64, 128}.
+ * bwd: delta [B][H][T] scratch; dqkv [B*T][3*H*HD] fully written.
+ * ------------------------------------------------------------------------------------ */
+int fs2hip_attention_fwd(const float* qkv, const int* lens, float* o, float* lse, int B, int T, int H,
+                         int HD, float drop_p, unsigned long long drop_seed,
+                         const unsigned long long* drop_step, void* stream);
+int fs2hip_attention_bwd(const float* qkv, const int* lens, const float* o, const float* dout,
+                         const float* lse, float* delta, float* dqkv, int B, int T, int H, int HD,
+                         float drop_p, unsigned long long drop_seed,
+                         const unsigned long long* drop_step, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Depthwise Conv1d over time on (B, T, C), 'same' padding, K in {3,5,7,9,15,31}; w is [K][C].
+ * glu = 1: the input has 2C columns (value | gate) and a = value * sigmoid(gate) is formed on
+ * the fly (torchaudio conv module: Conv1d(D,2D,1) -> GLU -> depthwise Conv1d).
+ * stats = 1: also writes per-workgroup (sum, sum of squares) per channel for BatchNorm:
+ *            partial[fs2hip_dwconv_blocks(B,T)][2][C].
+ * Also the depthwise half of fs2/blocks.py:8-13.
+ * bwd: dx has the layout of x; partial [blocks][K+1][C]; dw [K][C] and dbias [C] are finished.
+ * ------------------------------------------------------------------------------------ */
+int fs2hip_dwconv_blocks(int B, int T);
+int fs2hip_dwconv_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, float* partial,
+                      int B, int T, int C, int K, int glu, int stats, void* stream);
+int fs2hip_dwconv_bwd(const float* dy, const float* x, int ldx, const float* w, float* dx, float* partial,
+                      float* dw, float* dbias, int B, int T, int C, int K, int glu, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * BatchNorm1d over the channels of [M][C] (+ activation + dropout), fs2/layers.py:204-212 and
+ * the Conformer conv module.  stats is [4][C]: scale, shift, mean, invstd.
+ *   colstats   : partial[fs2hip_colstats_parts(M)][2][C] = per-stripe (sum, sum sq)
+ *   finalize   : training: batch statistics (fp64 finish) + running-stat update (momentum,
+ *                unbiased variance); eval: running statistics
+ *   bn_act_fwd : out = dropout(act(y*scale + shift))
+ *   bn_act_bwd : dy (grad of y), dgamma, dbeta; partial as colstats, coef [2][C] scratch
+ * ------------------------------------------------------------------------------------ */
+int fs2hip_colstats_parts(int M);
+int fs2hip_colstats(const float* y, int M, int C, float* partial, void* stream);
+int fs2hip_bn_finalize(const float* partial, int nparts, long long count, const float* gamma,
+                       const float* beta, float* running_mean, float* running_var, float momentum,
+                       float eps, int training, float* stats, int C, void* stream);
+int fs2hip_bn_act_fwd(const float* y, const float* stats, float* out, int M, int C, int act, float drop_p,
+                      unsigned long long drop_seed, const unsigned long long* drop_step, void* stream);
+int fs2hip_bn_act_bwd(const float* dout, const float* y, const float* stats, float* partial, float* coef,
+                      float* dgamma, float* dbeta, float* dy, int M, int C, int act, float drop_p,
+                      unsigned long long drop_seed, const unsigned long long* drop_step, int training,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Positional table / embeddings / bucketize  (fs2/layers.py:123-140, fs2/model.py:183-193,
+ * :233-241, fs2/variance_adaptor.py:197-205)
+ * ------------------------------------------------------------------------------------ */
+int fs2hip_posenc_table(const float* inv_freq, float* table, int T, int D, void* stream);
+int fs2hip_add_posenc(const float* x, const float* table, const int* lens, float* out, int B, int T, int D,
+                      void* stream);
+int fs2hip_embedding_fwd(const int* idx, const float* W, float* out, int M, int V, int D, void* stream);
+int fs2hip_embedding_bwd(const int* idx, const float* dy, float* dW, int M, int V, int D, int padding_idx,
+                         void* stream);
+/* out = x + W[lower_bound(bins, val*control)]; idx_out (int32, bit-exact vs torch.bucketize) optional */
+int fs2hip_bucket_embed_add(const float* val, float control, const float* bins, int NB, const float* W,
+                            const float* x, float* out, int* idx_out, int M, int D, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * LengthRegulator (fs2/variance_adaptor.py:65-81): out[b, t] = x[b, j] for the token j whose
+ * duration segment contains frame t (zero rows past the total), bit-exact indexing.
+ *   cum [B][Ts] inclusive cumulative durations (written), out_lens [B] = min(total, Tm),
+ *   src_idx [B][Tm] source token or -1 (optional), posenc_table [>=Tm][D] added on valid frames
+ *   (optional: fuses fs2/model.py:233-241).
+ * bwd: dx[b, j] = sum of dy over the token's frame segment (contiguous, no atomics).
+ * ------------------------------------------------------------------------------------ */
+int fs2hip_length_regulate_fwd(const float* x, const int* dur, const float* posenc_table, float* out,
+                               int* cum, int* out_lens, int* src_idx, int B, int Ts, int Tm, int D,
+                               void* stream);
+int fs2hip_length_regulate_bwd(const float* dy, const int* cum, float* dx, int B, int Ts, int Tm, int D,
+                               void* stream);
+
+/* predictor head (fs2/variance_adaptor.py:53-62): out[m] = (x[m,:].w + b) * (t < lens[b]) */
+int fs2hip_rowdot_fwd(const float* x, const float* w, const float* bias, const int* lens, float* out, int M,
+                      int T, int C, void* stream);
+int fs2hip_rowdot_blocks(int M);
+int fs2hip_rowdot_bwd(const float* dout, const float* x, const float* w, const int* lens, float* dx,
+                      float* partial, float* dw, float* dbias, int M, int T, int C, void* stream);
+
+/* masked MSE (kind 0) / MAE (kind 1) of fs2/loss.py:44-106 with its padded-mean denominator;
+ * tgt_int != NULL: target = log(tgt_int + 1) (duration loss).  Writes loss_out[0] and, if
+ * dpred != NULL, d(loss)/d(pred).  partial: >= 1024 floats. */
+int fs2hip_masked_loss(const float* pred, const float* tgt, const int* tgt_int, const int* lens, int B, int T,
+                       int C, int kind, float weight, float* dpred, float* partial, float* loss_out,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Optimizer (fs2/model.py:530-549 AdamW + fs2/noam.py:20-26 + clip of fs2/cli/train.py:38).
+ * `state` is a 32-byte device record { uint64 step; float lr, bc1, bc2, clip_coef, grad_norm, pad }
+ * advanced on the device so that a captured hipGraph needs no new arguments per step; its first
+ * 8 bytes double as the `drop_step` counter of the dropout kernels.
+ * ------------------------------------------------------------------------------------ */
+int fs2hip_step_advance(void* state, float base_lr, float warmup, float beta1, float beta2, void* stream);
+int fs2hip_grad_clip_coef(const float* grad, long long n, float max_norm, float grad_scale, float* partial,
+                          void* state, void* stream);
+int fs2hip_adamw_step(float* p, const float* g, float* m, float* v, long long n, const void* state,
+                      float beta1, float beta2, float eps, float weight_decay, void* stream);
+
+/* out = a * x * dropmask + b * y (y may be NULL);  out[b,t,:] = x[b,t,:] + e[b,:] */
+int fs2hip_axpby(const float* x, const float* y, float* out, long long n, float a, float b, float drop_p,
+                 unsigned long long drop_seed, const unsigned long long* drop_step, void* stream);
+int fs2hip_add_rowvec(const float* x, const float* e, float* out, int B, int T, int D, void* stream);
 
 #ifdef __cplusplus
 }

@@ -96,16 +96,17 @@ def test_dropout_epilogue_statistics_and_replay(H):
     M, N, K = 512, 256, 64
     x, w = rnd(M, K, seed=1), rnd(N, K, seed=2)
     y0 = H.linear_fwd(x.cuda(), w.cuda())
-    y1 = H.linear_fwd(x.cuda(), w.cuda(), epi=H.EPI_ACT, act="none", drop_p=0.2, drop_seed=77)
-    y2 = H.linear_fwd(x.cuda(), w.cuda(), epi=H.EPI_ACT, act="none", drop_p=0.2, drop_seed=77)
+    y1 = H.linear_fwd(x.cuda(), w.cuda(), epi=H.EPI_ACT, act="none", drop=H.Drop(0.2, 77))
+    y2 = H.linear_fwd(x.cuda(), w.cuda(), epi=H.EPI_ACT, act="none", drop=H.Drop(0.2, 77))
     assert torch.equal(y1, y2)  # same seed -> same mask (the backward regenerates it)
     kept = (y1 != 0).float().mean().item()
     assert abs(kept - 0.8) < 0.01
     m = y1 != 0
     close(y1[m], y0[m] / 0.8, K, "scaled survivors")
     # the same mask multiplies the gradient in EPI_DACT
-    g = H.linear_bwd_data(torch.ones(M, K, device="cuda"), torch.eye(K, N, device="cuda"),
-                          epi=H.EPI_DACT, act="none", aux=torch.zeros(M, N, device="cuda"), drop_p=0.2, drop_seed=77)
+    g = H.linear_bwd_data(torch.ones(M, K, device="cuda"), torch.ones(K, N, device="cuda"),
+                          epi=H.EPI_DACT, act="none", aux=torch.zeros(M, N, device="cuda"), drop=H.Drop(0.2, 77))
+    assert torch.equal(g != 0, y1 != 0)
     assert g.shape == (M, N)
 
 

@@ -1,0 +1,240 @@
+"""GPU parity of the conv / BatchNorm / gather / loss / optimizer kernels against plain
+PyTorch fp32 references (integer outputs bit-exact, floats at ~1e-5 of scale)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def H():
+    from fastspeech2_lightning_amd import hip
+    hip.lib()
+    return hip
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def close(a, b, tol=2e-5, msg=""):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    scale = max(float(b.abs().max()), 1e-6)
+    err = float((a - b).abs().max()) / scale
+    assert err < tol, f"{msg}: rel err {err:.3e}"
+
+
+@pytest.mark.parametrize("K,C,glu", [(9, 256, True), (3, 256, False), (9, 32, True), (3, 32, False), (5, 80, False)])
+def test_dwconv(H, K, C, glu):
+    B, T = 3, 70
+    x = rnd(B, T, 2 * C if glu else C, seed=1).requires_grad_(True)
+    w = rnd(C, 1, K, seed=2, scale=0.3).requires_grad_(True)
+    b = rnd(C, seed=3).requires_grad_(True)
+    a = F.glu(x, dim=-1) if glu else x
+    ref = F.conv1d(a.transpose(1, 2), w, b, padding=(K - 1) // 2, groups=C).transpose(1, 2)
+    wk = w.detach()[:, 0, :].t().contiguous().cuda()  # [K, C]
+    y, partial, nparts = H.dwconv_fwd(x.detach().cuda(), wk, b.detach().cuda(), B, T, glu=glu, stats=True)
+    close(y, ref, msg="dwconv fwd")
+    close(partial.sum(0)[0], ref.reshape(-1, C).sum(0), 1e-4, "stats sum")
+    close(partial.sum(0)[1], (ref ** 2).reshape(-1, C).sum(0), 1e-4, "stats sumsq")
+    dy = rnd(B, T, C, seed=4)
+    ref.backward(dy)
+    dw, db = torch.empty(K, C, device="cuda"), torch.empty(C, device="cuda")
+    dx = H.dwconv_bwd(dy.cuda(), x.detach().cuda(), wk, dw, db, B, T, glu=glu)
+    close(dx, x.grad, msg="dwconv dx")
+    close(dw, w.grad[:, 0, :].t(), 1e-4, "dwconv dw")
+    close(db, b.grad, 1e-4, "dwconv db")
+
+
+@pytest.mark.parametrize("act,C", [("silu", 256), ("tanh", 512), (None, 80)])
+def test_batchnorm_train_and_eval(H, act, C):
+    M = 1234
+    y = (rnd(M, C, seed=1) * 2 + 0.5).requires_grad_(True)
+    g, b = (1 + 0.1 * rnd(C, seed=2)).requires_grad_(True), rnd(C, seed=3).requires_grad_(True)
+    rm, rv = 0.1 * rnd(C, seed=4), torch.rand(C, generator=torch.Generator().manual_seed(5)) + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    f = {"silu": F.silu, "tanh": torch.tanh, None: lambda t: t}[act]
+    ref = f(F.batch_norm(y, rm_ref, rv_ref, g, b, training=True, momentum=0.1, eps=1e-5))
+    rm_d, rv_d = rm.cuda(), rv.cuda()
+    partial, nparts = H.colstats(y.detach().cuda())
+    stats = H.bn_finalize(partial, nparts, M, g.detach().cuda(), b.detach().cuda(), rm_d, rv_d, training=True)
+    out = H.bn_act_fwd(y.detach().cuda(), stats, act)
+    close(out, ref, msg="bn fwd")
+    close(rm_d, rm_ref, msg="running mean")
+    close(rv_d, rv_ref, msg="running var")
+    dout = rnd(M, C, seed=6)
+    ref.backward(dout)
+    dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    dy = H.bn_act_bwd(dout.cuda(), y.detach().cuda(), stats, dg, db, act)
+    close(dy, y.grad, 5e-5, "bn dy")
+    close(dg, g.grad, 1e-4, "bn dgamma")
+    close(db, b.grad, 1e-4, "bn dbeta")
+    # eval mode uses the running statistics
+    stats_e = H.bn_finalize(None, 0, 0, g.detach().cuda(), b.detach().cuda(), rm_d, rv_d, training=False)
+    out_e = H.bn_act_fwd(y.detach().cuda(), stats_e, act)
+    ref_e = f(F.batch_norm(y.detach(), rm_ref, rv_ref, g.detach(), b.detach(), training=False, eps=1e-5))
+    close(out_e, ref_e, msg="bn eval")
+
+
+def test_posenc_embedding_bucketize(H, golden_dir):
+    g = dict(np.load(golden_dir / "units.npz"))
+    D, T = 8, 7
+    inv_freq = 1 / (10000 ** (torch.arange(0.0, D, 2.0) / D))
+    table = H.posenc_table(inv_freq.cuda(), T, D)
+    np.testing.assert_allclose(table.cpu().numpy(), g["pos/out"][0], rtol=2e-6, atol=2e-7)
+    # masked add
+    B, T, D = 3, 9, 16
+    x = rnd(B, T, D, seed=1)
+    inv = 1 / (10000 ** (torch.arange(0.0, D, 2.0) / D))
+    lens = torch.tensor([9, 4, 1], dtype=torch.int32)
+    tab = H.posenc_table(inv.cuda(), T, D)
+    out = H.add_posenc(x.cuda(), tab, lens.cuda(), B, T)
+    ang = torch.arange(T).float()[:, None] @ inv[None, :]
+    pe = torch.cat([ang.sin(), ang.cos()], 1)
+    mask = torch.arange(T)[None, :] < lens[:, None]
+    close(out, x + pe[None] * mask[..., None], msg="add_posenc")
+    # embedding fwd / bwd with padding row
+    V = 11
+    W = rnd(V, D, seed=2).requires_grad_(True)
+    idx = torch.randint(0, V, (B, T), generator=torch.Generator().manual_seed(3))
+    ref = F.embedding(idx, W, padding_idx=0)
+    out = H.embedding_fwd(idx.int().cuda(), W.detach().cuda())
+    assert torch.equal(out.cpu(), ref.detach())
+    dy = rnd(B, T, D, seed=4)
+    ref.backward(dy)
+    dW = torch.empty(V, D, device="cuda")
+    H.embedding_bwd(idx.int().cuda(), dy.cuda(), dW, padding_idx=0)
+    close(dW, W.grad, msg="embedding bwd")
+    # bucketize: golden vector from the reference's own torch.bucketize call + random
+    bins, v = torch.tensor(g["bucket/bins"]), torch.tensor(g["bucket/v"])
+    emb = rnd(bins.numel() + 1, D, seed=5)
+    xx = rnd(v.numel(), D, seed=6)
+    out, bidx = H.bucket_embed_add(v.cuda(), bins.cuda(), emb.cuda(), xx.cuda())
+    np.testing.assert_array_equal(bidx.cpu().numpy(), g["bucket/out"])
+    assert torch.equal(out.cpu(), xx + emb[torch.tensor(g["bucket/out"])])
+    bins = torch.linspace(-3, 3, 255)
+    v = rnd(5000, seed=7) * 2
+    v[:255] = bins  # exactly on the edges
+    _, bidx = H.bucket_embed_add(v.cuda(), bins.cuda(), rnd(256, D).cuda(), rnd(5000, D).cuda())
+    assert torch.equal(bidx.cpu().long(), torch.bucketize(v, bins))
+
+
+def test_length_regulator(H, golden_dir):
+    g = dict(np.load(golden_dir / "units.npz"))
+    x, dur = torch.tensor(g["lr/x"]), torch.tensor(g["lr/dur"])
+    D = x.shape[-1]
+    x4 = torch.cat([x, torch.zeros(*x.shape[:2], 8 - D)], -1)  # kernel wants D % 4 == 0
+    for tag in ("full", "trunc"):
+        ref, mask = g[f"lr/{tag}/out"], g[f"lr/{tag}/mask"]
+        Tm = ref.shape[1]
+        out, cum, lens = H.length_regulate_fwd(x4.cuda(), dur.cuda(), Tm)
+        np.testing.assert_array_equal(out.cpu().numpy()[..., :D], ref)
+        got_mask = (torch.arange(Tm)[None, :] < lens.cpu()[:, None]).numpy()
+        # reference mask uses the untruncated total; both agree on [0, Tm)
+        np.testing.assert_array_equal(got_mask, mask)
+    # random, with backward vs autograd of repeat_interleave
+    B, Ts, D = 4, 19, 32
+    x = rnd(B, Ts, D, seed=1).requires_grad_(True)
+    dur = torch.randint(0, 6, (B, Ts), generator=torch.Generator().manual_seed(2), dtype=torch.int32)
+    Tm = int(dur.sum(1).max())
+    rows = [torch.repeat_interleave(x[b], dur[b].long(), dim=0) for b in range(B)]
+    ref = torch.zeros(B, Tm, D)
+    for b, r in enumerate(rows):
+        ref[b, : r.shape[0]] = r
+    out, cum, lens = H.length_regulate_fwd(x.detach().cuda(), dur.cuda(), Tm)
+    assert torch.equal(out.cpu(), ref.detach())
+    assert torch.equal(lens.cpu(), dur.sum(1).int())
+    dy = rnd(B, Tm, D, seed=3)
+    ref.backward(dy)
+    dx = H.length_regulate_bwd(dy.cuda(), cum)
+    close(dx, x.grad, msg="lr bwd")
+
+
+def test_rowdot_and_losses(H):
+    B, T, C = 3, 21, 256
+    x = rnd(B, T, C, seed=1).requires_grad_(True)
+    w, b = rnd(1, C, seed=2, scale=0.1).requires_grad_(True), rnd(1, seed=3).requires_grad_(True)
+    lens = torch.tensor([21, 10, 3], dtype=torch.int32)
+    mask = torch.arange(T)[None, :] < lens[:, None]
+    ref = F.linear(x, w, b).squeeze(-1) * mask
+    out = H.rowdot_fwd(x.detach().cuda(), w.detach().cuda(), b.detach().cuda(), lens.cuda(), B, T)
+    close(out, ref, msg="rowdot fwd")
+    tgt = rnd(B, T, seed=4)
+    for kind, fn in (("mse", F.mse_loss), ("mae", F.l1_loss)):
+        for t_ in (x, w, b):
+            t_.grad = None
+        loss = fn(ref * mask, tgt * mask) * 0.1
+        loss.backward(retain_graph=True)
+        slot = torch.zeros(1, device="cuda")
+        dpred = H.masked_loss(out, tgt.cuda(), lens.cuda(), B, T, 1, kind=kind, weight=0.1, loss_out=slot)
+        close(slot, loss.detach().reshape(1), msg=f"{kind} value")
+        dw, db = torch.empty(C, device="cuda"), torch.empty(1, device="cuda")
+        dx = H.rowdot_bwd(dpred, x.detach().cuda(), w.detach().cuda(), lens.cuda(), dw, db, B, T)
+        close(dx, x.grad, msg=f"{kind} dx")
+        close(dw, w.grad.reshape(-1), msg=f"{kind} dw")
+        close(db, b.grad, msg=f"{kind} db")
+    # duration loss: log(d + 1) target; spec loss with channels
+    dur = torch.randint(0, 9, (B, T), generator=torch.Generator().manual_seed(5), dtype=torch.int32)
+    pred = rnd(B, T, seed=6)
+    ref = F.mse_loss(pred * mask, torch.log(dur.float() + 1) * mask) * 0.1
+    slot = torch.zeros(1, device="cuda")
+    H.masked_loss(pred.cuda(), dur.cuda(), lens.cuda(), B, T, 1, weight=0.1, loss_out=slot)
+    close(slot, ref.reshape(1), msg="duration loss")
+    spec, mel = rnd(B, T, 80, seed=7).requires_grad_(True), rnd(B, T, 80, seed=8)
+    ref = F.mse_loss(spec * mask[..., None], mel * mask[..., None])
+    ref.backward()
+    d = H.masked_loss(spec.detach().cuda(), mel.cuda(), lens.cuda(), B, T, 80, loss_out=slot)
+    close(slot, ref.detach().reshape(1), msg="spec loss")
+    close(d, spec.grad, msg="spec grad")
+
+
+def test_adamw_noam_clip(H):
+    n = 100003
+    p0, steps = rnd(n, seed=1), 5
+    p_ref = p0.clone().requires_grad_(True)
+    base_lr, warm, betas, eps, wd = 1e-3, 3, (0.9, 0.98), 1e-8, 0.01
+    opt = torch.optim.AdamW([p_ref], base_lr, betas=betas, eps=eps, weight_decay=wd)
+    p = p0.clone().cuda()
+    m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    st = H.new_step_state("cuda")
+    for k in range(1, steps + 1):
+        gk = rnd(n, seed=10 + k) * (3.0 if k % 2 else 0.001)
+        s = max(1, k - 1)
+        lr = base_lr * warm ** 0.5 * min(s ** -0.5, s * warm ** -1.5)
+        for grp in opt.param_groups:
+            grp["lr"] = lr
+        p_ref.grad = gk.clone()
+        torch.nn.utils.clip_grad_norm_([p_ref], 1.0)
+        opt.step()
+        H.step_advance(st, base_lr, warm, betas[0], betas[1])
+        H.grad_clip_coef(gk.cuda(), 1.0, 1.0, st)
+        H.adamw_step(p, gk.cuda(), m, v, st, betas[0], betas[1], eps, wd)
+        rec = st.cpu()
+        assert int(rec[0]) == k
+        assert abs(float(rec.view(torch.float32)[2]) - lr) < 1e-9
+        assert abs(float(rec.view(torch.float32)[6]) - float(gk.norm())) < 1e-3 * float(gk.norm())
+    close(p, p_ref, 1e-5, "adamw params")
+
+
+def test_axpby_and_rowvec(H):
+    x, y = rnd(1000, seed=1), rnd(1000, seed=2)
+    close(H.axpby(x.cuda(), y.cuda(), 0.5, 2.0), 0.5 * x + 2 * y, msg="axpby")
+    d = H.Drop(0.25, 5)
+    a = H.axpby(x.cuda(), None, 1.0, 0.0, d)
+    b = H.axpby(torch.ones(1000, device="cuda"), None, 1.0, 0.0, d)
+    assert torch.allclose(a, x.cuda() * b)
+    assert abs((b == 0).float().mean().item() - 0.25) < 0.05
+    # the device step counter changes the mask without changing the kernel arguments
+    step = torch.zeros(1, dtype=torch.int64, device="cuda")
+    d2 = H.Drop(0.25, 5, step)
+    m0 = H.axpby(torch.ones(1000, device="cuda"), None, 1.0, 0.0, d2)
+    step += 1
+    m1 = H.axpby(torch.ones(1000, device="cuda"), None, 1.0, 0.0, d2)
+    assert not torch.equal(m0, m1)
+    B, T, D = 2, 5, 8
+    xx, e = rnd(B, T, D, seed=3), rnd(B, D, seed=4)
+    close(H.add_rowvec(xx.cuda(), e.cuda(), B, T), xx + e[:, None], msg="rowvec")
