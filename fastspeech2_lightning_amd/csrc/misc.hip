@@ -327,6 +327,25 @@ __global__ __launch_bounds__(256) void add_rowvec_kernel(const float* __restrict
   }
 }
 
+// out = dy * act'(aux)  (aux = the activation's OUTPUT for ReLU, its input otherwise)
+__global__ __launch_bounds__(256) void dact_mul_kernel(const float* __restrict__ dy, const float* __restrict__ aux,
+                                                        float* __restrict__ out, long long n, int act) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    out[i] = dy[i] * fs2_dact(act, aux[i]);
+}
+
+// fs2/utils/heavy.py:11-15  mask[b][t] = t < lens[b]   (bool as uint8)
+__global__ void mask_from_lens_kernel(const int* __restrict__ lens, unsigned char* __restrict__ mask, int B, int T) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B * T) mask[i] = (i % T) < lens[i / T] ? 1 : 0;
+}
+
+__global__ void sum_slots_kernel(const float* __restrict__ x, int n, float* __restrict__ out) {
+  float s = 0.f;
+  for (int i = 0; i < n; ++i) s += x[i];
+  out[0] = s;
+}
+
 inline unsigned grid_for(long long n, int per_block = 256, long long cap = 4096) {
   long long b = (n + per_block - 1) / per_block;
   if (b > cap) b = cap;
@@ -463,6 +482,27 @@ extern "C" int fs2hip_axpby(const float* x, const float* y, float* out, long lon
   if (n <= 0) return FS2HIP_EINVAL;
   axpby_kernel<<<dim3(grid_for(n, 256, 8192)), dim3(256), 0, S_>>>(x, y, out, n, a, b,
                                                                     fs2_make_drop(drop_p, drop_seed, drop_step));
+  FS2_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fs2hip_dact_mul(const float* dy, const float* aux, float* out, long long n, int act, void* stream) {
+  if (n <= 0) return FS2HIP_EINVAL;
+  dact_mul_kernel<<<dim3(grid_for(n, 256, 8192)), dim3(256), 0, S_>>>(dy, aux, out, n, act);
+  FS2_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fs2hip_mask_from_lens(const int* lens, unsigned char* mask, int B, int T, void* stream) {
+  if (B <= 0 || T <= 0) return FS2HIP_EINVAL;
+  mask_from_lens_kernel<<<dim3((B * T + 255) / 256), dim3(256), 0, S_>>>(lens, mask, B, T);
+  FS2_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fs2hip_sum_slots(const float* x, int n, float* out, void* stream) {
+  if (n <= 0) return FS2HIP_EINVAL;
+  sum_slots_kernel<<<dim3(1), dim3(1), 0, S_>>>(x, n, out);
   FS2_LAUNCH_CHECK();
   return 0;
 }

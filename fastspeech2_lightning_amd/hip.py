@@ -80,6 +80,9 @@ SIGNATURES = {
     "fs2hip_adamw_step": "ppppqpffffp",
     "fs2hip_axpby": "pppqfffQpp",
     "fs2hip_add_rowvec": "pppiiip",
+    "fs2hip_dact_mul": "pppqip",
+    "fs2hip_mask_from_lens": "ppiip",
+    "fs2hip_sum_slots": "pipp",
 }
 EXPORTS = list(SIGNATURES)
 
@@ -615,3 +618,25 @@ def add_rowvec(x, e, B, T):
     out = torch.empty_like(x)
     _ok(lib().fs2hip_add_rowvec(_p(x), _p(e), _p(out), B, T, D, _stream()), "add_rowvec")
     return out
+
+
+def dact_mul(dy, aux, act):
+    _chk(dy, name="dy"); _chk(aux, name="aux")
+    _req(dy.numel() == aux.numel(), "dact_mul: size mismatch")
+    out = torch.empty_like(dy)
+    _ok(lib().fs2hip_dact_mul(_p(dy), _p(aux), _p(out), dy.numel(), _ACT[act], _stream()), "dact_mul")
+    return out
+
+
+def mask_from_lens(lens, T):
+    _chk(lens, torch.int32, "lens")
+    B = lens.numel()
+    mask = torch.empty(B, T, device=lens.device, dtype=torch.bool)
+    _ok(lib().fs2hip_mask_from_lens(_p(lens), _p(mask), B, T, _stream()), "mask_from_lens")
+    return mask
+
+
+def sum_slots(x, n, out):
+    _chk(x, name="x"); _chk(out, name="out")
+    _req(x.numel() >= n and out.numel() == 1, "sum_slots: size mismatch")
+    _ok(lib().fs2hip_sum_slots(_p(x), n, _p(out), _stream()), "sum_slots")

@@ -1,0 +1,483 @@
+"""``FastSpeech2`` -- the reference's module surface (reference ``fs2/model.py:38-549``) over the
+fs2hip kernels.
+
+Same constructor, same batch dict in (``collate_method`` output, ``fs2/dataset.py:257-293``), same
+16-key dict out (``fs2/model.py:251-268``), same hooks (``training_step``, ``validation_step``,
+``predict_step``, ``configure_optimizers``, ``on_save_checkpoint`` / ``on_load_checkpoint``) and the
+same state-dict keys, so a reference checkpoint loads and a checkpoint written here loads in the
+reference.  Differences, all forced by the design (MI355X-first):
+
+* no autograd tape: ``training_step`` runs forward, loss, backward and leaves the gradients in the
+  flat gradient buffer (``model.store.grad``); the optimizer is the fused AdamW of ``optim.py``;
+* no host synchronisation inside a step (the reference has a Python loop + ``.item()`` calls);
+* the GPU is mandatory: every op raises if the fs2hip library is missing or a tensor is on the CPU.
+"""
+from __future__ import annotations
+
+import sys
+from collections import OrderedDict
+from typing import Optional
+
+import torch
+
+from . import hip as H
+from . import modules as M
+from . import params as P
+from .config import (BadDataError, FastSpeech2Config, InferenceControl, N_PHONOLOGICAL_FEATURES, Stats,
+                     TargetTrainingTextRepresentationLevel, TextProcessor)
+
+try:  # keep the Lightning surface when Lightning is present (it is not in the build image)
+    import pytorch_lightning as pl  # type: ignore
+
+    _Base = pl.LightningModule
+except Exception:  # pragma: no cover - depends on the environment
+    _Base = torch.nn.Module
+
+LOSS_KEYS = ("pitch", "energy", "duration", "spec", "postnet", "attn_ctc", "attn_bin")
+
+
+class VarianceAdaptor:
+    """reference ``fs2/variance_adaptor.py:84-412`` (order of operations ``:309-397``)."""
+
+    def __init__(self, S: P.ParamStore, env: M.Env, config: FastSpeech2Config, stats: Stats):
+        self.S, self.env, self.config = S, env, config
+        vp, d = config.model.variance_predictors, config.model.encoder.input_dim
+        pre = "variance_adaptor."
+        # declaration order = execution order: energy, pitch, duration
+        self.energy_predictor = M.VariancePredictor(S, env, pre + "energy_predictor.", d, vp.energy)
+        S.add(pre + "energy_embedding.weight", (vp.energy.n_bins, vp.energy.input_dim), "id", P.init_normal)
+        self.pitch_predictor = M.VariancePredictor(S, env, pre + "pitch_predictor.", d, vp.pitch)
+        S.add(pre + "pitch_embedding.weight", (vp.pitch.n_bins, vp.pitch.input_dim), "id", P.init_normal)
+        self.duration_predictor = M.VariancePredictor(S, env, pre + "duration_predictor.", d, vp.duration)
+        S.add_buffer(pre + "pitch_bins", torch.linspace(stats.pitch.norm_min, stats.pitch.norm_max, vp.pitch.n_bins - 1))
+        S.add_buffer(pre + "energy_bins", torch.linspace(stats.energy.norm_min, stats.energy.norm_max, vp.energy.n_bins - 1))
+        self.pre = pre
+
+    def _variance(self, name, x, target, lens, control, inference):
+        S, pre = self.S, self.pre
+        predictor = getattr(self, f"{name}_predictor")
+        pred, pctx = predictor.fwd(x, lens)
+        if inference:
+            out, idx = H.bucket_embed_add(pred, S.b(pre + f"{name}_bins"), S.p(pre + f"{name}_embedding.weight"), x, control)
+            if control != 1.0:
+                pred = H.axpby(pred, None, control, 0.0)
+        else:
+            out, idx = H.bucket_embed_add(target, S.b(pre + f"{name}_bins"), S.p(pre + f"{name}_embedding.weight"), x)
+        return pred, out, (pctx, idx)
+
+    def fwd(self, x, batch, src_lens, table, Tm, control, inference, teacher_forcing):
+        cfg = self.config.model.variance_predictors
+        B, Ts, D = x.shape
+        c = {}
+        energy_t = None if inference else batch["energy"]
+        pitch_t = None if inference else batch["pitch"]
+        energy_p = pitch_p = None
+        if cfg.energy.level.value == "phone":
+            energy_p, x, c["energy"] = self._variance("energy", x, energy_t, src_lens, control.energy, inference)
+        if cfg.pitch.level.value == "phone":
+            pitch_p, x, c["pitch"] = self._variance("pitch", x, pitch_t, src_lens, control.pitch, inference)
+        logd, c["duration"] = self.duration_predictor.fwd(x, src_lens)
+        if teacher_forcing or not inference:
+            dur = batch["duration"]
+        else:
+            # fs2/variance_adaptor.py:360-366: clamp(round(exp(logd) - 1) * control, min=0).int()
+            dur = torch.clamp(torch.round(torch.exp(logd) - 1) * control.duration, min=0).int()
+            Tm = int(min(int(dur.sum(1).max()), int(Tm)))  # host sync: inference only
+            Tm = max(Tm, 1)
+        frame_level = cfg.energy.level.value == "frame" or cfg.pitch.level.value == "frame"
+        x, cum, tgt_lens = H.length_regulate_fwd(x, dur, Tm, None if frame_level else table(Tm))
+        c["cum"] = cum
+        if cfg.energy.level.value == "frame":
+            energy_p, x, c["energy"] = self._variance("energy", x, energy_t, tgt_lens, control.energy, inference)
+        if cfg.pitch.level.value == "frame":
+            pitch_p, x, c["pitch"] = self._variance("pitch", x, pitch_t, tgt_lens, control.pitch, inference)
+        if frame_level:
+            x = H.add_posenc(x, table(Tm), tgt_lens, B, Tm)
+        return dict(output=x, duration_prediction=logd, duration_target=dur if (teacher_forcing or not inference) else None,
+                    duration_rounded=dur, pitch_prediction=pitch_p, pitch_target=pitch_t, energy_prediction=energy_p,
+                    energy_target=energy_t, tgt_lens=tgt_lens, Tm=Tm), c
+
+    def bwd(self, d_dec_in, dpred, c):
+        """d_dec_in: gradient of the decoder input; dpred: {'pitch','energy','duration'} loss gradients."""
+        S, pre = self.S, self.pre
+        cfg = self.config.model.variance_predictors
+
+        def variance_bwd(name, d):
+            pctx, idx = c[name]
+            H.embedding_bwd(idx.reshape(-1), d, S.g(pre + f"{name}_embedding.weight"))
+            return H.axpby(d, getattr(self, f"{name}_predictor").bwd(dpred[name], pctx))
+
+        d = d_dec_in
+        if cfg.pitch.level.value == "frame":
+            d = variance_bwd("pitch", d)
+        if cfg.energy.level.value == "frame":
+            d = variance_bwd("energy", d)
+        d = H.length_regulate_bwd(d, c["cum"])
+        d = H.axpby(d, self.duration_predictor.bwd(dpred["duration"], c["duration"]))
+        if cfg.pitch.level.value == "phone":
+            d = variance_bwd("pitch", d)
+        if cfg.energy.level.value == "phone":
+            d = variance_bwd("energy", d)
+        return d
+
+
+class FastSpeech2Loss:
+    """reference ``fs2/loss.py:19-126``: ``model.loss(output, batch, current_epoch)``."""
+
+    def __init__(self, model: "FastSpeech2"):
+        self.model = model
+
+    def __call__(self, output, batch, current_epoch=0, frozen_components=None):
+        m = self.model
+        cfg, t = m.config.model, m.config.training
+        dev = m.device_
+        slots = torch.zeros(len(LOSS_KEYS) + 1, device=dev, dtype=torch.float32)
+        want = m.training
+        B = output["src_lens"].numel()
+        Ts, Tm = output["src_mask"].shape[1], output["tgt_mask"].shape[1]
+        src_lens, tgt_lens = output["src_lens"], output["tgt_lens"]
+        grads, losses = {}, OrderedDict()
+
+        def term(key, pred, target, lens, T, C, kind, weight):
+            i = LOSS_KEYS.index(key)
+            grads[key] = H.masked_loss(pred, target, lens, B, T, C, kind=kind, weight=weight,
+                                       loss_out=slots[i:i + 1], want_grad=want)
+            losses[key] = slots[i]
+
+        for name, w in (("pitch", t.pitch_loss_weight), ("energy", t.energy_loss_weight)):
+            if output[f"{name}_target"] is None:
+                continue
+            c = getattr(cfg.variance_predictors, name)
+            phone = c.level.value == "phone"
+            term(name, output[f"{name}_prediction"], output[f"{name}_target"], src_lens if phone else tgt_lens,
+                 Ts if phone else Tm, 1, c.loss.value, w)
+        term("duration", output["duration_prediction"], output["duration_target"], src_lens, Ts, 1,
+             cfg.variance_predictors.duration.loss.value, t.duration_loss_weight)
+        mel = batch["mel"]
+        n_mels = mel.shape[-1]
+        term("spec", output["output"], mel, tgt_lens, Tm, n_mels, cfg.mel_loss.value, t.mel_loss_weight)
+        if cfg.use_postnet:
+            term("postnet", output["postnet_output"], mel, tgt_lens, Tm, n_mels, cfg.mel_loss.value, t.postnet_loss_weight)
+        H.sum_slots(slots, len(LOSS_KEYS), slots[len(LOSS_KEYS):])
+        losses["total"] = slots[len(LOSS_KEYS)]
+        m._loss_grads = grads if want else None
+        m._loss_slots = slots
+        return losses
+
+
+class FastSpeech2(_Base):
+    _VERSION: str = "1.2"
+
+    def __init__(self, config, stats=None, lang2id: Optional[dict] = None, speaker2id: Optional[dict] = None,
+                 device: Optional[str] = None, seed: int = 1234):
+        super().__init__()
+        if not isinstance(config, FastSpeech2Config):
+            from pydantic import ValidationError
+            try:
+                config = FastSpeech2Config(**config)
+            except ValidationError as e:
+                raise TypeError("Unable to load config.  Possible causes: is it really a FastSpeech2Config? "
+                                "or the correct version?") from e
+        if stats is not None and not isinstance(stats, Stats):
+            stats = Stats(**stats)
+        H.lib()  # fail loudly when the HIP library has not been built
+        if not torch.cuda.is_available():
+            raise RuntimeError("FastSpeech2 (MI355X build) needs a GPU: there is no CPU path")
+        self.device_ = torch.device(device or f"cuda:{torch.cuda.current_device()}")
+        self.config, self.stats = config, stats
+        self.batch_size = config.training.batch_size
+        self.text_processor = TextProcessor(config.text)
+        self.lang2id, self.speaker2id = lang2id or {}, speaker2id or {}
+        self.current_epoch_ = 0
+        m = config.model
+        if m.learn_alignment:
+            raise NotImplementedError("learn_alignment=True (aligner path, SURVEY A14-A17) is not built yet")
+        if m.use_global_style_token_module:
+            raise NotImplementedError("GST style encoder (SURVEY A18) is not built yet")
+        if m.target_text_representation_level == TargetTrainingTextRepresentationLevel.phonological_features:
+            raise NotImplementedError("phonological-feature input layer is not built yet")
+        d = m.encoder.input_dim
+        self.step_state = H.new_step_state(self.device_)
+        self.env = M.Env(self.step_state, seed)
+        S = self.store = P.ParamStore()
+        self.padding_idx = self.text_processor.encode_text(self.text_processor._pad_symbol)[0]
+        S.add("text_input_layer.weight", (len(self.text_processor.symbols), d), "id", self._init_text_embedding)
+        S.add_buffer("position_embedding.inv_freq", 1 / (10000 ** (torch.arange(0.0, d, 2.0) / d)))
+        self.encoder = M.Conformer(S, self.env, "encoder.", m.encoder)
+        S.next_bucket()
+        if m.multispeaker:
+            if len(self.speaker2id) == 0:
+                print("Your model is multispeaker but speaker2id LookupTable is empty", file=sys.stderr)
+                sys.exit(1)
+            S.add("speaker_embedding.weight", (len(self.speaker2id), d), "id", P.init_normal)
+        if m.multilingual:
+            if len(self.lang2id) == 0:
+                print("Your model is multilingual but language2id LookupTable is empty", file=sys.stderr)
+                sys.exit(1)
+            S.add("language_embedding.weight", (len(self.lang2id), d), "id", P.init_normal)
+        if stats is None:
+            print("Your model doesn't have a value for self.stats: the variance adaptor cannot be built", file=sys.stderr)
+            self.variance_adaptor = None
+        else:
+            self.variance_adaptor = VarianceAdaptor(S, self.env, config, stats)
+        S.next_bucket()
+        self.decoder = M.Conformer(S, self.env, "decoder.", m.decoder)
+        S.next_bucket()
+        n_mels = config.preprocessing.audio.n_mels
+        M.decl_linear(S, "mel_linear.", n_mels, m.decoder.input_dim)
+        if m.use_postnet:
+            self.postnet = M.PostNet(S, self.env, "postnet.", n_mels)
+            self.output_key = "postnet_output"
+        else:
+            self.postnet = None
+            self.output_key = "output"
+        S.finalize(self.device_, seed)
+        self._reorder_state_dict_keys()
+        self.loss = FastSpeech2Loss(self)
+        self._tables = {}
+        self._ctx = self._loss_grads = self._loss_slots = None
+        self.grad_sync = None  # set by parallel.GradSync for data-parallel training
+        self.training = False
+        self.env.training = False
+
+    # ---- helpers ------------------------------------------------------------------------------------
+    def _init_text_embedding(self, t):
+        torch.nn.init.normal_(t)
+        t[self.padding_idx].zero_()
+
+    def _reorder_state_dict_keys(self):
+        """state_dict() lists keys in the reference's module registration order."""
+        groups = ["text_input_layer.", "position_embedding.", "encoder.", "variance_adaptor.duration_predictor.",
+                  "variance_adaptor.pitch_predictor.", "variance_adaptor.pitch_embedding.", "variance_adaptor.pitch_bins",
+                  "variance_adaptor.energy_predictor.", "variance_adaptor.energy_embedding.", "variance_adaptor.energy_bins",
+                  "variance_adaptor.attention.", "decoder.", "mel_linear.", "postnet.", "speaker_embedding.",
+                  "language_embedding."]
+        names = self.store.order_hint
+        self.store.order_hint = sorted(names, key=lambda n: next((i for i, g in enumerate(groups) if n.startswith(g)), 99))
+
+    @property
+    def current_epoch(self):
+        try:
+            return super().current_epoch  # Lightning
+        except Exception:
+            return self.current_epoch_
+
+    def train(self, mode: bool = True):
+        self.training = mode
+        self.env.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def parameters(self, recurse=True):  # the flat buffer is the parameter
+        return iter([self.store.flat])
+
+    def state_dict(self, *a, **k):
+        return self.store.state_dict()
+
+    def load_state_dict(self, sd, strict=True, **k):
+        return self.store.load_state_dict(sd, strict)
+
+    def _table(self, T: int):
+        """Positional table [T, D] (fs2/layers.py:132-140), cached per length."""
+        tab = self._tables.get("tab")
+        if tab is None or tab.shape[0] < T:
+            d = self.config.model.encoder.input_dim
+            tab = H.posenc_table(self.store.b("position_embedding.inv_freq"), max(T, 256), d)
+            self._tables["tab"] = tab
+        return tab
+
+    def _dev(self, t, dtype=None):
+        if t is None or not torch.is_tensor(t):
+            return t
+        t = t.to(self.device_, non_blocking=True)
+        if dtype is not None and t.dtype != dtype:
+            t = t.to(dtype)
+        return t.contiguous()
+
+    def prepare_batch(self, batch):
+        """Moves the collated batch to the GPU with the dtypes the kernels take."""
+        b = dict(batch)
+        for k in ("text", "src_lens", "mel_lens", "speaker_id", "language_id"):
+            if b.get(k) is not None:
+                b[k] = self._dev(b[k], torch.int32)
+        for k in ("mel", "pitch", "energy"):
+            if b.get(k) is not None:
+                b[k] = self._dev(b[k], torch.float32)
+        if b.get("duration") is not None and torch.is_tensor(b["duration"]):
+            b["duration"] = self._dev(b["duration"], torch.int32)
+        return b
+
+    # ---- forward (fs2/model.py:153-268) -------------------------------------------------------------
+    def forward(self, batch, control=None, inference=False):
+        control = control or InferenceControl()
+        if "duration_control" in batch and batch["duration_control"] and batch["duration_control"][0]:
+            control.duration = batch["duration_control"][0]
+        batch = self.prepare_batch(batch)
+        teacher_forcing = bool(inference and batch.get("mel_lens") is not None)
+        S, m = self.store, self.config.model
+        text, src_lens = batch["text"], batch["src_lens"]
+        B, Ts = text.shape
+        if int(batch["max_src_len"]) != Ts:
+            raise ValueError("max_src_len must equal the padded text length")
+        save = self.training and not inference
+        inputs = H.embedding_fwd(text, S.p("text_input_layer.weight"))
+        x = H.add_posenc(inputs, self._table(Ts), src_lens, B, Ts)
+        x, enc_ctx = self.encoder.fwd(x, src_lens)
+        if m.multispeaker:
+            x = H.add_rowvec(x, H.embedding_fwd(batch["speaker_id"], S.p("speaker_embedding.weight")), B, Ts)
+        if m.multilingual:
+            x = H.add_rowvec(x, H.embedding_fwd(batch["language_id"], S.p("language_embedding.weight")), B, Ts)
+        Tm = batch["max_mel_len"]
+        va, va_ctx = self.variance_adaptor.fwd(x, batch, src_lens, self._table, int(Tm), control, inference,
+                                               teacher_forcing)
+        Tm, tgt_lens = va["Tm"], va["tgt_lens"]
+        if (teacher_forcing or not inference) and batch.get("mel") is not None and batch["mel"].shape[1] != Tm:
+            raise ValueError("max_mel_len must equal the padded mel length")
+        y, dec_ctx = self.decoder.fwd(va["output"], tgt_lens)
+        output = H.linear_fwd(y, S.p("mel_linear.weight"), S.p("mel_linear.bias"))
+        postnet_output, post_ctx = None, None
+        if m.use_postnet:
+            post, post_ctx = self.postnet.fwd(output)
+            postnet_output = H.axpby(output, post)
+        if save:
+            self._ctx = dict(text=text, enc=enc_ctx, va=va_ctx, dec=dec_ctx, dec_out=y, post=post_ctx, B=B, Ts=Ts, Tm=Tm,
+                             batch=batch)
+        return {
+            "output": output, "postnet_output": postnet_output,
+            "src_mask": H.mask_from_lens(src_lens, Ts), "src_lens": src_lens,
+            "tgt_mask": H.mask_from_lens(tgt_lens, Tm), "tgt_lens": tgt_lens,
+            "attn_logprob": None, "attn_soft": None, "attn_hard": None,
+            "duration_prediction": va["duration_prediction"], "duration_target": va["duration_target"],
+            "energy_prediction": va["energy_prediction"], "energy_target": va["energy_target"],
+            "pitch_prediction": va["pitch_prediction"], "pitch_target": va["pitch_target"],
+            "text_input": text,
+        }
+
+    __call__ = forward
+
+    # ---- backward -----------------------------------------------------------------------------------
+    def backward(self):
+        """Fills ``store.grad`` with d(total loss)/d(parameters) for the last training forward + loss."""
+        if self._ctx is None or self._loss_grads is None:
+            raise RuntimeError("backward() needs a training-mode forward() and loss() first")
+        S, c, g, m = self.store, self._ctx, self._loss_grads, self.config.model
+        sync = self.grad_sync
+        d_out = g["spec"]
+        if m.use_postnet:
+            d_post = g["postnet"]
+            d_out = H.axpby(d_out, d_post)
+            d_out = H.axpby(d_out, self.postnet.bwd(d_post, c["post"]))
+        H.linear_bwd_weight(d_out, c["dec_out"], S.g("mel_linear.weight"))
+        H.colsum(d_out, S.g("mel_linear.bias"))
+        d = H.linear_bwd_data(d_out, S.p("mel_linear.weight"))
+        if sync:
+            sync.bucket_ready(3)
+        d = self.decoder.bwd(d, c["dec"])
+        if sync:
+            sync.bucket_ready(2)
+        d = self.variance_adaptor.bwd(d, g, c["va"])
+        if m.multispeaker:
+            self._rowvec_embedding_bwd("speaker_embedding.weight", c["batch"]["speaker_id"], d)
+        if m.multilingual:
+            self._rowvec_embedding_bwd("language_embedding.weight", c["batch"]["language_id"], d)
+        if sync:
+            sync.bucket_ready(1)
+        d = self.encoder.bwd(d, c["enc"])
+        H.embedding_bwd(c["text"].reshape(-1), d, S.g("text_input_layer.weight"), self.padding_idx)
+        if sync:
+            sync.bucket_ready(0)
+        self._ctx = self._loss_grads = None
+
+    def _rowvec_embedding_bwd(self, name, ids, d):
+        B, T, D = d.shape
+        summed = torch.empty(B, D, device=d.device, dtype=torch.float32)
+        for b in range(B):  # config-5 path; one column-sum per utterance
+            H.colsum(d[b], summed[b])
+        H.embedding_bwd(ids, summed, self.store.g(name))
+
+    # ---- Lightning-style hooks ----------------------------------------------------------------------
+    def training_step(self, batch, batch_idx=0):
+        """fs2/model.py:384-390 -- forward, losses, and (here) the backward pass as well."""
+        if not self.training:
+            raise RuntimeError("training_step() needs model.train()")
+        output = self(batch)
+        losses = self.loss(output, self._ctx["batch"], self.current_epoch)
+        self.backward()
+        self.last_losses = losses
+        return losses["total"]
+
+    def validation_step(self, batch, batch_idx=0):
+        """fs2/model.py:515-528 (plots/audio logging are out of scope)."""
+        was = self.training
+        self.eval()
+        output = self(batch)
+        losses = self.loss(output, self.prepare_batch(batch), self.current_epoch)
+        self.train(was)
+        return losses
+
+    def predict_step(self, batch, batch_idx=0):
+        was = self.training
+        self.eval()
+        out = self(batch, inference=True)
+        self.train(was)
+        return out
+
+    def configure_optimizers(self):
+        """fs2/model.py:530-549: AdamW + NoamLR stepped per optimizer step (both fused on the device)."""
+        from .optim import FusedAdamWNoam
+        o = self.config.training.optimizer
+        self.optimizer = FusedAdamWNoam(self.store, self.step_state, o.learning_rate, tuple(o.betas), o.eps,
+                                        o.weight_decay, o.warmup_steps)
+        return [self.optimizer], [{"scheduler": self.optimizer, "interval": "step"}]
+
+    # ---- checkpoint hooks (fs2/model.py:270-378) ------------------------------------------------------
+    def on_save_checkpoint(self, checkpoint):
+        checkpoint.setdefault("hyper_parameters", {})
+        checkpoint["hyper_parameters"]["config"] = self.config.model_checkpoint_dump()
+        if self.stats is not None:
+            checkpoint["hyper_parameters"]["stats"] = self.stats.model_dump(mode="json")
+        checkpoint["hyper_parameters"]["lang2id"] = self.lang2id
+        checkpoint["hyper_parameters"]["speaker2id"] = self.speaker2id
+        checkpoint["model_info"] = {"name": self.__class__.__name__, "version": self._VERSION}
+
+    def check_and_upgrade_checkpoint(self, checkpoint):
+        from packaging.version import Version
+        info = checkpoint.get("model_info", {"name": self.__class__.__name__, "version": "1.0"})
+        name = info.get("name", "MISSING_TYPE")
+        if name != self.__class__.__name__:
+            raise TypeError(f"Wrong model type ({name}), we are expecting a '{self.__class__.__name__}' model")
+        version = Version(info.get("version", "0.0"))
+        if version > Version(self._VERSION):
+            raise ValueError("Your model was created with a newer version of EveryVoice, please update your software.")
+        if version < Version("1.0"):
+            checkpoint.setdefault("model_info", {})["version"] = "1.0"
+        level = checkpoint["hyper_parameters"]["config"]["model"].get("target_text_representation_level")
+        if version < Version("1.2") and level == TargetTrainingTextRepresentationLevel.phonological_features.value:
+            raise ValueError("There were breaking changes to the handling of phonological features in version 1.2; "
+                             f"your model is version {version}.")
+        return checkpoint
+
+    def on_load_checkpoint(self, checkpoint):
+        checkpoint = self.check_and_upgrade_checkpoint(checkpoint)
+        self.config = FastSpeech2Config(**checkpoint["hyper_parameters"]["config"])
+        if checkpoint["hyper_parameters"].get("stats") is not None:
+            self.stats = Stats(**checkpoint["hyper_parameters"]["stats"])
+
+    def save_checkpoint(self, path, global_step=0, epoch=0, optimizer=None):
+        ckpt = {"state_dict": {k: v.cpu() for k, v in self.state_dict().items()}, "global_step": global_step,
+                "epoch": epoch, "hyper_parameters": {}}
+        self.on_save_checkpoint(ckpt)
+        if optimizer is not None:
+            ckpt["fs2hip_optimizer"] = optimizer.state_dict()
+        torch.save(ckpt, path)
+
+    @classmethod
+    def load_from_checkpoint(cls, path, device=None):
+        ckpt = torch.load(path, map_location="cpu", weights_only=False)
+        hp = ckpt["hyper_parameters"]
+        model = cls(hp["config"], hp.get("stats"), hp.get("lang2id"), hp.get("speaker2id"), device=device)
+        model.on_load_checkpoint(ckpt)
+        model.load_state_dict(ckpt["state_dict"])
+        return model

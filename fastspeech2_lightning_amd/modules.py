@@ -1,0 +1,385 @@
+"""Layers of the feature-prediction path as explicit forward / backward launch sequences over
+the fs2hip kernels (no autograd tape: each ``fwd`` returns the tensors its ``bwd`` needs, each
+``bwd`` writes its parameter gradients straight into the flat gradient buffer).
+
+Layer structure follows the reference (file:line in each class); parameter names are the
+reference's state-dict keys.  All activations are dense padded (B, T, C) fp32 -- padding rows are
+processed like any other row because the reference does so too (finding 4).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import hip as H
+from . import params as P
+
+
+class Ctx:
+    """What a layer's forward keeps for its backward."""
+    __slots__ = ("t",)
+
+    def __init__(self, **t):
+        self.t = t
+
+    def __getattr__(self, k):
+        try:
+            return self.t[k]
+        except KeyError:
+            raise AttributeError(k)
+
+
+class Env:
+    """Per-model run-time switches shared by all layers."""
+
+    def __init__(self, step_state: torch.Tensor, seed: int = 0):
+        self.training = False
+        self.step_state = step_state
+        self.seed = seed
+        self._site = 0
+
+    def new_site(self) -> int:
+        self._site += 1
+        return self._site
+
+    def drop(self, p: float, site: int) -> H.Drop:
+        if not self.training or p <= 0.0:
+            return H.NO_DROP
+        return H.Drop(p, (self.seed * 0x9E3779B1 + site * 0x632BE59BD9B4E019) & 0xFFFFFFFFFFFFFFFF, self.step_state)
+
+
+# ------------------------------------------------------------------------------------------------
+# declaration helpers (reference key names)
+# ------------------------------------------------------------------------------------------------
+def decl_linear(S: P.ParamStore, prefix, n_out, n_in, wname="weight", bname="bias", w_init=None, b_init=None):
+    S.add(f"{prefix}{wname}", (n_out, n_in), "id", w_init or P.init_linear_weight)
+    S.add(f"{prefix}{bname}", (n_out,), "id", b_init or P.init_bias_for(n_in))
+
+
+def decl_norm(S: P.ParamStore, prefix):
+    return prefix
+
+
+class LayerNorm:
+    def __init__(self, S: P.ParamStore, prefix, dim):
+        self.S, self.w, self.b, self.dim = S, prefix + "weight", prefix + "bias", dim
+        S.add(self.w, (dim,), "id", P.init_ones)
+        S.add(self.b, (dim,), "id", P.init_zeros)
+
+    def fwd(self, x):
+        y, mean, rstd = H.layernorm_fwd(x, self.S.p(self.w), self.S.p(self.b))
+        return y, (x, mean, rstd)
+
+    def bwd(self, dy, saved, dx_add=None):
+        x, mean, rstd = saved
+        return H.layernorm_bwd(dy, x, self.S.p(self.w), mean, rstd, self.S.g(self.w), self.S.g(self.b), dx_add)
+
+
+class BatchNorm:
+    """nn.BatchNorm1d over channels of [M, C] (+ running buffers)."""
+
+    def __init__(self, S: P.ParamStore, prefix, dim):
+        self.S, self.prefix, self.dim = S, prefix, dim
+        S.add(prefix + "weight", (dim,), "id", P.init_ones)
+        S.add(prefix + "bias", (dim,), "id", P.init_zeros)
+        S.add_buffer(prefix + "running_mean", torch.zeros(dim))
+        S.add_buffer(prefix + "running_var", torch.ones(dim))
+        S.add_buffer(prefix + "num_batches_tracked", torch.zeros((), dtype=torch.long))
+
+    def stats(self, partial, nparts, count, training):
+        S, p = self.S, self.prefix
+        st = H.bn_finalize(partial, nparts, count, S.p(p + "weight"), S.p(p + "bias"), S.b(p + "running_mean"),
+                           S.b(p + "running_var"), training=training)
+        if training:
+            S.b(p + "num_batches_tracked").add_(1)
+        return st
+
+    def grads(self):
+        return self.S.g(self.prefix + "weight"), self.S.g(self.prefix + "bias")
+
+
+# ------------------------------------------------------------------------------------------------
+# Conformer (torchaudio.models.Conformer; call sites fs2/model.py:95-119)
+# ------------------------------------------------------------------------------------------------
+class FeedForward:
+    """LayerNorm -> Linear(D,F) -> SiLU -> Dropout -> Linear(F,D) -> Dropout; y = x + 0.5 * f(x)."""
+
+    def __init__(self, S, env: Env, prefix, d, f, p):
+        self.S, self.env, self.p = S, env, p
+        self.ln = LayerNorm(S, prefix + "sequential.0.", d)
+        self.w1, self.b1 = prefix + "sequential.1.weight", prefix + "sequential.1.bias"
+        self.w2, self.b2 = prefix + "sequential.4.weight", prefix + "sequential.4.bias"
+        decl_linear(S, prefix + "sequential.1.", f, d)
+        decl_linear(S, prefix + "sequential.4.", d, f)
+        self.s1, self.s2 = env.new_site(), env.new_site()
+        self.f = f
+
+    def fwd(self, x):
+        S, env = self.S, self.env
+        h, ln_saved = self.ln.fwd(x)
+        u = torch.empty(*x.shape[:-1], self.f, device=x.device, dtype=torch.float32)
+        a = H.linear_fwd(h, S.p(self.w1), S.p(self.b1), epi=H.EPI_ACT, act="silu", out_pre=u,
+                         drop=env.drop(self.p, self.s1))
+        y = H.linear_fwd(a, S.p(self.w2), S.p(self.b2), epi=H.EPI_RESID, resid=x, res_scale=0.5,
+                         drop=env.drop(self.p, self.s2))
+        return y, Ctx(ln=ln_saved, h=h, u=u, a=a)
+
+    def bwd(self, dy, c):
+        S, env = self.S, self.env
+        dz = H.axpby(dy, None, 0.5, 0.0, env.drop(self.p, self.s2))
+        H.linear_bwd_weight(dz, c.a, S.g(self.w2))
+        H.colsum(dz, S.g(self.b2))
+        du = H.linear_bwd_data(dz, S.p(self.w2), epi=H.EPI_DACT, act="silu", aux=c.u, drop=env.drop(self.p, self.s1))
+        H.linear_bwd_weight(du, c.h, S.g(self.w1))
+        H.colsum(du, S.g(self.b1))
+        dh = H.linear_bwd_data(du, S.p(self.w1))
+        return self.ln.bwd(dh, c.ln, dx_add=dy)
+
+
+class SelfAttention:
+    """LayerNorm -> nn.MultiheadAttention(key_padding_mask) -> Dropout; y = x + f(x)."""
+
+    def __init__(self, S, env: Env, prefix, d, heads, p):
+        self.S, self.env, self.p, self.heads = S, env, p, heads
+        self.ln = LayerNorm(S, prefix + "self_attn_layer_norm.", d)
+        a = prefix + "self_attn."
+        self.wi, self.bi, self.wo, self.bo = a + "in_proj_weight", a + "in_proj_bias", a + "out_proj.weight", a + "out_proj.bias"
+        S.add(self.wi, (3 * d, d), "id", P.init_xavier("linear"))
+        S.add(self.bi, (3 * d,), "id", P.init_zeros)
+        S.add(self.wo, (d, d), "id", P.init_linear_weight)
+        S.add(self.bo, (d,), "id", P.init_zeros)
+        self.sa, self.so = env.new_site(), env.new_site()
+
+    def fwd(self, x, lens):
+        S, env = self.S, self.env
+        B, T, _ = x.shape
+        h, ln_saved = self.ln.fwd(x)
+        qkv = H.linear_fwd(h, S.p(self.wi), S.p(self.bi))
+        o, lse = H.attention_fwd(qkv, lens, B, T, self.heads, env.drop(self.p, self.sa))
+        y = H.linear_fwd(o, S.p(self.wo), S.p(self.bo), epi=H.EPI_RESID, resid=x, drop=env.drop(self.p, self.so))
+        return y, Ctx(ln=ln_saved, h=h, qkv=qkv, o=o, lse=lse, lens=lens)
+
+    def bwd(self, dy, c):
+        S, env = self.S, self.env
+        B, T, _ = dy.shape
+        d_o = env.drop(self.p, self.so)
+        dz = H.axpby(dy, None, 1.0, 0.0, d_o) if d_o.p > 0 else dy
+        H.linear_bwd_weight(dz, c.o, S.g(self.wo))
+        H.colsum(dz, S.g(self.bo))
+        do = H.linear_bwd_data(dz, S.p(self.wo))
+        dqkv = H.attention_bwd(c.qkv, c.lens, c.o, do, c.lse, B, T, self.heads, env.drop(self.p, self.sa))
+        H.linear_bwd_weight(dqkv, c.h, S.g(self.wi))
+        H.colsum(dqkv, S.g(self.bi))
+        dh = H.linear_bwd_data(dqkv, S.p(self.wi))
+        return self.ln.bwd(dh, c.ln, dx_add=dy)
+
+
+class ConvModule:
+    """LayerNorm -> Conv1d(D,2D,1) -> GLU -> depthwise Conv1d(k) -> BatchNorm1d -> SiLU -> Conv1d(D,D,1)
+    -> Dropout; y = x + f(x)."""
+
+    def __init__(self, S, env: Env, prefix, d, k, p):
+        self.S, self.env, self.p, self.k, self.d = S, env, p, k, d
+        self.ln = LayerNorm(S, prefix + "layer_norm.", d)
+        q = prefix + "sequential."
+        self.w1, self.b1 = q + "0.weight", q + "0.bias"
+        self.wd, self.bd = q + "2.weight", q + "2.bias"
+        self.w2, self.b2 = q + "5.weight", q + "5.bias"
+        S.add(self.w1, (2 * d, d, 1), "pw", P.init_linear_weight)
+        S.add(self.b1, (2 * d,), "id", P.init_bias_for(d))
+        S.add(self.wd, (d, 1, k), "dw", P.init_linear_weight)
+        S.add(self.bd, (d,), "id", P.init_bias_for(k))
+        self.bn = BatchNorm(S, q + "3.", d)
+        S.add(self.w2, (d, d, 1), "pw", P.init_linear_weight)
+        S.add(self.b2, (d,), "id", P.init_bias_for(d))
+        self.site = env.new_site()
+
+    def fwd(self, x):
+        S, env = self.S, self.env
+        B, T, _ = x.shape
+        h, ln_saved = self.ln.fwd(x)
+        g2 = H.linear_fwd(h, S.p(self.w1), S.p(self.b1))
+        c, partial, nparts = H.dwconv_fwd(g2, S.p(self.wd), S.p(self.bd), B, T, glu=True, stats=env.training)
+        stats = self.bn.stats(partial, nparts, B * T, env.training)
+        s = H.bn_act_fwd(c, stats, "silu")
+        y = H.linear_fwd(s, S.p(self.w2), S.p(self.b2), epi=H.EPI_RESID, resid=x, drop=env.drop(self.p, self.site))
+        return y, Ctx(ln=ln_saved, h=h, g2=g2, c=c, stats=stats, s=s)
+
+    def bwd(self, dy, c):
+        S, env = self.S, self.env
+        B, T, _ = dy.shape
+        d_o = env.drop(self.p, self.site)
+        dz = H.axpby(dy, None, 1.0, 0.0, d_o) if d_o.p > 0 else dy
+        H.linear_bwd_weight(dz, c.s, S.g(self.w2))
+        H.colsum(dz, S.g(self.b2))
+        ds = H.linear_bwd_data(dz, S.p(self.w2))
+        gg, gb = self.bn.grads()
+        dc = H.bn_act_bwd(ds, c.c, c.stats, gg, gb, "silu", training=env.training)
+        dg2 = H.dwconv_bwd(dc, c.g2, S.p(self.wd), S.g(self.wd), S.g(self.bd), B, T, glu=True)
+        H.linear_bwd_weight(dg2, c.h, S.g(self.w1))
+        H.colsum(dg2, S.g(self.b1))
+        dh = H.linear_bwd_data(dg2, S.p(self.w1))
+        return self.ln.bwd(dh, c.ln, dx_add=dy)
+
+
+class ConformerLayer:
+    def __init__(self, S, env, prefix, d, f, heads, k, p):
+        self.ffn1 = FeedForward(S, env, prefix + "ffn1.", d, f, p)
+        self.attn = SelfAttention(S, env, prefix, d, heads, p)
+        self.conv = ConvModule(S, env, prefix + "conv_module.", d, k, p)
+        self.ffn2 = FeedForward(S, env, prefix + "ffn2.", d, f, p)
+        self.final = LayerNorm(S, prefix + "final_layer_norm.", d)
+
+    def fwd(self, x, lens):
+        x, c1 = self.ffn1.fwd(x)
+        x, c2 = self.attn.fwd(x, lens)
+        x, c3 = self.conv.fwd(x)
+        x, c4 = self.ffn2.fwd(x)
+        y, c5 = self.final.fwd(x)
+        return y, (c1, c2, c3, c4, c5)
+
+    def bwd(self, dy, c):
+        c1, c2, c3, c4, c5 = c
+        d = self.final.bwd(dy, c5)
+        d = self.ffn2.bwd(d, c4)
+        d = self.conv.bwd(d, c3)
+        d = self.attn.bwd(d, c2)
+        return self.ffn1.bwd(d, c1)
+
+
+class Conformer:
+    def __init__(self, S, env, prefix, cfg):
+        self.layers = [ConformerLayer(S, env, f"{prefix}conformer_layers.{i}.", cfg.input_dim, cfg.feedforward_dim,
+                                      cfg.heads, cfg.conv_kernel_size, cfg.dropout) for i in range(cfg.layers)]
+
+    def fwd(self, x, lens):
+        saved = []
+        for layer in self.layers:
+            x, c = layer.fwd(x, lens)
+            saved.append(c)
+        return x, saved
+
+    def bwd(self, dy, saved):
+        for layer, c in zip(reversed(self.layers), reversed(saved)):
+            dy = layer.bwd(dy, c)
+        return dy
+
+
+# ------------------------------------------------------------------------------------------------
+# VariancePredictor  fs2/variance_adaptor.py:18-62, fs2/layers.py:20-48, fs2/blocks.py:4-19
+# ------------------------------------------------------------------------------------------------
+class VariancePredictor:
+    def __init__(self, S, env: Env, prefix, d_in, cfg):
+        self.S, self.env = S, env
+        self.depthwise, self.k, self.p, self.c = cfg.depthwise, cfg.kernel_size, cfg.dropout, cfg.input_dim
+        self.layers = []
+        for i in range(cfg.n_layers):
+            cin = d_in if i == 0 else cfg.input_dim
+            q = f"{prefix}conv.{i}.layers."
+            L = {"site": env.new_site(), "cin": cin}
+            if cfg.depthwise:
+                L["wd"], L["bd"] = q + "0.module.model.0.weight", q + "0.module.model.0.bias"
+                L["wp"], L["bp"] = q + "0.module.model.1.weight", q + "0.module.model.1.bias"
+                S.add(L["wd"], (cin, 1, self.k), "dw", P.init_linear_weight)
+                S.add(L["bd"], (cin,), "id", P.init_bias_for(self.k))
+                S.add(L["wp"], (self.c, cin, 1), "pw", P.init_linear_weight)
+                S.add(L["bp"], (self.c,), "id", P.init_bias_for(cin))
+            else:
+                L["wc"], L["bc"] = q + "0.module.weight", q + "0.module.bias"
+                S.add(L["wc"], (self.c, cin, self.k), "convk", P.init_linear_weight)
+                S.add(L["bc"], (self.c,), "id", P.init_bias_for(cin * self.k))
+            L["ln"] = LayerNorm(S, q + "2.", self.c)
+            self.layers.append(L)
+        self.wl, self.bl = prefix + "linear.weight", prefix + "linear.bias"
+        S.add(self.wl, (1, self.c), "id", P.init_linear_weight)
+        S.add(self.bl, (1,), "id", P.init_bias_for(self.c))
+
+    def fwd(self, x, lens):
+        S, env = self.S, self.env
+        B, T, _ = x.shape
+        saved = []
+        for L in self.layers:
+            if self.depthwise:
+                c, _, _ = H.dwconv_fwd(x, S.p(L["wd"]), S.p(L["bd"]), B, T)
+                r = H.linear_fwd(c, S.p(L["wp"]), S.p(L["bp"]), epi=H.EPI_ACT, act="relu")
+            else:
+                c = None
+                r = H.linear_fwd(x, S.p(L["wc"]), S.p(L["bc"]), epi=H.EPI_ACT, act="relu", taps=self.k, T=T)
+            n, ln_saved = L["ln"].fwd(r)
+            d = env.drop(self.p, L["site"])
+            out = H.axpby(n, None, 1.0, 0.0, d) if d.p > 0 else n
+            saved.append((x, c, r, ln_saved))
+            x = out
+        pred = H.rowdot_fwd(x, S.p(self.wl), S.p(self.bl), lens, B, T)
+        return pred, (saved, x, lens)
+
+    def bwd(self, dpred, ctx):
+        S, env = self.S, self.env
+        saved, xl, lens = ctx
+        B, T, _ = xl.shape
+        d = H.rowdot_bwd(dpred, xl, S.p(self.wl), lens, S.g(self.wl), S.g(self.bl), B, T)
+        for L, (x, c, r, ln_saved) in zip(reversed(self.layers), reversed(saved)):
+            dr = env.drop(self.p, L["site"])
+            if dr.p > 0:
+                d = H.axpby(d, None, 1.0, 0.0, dr)
+            d = L["ln"].bwd(d, ln_saved)
+            d = H.dact_mul(d, r, "relu")
+            if self.depthwise:
+                H.linear_bwd_weight(d, c, S.g(L["wp"]))
+                H.colsum(d, S.g(L["bp"]))
+                dc = H.linear_bwd_data(d, S.p(L["wp"]))
+                d = H.dwconv_bwd(dc, x, S.p(L["wd"]), S.g(L["wd"]), S.g(L["bd"]), B, T)
+            else:
+                H.linear_bwd_weight(d, x, S.g(L["wc"]), taps=self.k, T=T)
+                H.colsum(d, S.g(L["bc"]))
+                d = H.linear_bwd_data(d, S.p(L["wc"]), taps=self.k, T=T)
+        return d
+
+
+# ------------------------------------------------------------------------------------------------
+# PostNet  fs2/layers.py:143-212
+# ------------------------------------------------------------------------------------------------
+class PostNet:
+    DROPOUT = 0.5  # hard-coded in the reference (fs2/layers.py:207-209)
+
+    def __init__(self, S, env: Env, prefix, n_mel, dim=512, k=5, n=5):
+        self.S, self.env, self.k, self.n = S, env, k, n
+        self.dropout_p = self.DROPOUT
+        chans = [n_mel] + [dim] * (n - 1) + [n_mel]
+        self.convs = []
+        for i in range(n):
+            q = f"{prefix}convolutions.{i}."
+            w, b = q + "0.conv.weight", q + "0.conv.bias"
+            S.add(w, (chans[i + 1], chans[i], k), "convk", P.init_xavier("tanh" if i < n - 1 else "linear"))
+            S.add(b, (chans[i + 1],), "id", P.init_bias_for(chans[i] * k))
+            self.convs.append((w, b, BatchNorm(S, q + "1.", chans[i + 1]), env.new_site()))
+
+    def fwd(self, x):
+        S, env = self.S, self.env
+        B, T, _ = x.shape
+        saved = []
+        for i, (w, b, bn, site) in enumerate(self.convs):
+            raw = H.linear_fwd(x, S.p(w), S.p(b), taps=self.k, T=T)
+            partial, nparts = H.colstats(raw) if env.training else (None, 0)
+            stats = bn.stats(partial, nparts, B * T, env.training)
+            act = "tanh" if i < self.n - 1 else None
+            out = H.bn_act_fwd(raw, stats, act, env.drop(self.dropout_p, site))
+            saved.append((x, raw, stats))
+            x = out
+        return x, saved
+
+    def bwd(self, dy, saved, need_dx=True):
+        S, env = self.S, self.env
+        B, T, _ = dy.shape
+        for i in range(self.n - 1, -1, -1):
+            w, b, bn, site = self.convs[i]
+            x, raw, stats = saved[i]
+            gg, gb = bn.grads()
+            act = "tanh" if i < self.n - 1 else None
+            draw = H.bn_act_bwd(dy, raw, stats, gg, gb, act, env.drop(self.dropout_p, site), training=env.training)
+            H.linear_bwd_weight(draw, x, S.g(w), taps=self.k, T=T)
+            H.colsum(draw, S.g(b))
+            if i > 0 or need_dx:
+                dy = H.linear_bwd_data(draw, S.p(w), taps=self.k, T=T)
+        return dy

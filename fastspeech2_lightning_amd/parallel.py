@@ -1,0 +1,51 @@
+"""Data-parallel gradient exchange: one process per GPU, RCCL over xGMI through
+``torch.distributed`` (backend "nccl" is RCCL on ROCm; "gloo" for the CPU rehearsal tests).
+
+The reference gets DDP implicitly from Lightning (``fs2/cli/train.py:33-41``).  Here
+the gradient already lives in one contiguous buffer laid out in forward order, so the backward
+pass -- which completes it from the end towards the beginning -- hands finished slices ("buckets":
+PostNet+mel head, decoder, variance adaptor, encoder+embedding) to an asynchronous sum-all-reduce
+as soon as their last kernel has been enqueued; the collective runs on RCCL's stream underneath the
+remaining backward kernels.  The 1/world_size factor is folded into the clip coefficient of the
+fused optimizer, so no extra pass over the gradient is needed.  BatchNorm statistics stay per rank
+(the reference does not use SyncBatchNorm).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+class GradSync:
+    def __init__(self, store, process_group=None, world_size: Optional[int] = None):
+        self.store, self.group = store, process_group
+        self.world = world_size if world_size is not None else dist.get_world_size(process_group)
+        self.ranges = store.bucket_ranges()
+        self._work = []
+
+    def bucket_ready(self, bucket: int):
+        """Called by ``FastSpeech2.backward`` right after the last gradient kernel of ``bucket``."""
+        if self.world == 1 or bucket >= len(self.ranges):
+            return
+        s, e = self.ranges[bucket]
+        self._work.append(dist.all_reduce(self.store.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self):
+        """Makes the current stream wait for every outstanding bucket (call before the optimizer)."""
+        for w in self._work:
+            w.wait()
+        self._work.clear()
+
+    def broadcast_parameters(self, src: int = 0):
+        """Rank ``src``'s weights and BatchNorm buffers to every rank (start of training)."""
+        if self.world == 1:
+            return
+        dist.broadcast(self.store.flat, src, group=self.group)
+        for b in self.store.buffers.values():
+            dist.broadcast(b, src, group=self.group)
+
+    @property
+    def grad_scale(self) -> float:
+        return 1.0 / self.world

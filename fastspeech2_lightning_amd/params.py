@@ -1,0 +1,206 @@
+"""Flat parameter store.
+
+All trainable parameters live in ONE fp32 device buffer, laid out in forward
+execution order and in the layout the kernels want (k-tap conv weights as
+[tap][Cout][Cin], depthwise weights as [tap][C]); gradients, Adam first and second
+moments are three more buffers of the same shape.  Consequences:
+
+* the optimizer is a single fused AdamW launch over 18 M contiguous floats;
+* the data-parallel exchange is an all-reduce of contiguous slices of the
+  gradient buffer, issued bucket by bucket as the backward pass (which fills
+  the buffer from the end towards the beginning) completes them;
+* ``state_dict()`` / ``load_state_dict()`` convert to and from the reference's
+  key names and tensor layouts, so checkpoints interchange.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from dataclasses import dataclass
+from typing import Callable, Optional
+
+import torch
+
+# layout kinds: reference tensor -> native tensor
+_TO_NATIVE = {
+    "id": lambda t: t,
+    "convk": lambda t: t.permute(2, 0, 1),   # (Cout, Cin, K) -> [K][Cout][Cin]
+    "dw": lambda t: t[:, 0, :].t(),           # (C, 1, K)     -> [K][C]
+    "pw": lambda t: t[:, :, 0],               # (Cout, Cin, 1) -> [Cout][Cin]
+}
+_TO_REF = {
+    "id": lambda t, shape: t,
+    "convk": lambda t, shape: t.permute(1, 2, 0),
+    "dw": lambda t, shape: t.t().unsqueeze(1),
+    "pw": lambda t, shape: t.unsqueeze(-1),
+}
+
+
+def native_shape(ref_shape, kind):
+    s = tuple(ref_shape)
+    if kind == "convk":
+        return (s[2], s[0], s[1])
+    if kind == "dw":
+        return (s[2], s[0])
+    if kind == "pw":
+        return (s[0], s[1])
+    return s
+
+
+# ---- initialisers on reference-shaped CPU tensors (PyTorch module defaults) ---------------
+def init_linear_weight(t):
+    torch.nn.init.kaiming_uniform_(t, a=math.sqrt(5))
+
+
+def init_bias_for(fan_in):
+    def f(t):
+        bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
+        torch.nn.init.uniform_(t, -bound, bound)
+    return f
+
+
+def init_xavier(gain_name):
+    def f(t):
+        torch.nn.init.xavier_uniform_(t, gain=torch.nn.init.calculate_gain(gain_name))
+    return f
+
+
+def init_ones(t):
+    t.fill_(1.0)
+
+
+def init_zeros(t):
+    t.zero_()
+
+
+def init_normal(t):
+    torch.nn.init.normal_(t)
+
+
+@dataclass
+class Entry:
+    name: str
+    ref_shape: tuple
+    kind: str
+    init: Callable
+    offset: int = 0
+    numel: int = 0
+    bucket: int = 0
+
+
+class ParamStore:
+    ALIGN = 4  # floats (16 B) so that every view is float4-addressable
+
+    def __init__(self):
+        self.entries: "OrderedDict[str, Entry]" = OrderedDict()
+        self.buffers: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+        self._buffer_specs = []
+        self.order_hint: list[str] = []  # reference registration order for state_dict()
+        self.flat = self.grad = self.adam_m = self.adam_v = None
+        self.total = 0
+        self._bucket = 0
+
+    # ---- declaration phase -----------------------------------------------------------------
+    def add(self, name, ref_shape, kind="id", init=init_zeros):
+        if name in self.entries:
+            raise KeyError(name)
+        e = Entry(name, tuple(ref_shape), kind, init)
+        e.numel = int(torch.Size(ref_shape).numel())
+        e.offset = self.total
+        e.bucket = self._bucket
+        self.total += (e.numel + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.entries[name] = e
+        self.order_hint.append(name)
+        return name
+
+    def add_buffer(self, name, tensor: torch.Tensor):
+        self._buffer_specs.append((name, tensor))
+        self.order_hint.append(name)
+        return name
+
+    def next_bucket(self):
+        """Marks a gradient-bucket boundary (data-parallel exchange granularity)."""
+        self._bucket += 1
+
+    # ---- materialisation -------------------------------------------------------------------
+    def finalize(self, device, seed: Optional[int] = None):
+        gen = torch.Generator().manual_seed(seed) if seed is not None else None
+        host = torch.zeros(self.total, dtype=torch.float32)
+        state = torch.random.get_rng_state() if gen is not None else None
+        if gen is not None:
+            torch.manual_seed(seed)
+        for e in self.entries.values():
+            ref = torch.empty(e.ref_shape, dtype=torch.float32)
+            e.init(ref)
+            host[e.offset:e.offset + e.numel] = _TO_NATIVE[e.kind](ref).contiguous().reshape(-1)
+        if state is not None:
+            torch.random.set_rng_state(state)
+        self.flat = host.to(device)
+        self.grad = torch.zeros_like(self.flat)
+        self.adam_m = torch.zeros_like(self.flat)
+        self.adam_v = torch.zeros_like(self.flat)
+        for name, t in self._buffer_specs:
+            self.buffers[name] = t.to(device)
+        self.device = torch.device(device)
+        return self
+
+    def _view(self, base, name):
+        e = self.entries[name]
+        return base[e.offset:e.offset + e.numel].view(native_shape(e.ref_shape, e.kind))
+
+    def p(self, name):
+        return self._view(self.flat, name)
+
+    def g(self, name):
+        return self._view(self.grad, name)
+
+    def b(self, name):
+        return self.buffers[name]
+
+    def bucket_ranges(self):
+        """[(start, end)] float offsets of each gradient bucket, in declaration order."""
+        out = {}
+        for e in self.entries.values():
+            end = e.offset + (e.numel + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+            s, t = out.get(e.bucket, (e.offset, end))
+            out[e.bucket] = (min(s, e.offset), max(t, end))
+        return [out[k] for k in sorted(out)]
+
+    @property
+    def num_trainable(self):
+        return sum(e.numel for e in self.entries.values())
+
+    # ---- reference-layout state dict ---------------------------------------------------------
+    def state_dict(self) -> "OrderedDict[str, torch.Tensor]":
+        sd = OrderedDict()
+        for name in self.order_hint:
+            if name in self.entries:
+                e = self.entries[name]
+                sd[name] = _TO_REF[e.kind](self.p(name), e.ref_shape).contiguous().clone()
+            else:
+                sd[name] = self.buffers[name].clone()
+        return sd
+
+    def load_state_dict(self, sd, strict=True):
+        missing = [k for k in self.order_hint if k not in sd]
+        unexpected = [k for k in sd if k not in self.entries and k not in self.buffers]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"state dict mismatch: missing {missing[:8]} unexpected {unexpected[:8]}")
+        with torch.no_grad():
+            for k, v in sd.items():
+                if k in self.entries:
+                    e = self.entries[k]
+                    if tuple(v.shape) != e.ref_shape:
+                        raise RuntimeError(f"{k}: shape {tuple(v.shape)} != {e.ref_shape}")
+                    self.p(k).copy_(_TO_NATIVE[e.kind](v.to(torch.float32)).to(self.device))
+                elif k in self.buffers:
+                    b = self.buffers[k]
+                    if tuple(v.shape) != tuple(b.shape):
+                        raise RuntimeError(f"{k}: shape {tuple(v.shape)} != {tuple(b.shape)}")
+                    b.copy_(v.to(b.dtype))
+        return missing, unexpected
+
+    def grad_state_dict(self):
+        """Gradients in the reference's layout (for parity tests)."""
+        return OrderedDict((n, _TO_REF[e.kind](self.g(n), e.ref_shape).contiguous().clone())
+                           for n, e in self.entries.items())

@@ -227,6 +227,11 @@ int fs2hip_adamw_step(float* p, const float* g, float* m, float* v, long long n,
 int fs2hip_axpby(const float* x, const float* y, float* out, long long n, float a, float b, float drop_p,
                  unsigned long long drop_seed, const unsigned long long* drop_step, void* stream);
 int fs2hip_add_rowvec(const float* x, const float* e, float* out, int B, int T, int D, void* stream);
+/* out = dy * act'(aux) (aux = activation output for ReLU, input otherwise); bool mask t < lens[b]
+ * (fs2/utils/heavy.py:11-15); out[0] = sum of n loss slots (fs2/loss.py:125) */
+int fs2hip_dact_mul(const float* dy, const float* aux, float* out, long long n, int act, void* stream);
+int fs2hip_mask_from_lens(const int* lens, unsigned char* mask, int B, int T, void* stream);
+int fs2hip_sum_slots(const float* x, int n, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,141 @@
+"""GPU parity of the whole path (forward, every loss term, every parameter gradient, BatchNorm
+running statistics) against (a) the golden vectors produced by the reference's own Python and
+(b) the CPU oracle on fresh inputs.
+
+Tolerances: outputs/losses 1e-4 relative to the tensor scale (fp32, ~10 layers of different
+summation order); gradients 2e-3 of each tensor's max (sums over B*T rows in a different order);
+integer outputs (masks, lengths, duration targets) bit-exact.  north_star bound: mel MSE < 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+from fastspeech2_lightning_amd.config import Stats
+from oracle import cases as C
+from oracle import fs2_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+GPU_CASES = [n for n, (ckw, _, _) in C.CASES.items() if not ckw.get("learn_alignment")]
+
+
+def build_model(name):
+    from fastspeech2_lightning_amd.model import FastSpeech2
+    config, batch, train = C.build(name)
+    model = FastSpeech2(config, Stats(**C.STATS))
+    model.load_state_dict(O.seeded_state_dict(model.state_dict()))
+    model.train(train)
+    model.postnet.dropout_p = 0.0  # goldens are generated with dropout as the identity
+    return model, batch, train
+
+
+def rel(a, b, floor=1e-6):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), floor))
+
+
+@pytest.mark.parametrize("name", GPU_CASES)
+def test_state_dict_layout_matches_reference(golden_dir, name):
+    g = dict(np.load(golden_dir / f"{name}.npz"))
+    model, _, _ = build_model(name)
+    sd = model.state_dict()
+    ref_grad_keys = {k[5:] for k in g if k.startswith("grad/")}
+    trainable = set(model.store.entries)
+    assert ref_grad_keys <= trainable, sorted(ref_grad_keys - trainable)[:5]
+    for k in g:
+        if k.startswith("sd_after/"):
+            assert k[9:] in sd, k
+    # round trip through the reference layout
+    model.load_state_dict(sd)
+    sd2 = model.state_dict()
+    for k in sd:
+        assert torch.equal(sd[k], sd2[k]), k
+
+
+@pytest.mark.parametrize("name", GPU_CASES)
+def test_forward_loss_backward_vs_reference_golden(golden_dir, name):
+    g = dict(np.load(golden_dir / f"{name}.npz"))
+    model, batch, train = build_model(name)
+    out = model(batch)
+    for k, v in out.items():
+        if v is None:
+            assert "out/" + k not in g, k
+            continue
+        ref = g["out/" + k]
+        got = v.detach().cpu().numpy()
+        if got.dtype.kind in "biu":
+            np.testing.assert_array_equal(got, ref, err_msg=k)
+        else:
+            assert rel(got, ref) < 1e-4, (k, rel(got, ref))
+    mse = float(((out["output"].cpu().numpy() - g["out/output"]) ** 2).mean())
+    assert mse < 1e-8, mse  # north_star: mel MSE vs reference < 1e-4
+    model.training = True  # losses' gradients are wanted in both modes for this test
+    losses = model.loss(out, model.prepare_batch(batch), C.EPOCH)
+    model.training = train
+    for k, v in losses.items():
+        assert abs(float(v) - float(g["loss/" + k])) < 1e-4 * max(1.0, abs(float(g["loss/" + k]))), k
+    if not train:
+        return
+    model.backward()
+    grads = model.store.grad_state_dict()
+    # a bias in front of a train-mode BatchNorm has an exactly-zero true gradient (fp32 noise on both
+    # sides): tensors are compared at max(their own scale, 1e-4 of the largest gradient in the model)
+    def body(k):  # strip the [l2 norm, sum] header of subsampled tensors
+        big = model.store.entries[k[5:]].numel > O.GRAD_SUBSAMPLE_THRESHOLD
+        return g[k][2:] if big else g[k]
+    floor = 1e-4 * max(float(np.abs(body(k)).max()) for k in g if k.startswith("grad/") and k[5:] in model.store.entries)
+    worst = ("", 0.0)
+    for k, v in grads.items():
+        key = "grad/" + k
+        if key not in g:
+            continue
+        a = v.cpu().numpy()
+        a = O.subsample(a) if a.size > O.GRAD_SUBSAMPLE_THRESHOLD else a
+        r = rel(a[2:], g[key][2:], floor) if v.numel() > O.GRAD_SUBSAMPLE_THRESHOLD else rel(a, g[key], floor)
+        if v.numel() > O.GRAD_SUBSAMPLE_THRESHOLD:  # [l2 norm, sum] header of the subsampled form
+            r = max(r, abs(a[0] - g[key][0]) / max(g[key][0], floor))
+        if r > worst[1]:
+            worst = (k, r)
+    assert worst[1] < 2e-3, worst
+    sd = model.state_dict()
+    for k in g:
+        if k.startswith("sd_after/") and "num_batches" not in k:
+            assert rel(sd[k[9:]].cpu().numpy(), g[k]) < 1e-4, k
+        elif k.startswith("sd_after/"):
+            assert int(sd[k[9:]]) == int(g[k]), k
+
+
+def test_against_oracle_on_fresh_inputs_with_default_widths():
+    """Default-width model (D=256, F=1024, hd=128, PostNet 512) on a fresh small batch: HIP path vs
+    the CPU oracle sharing one state dict."""
+    from fastspeech2_lightning_amd.config import FastSpeech2Config
+    from fastspeech2_lightning_amd.model import FastSpeech2
+    conf = dict(layers=1, dropout=0.0)
+    vp = dict(dropout=0.0)
+    config = FastSpeech2Config(
+        model=dict(encoder=conf, decoder=conf, learn_alignment=False,
+                   variance_predictors=dict(energy=vp, pitch=vp, duration=vp)),
+        text=dict(symbols=dict(letters=[f"s{i}" for i in range(40)])))
+    batch = O.synthetic_batch(B=2, ts_lo=20, ts_hi=33, n_symbols=41, n_mels=80, seed=3, dur_hi=5)
+    model = FastSpeech2(config, Stats(**C.STATS))
+    oracle = O.FastSpeech2Oracle(config, Stats(**C.STATS), n_symbols=41)
+    sd = O.seeded_state_dict(oracle.state_dict())
+    oracle.load_state_dict(sd)
+    model.load_state_dict(sd)
+    model.train(); oracle.train()
+    model.postnet.dropout_p = 0.0
+    oracle.postnet.dropout_p = 0.0
+    ref = oracle(batch)
+    ref_losses = oracle.loss(ref, batch, 0)
+    ref_losses["total"].backward()
+    total = model.training_step(batch)
+    assert abs(float(total) - float(ref_losses["total"])) < 1e-4 * float(ref_losses["total"])
+    got = model.store.grad_state_dict()
+    floor = 1e-4 * max(float(p.grad.abs().max()) for p in oracle.parameters() if p.grad is not None)
+    worst = ("", 0.0)
+    for k, p in oracle.named_parameters():
+        if p.grad is None:
+            continue
+        r = rel(got[k].cpu().numpy(), p.grad.numpy(), floor)
+        if r > worst[1]:
+            worst = (k, r)
+    assert worst[1] < 2e-3, worst
