@@ -1,0 +1,244 @@
+#!/usr/bin/env python
+"""Throughput of the FastSpeech2 feature-prediction train step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = forward + all losses + backward + gradient exchange (N > 1) + clip + fused AdamW on one
+synthetic LJSpeech-shaped batch of 32 utterances per GPU (BASELINE.json configs[1]: fp32, batch 32,
+~100-128 phonemes, 80 x ~600 mel), dropout ON as in training, inputs resident in HBM before the
+timed region.  ``value`` = real (unpadded) mel frames processed per second by the whole job.
+
+The JSON line also carries
+  roofline     : the dominant kernel (fp32 MFMA GEMM family) -- algorithmic FLOPs per launch / average
+                 launch duration, measured live with HIP events on the launch stream, against the
+                 157.3 TFLOP/s fp32 matrix peak;
+  cpu_baseline : the CPU oracle (pure-PyTorch restatement of the reference, ``oracle/``) timed on this
+                 box's host cores on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
+
+
+def host_cores() -> int:
+    """Threads for the CPU baseline: the box's CPU share (16 per GPU on the pool), not the host's total."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, int(os.environ.get("FS2_BENCH_CPU_THREADS", 16))))
+
+
+def log(msg):
+    print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+T_START = time.perf_counter()
+
+
+def make_config(learn_alignment=False):
+    from fastspeech2_lightning_amd.config import FastSpeech2Config
+    from fastspeech2_lightning_amd.synthetic import default_symbols
+    return FastSpeech2Config(model=dict(learn_alignment=learn_alignment), text=default_symbols(64))
+
+
+def cpu_baseline(config, batch, sample_B=32, iters=2):
+    """Oracle (CPU port of the reference path) fwd + loss + bwd + AdamW on the first ``sample_B``
+    utterances of the benchmark batch."""
+    from fastspeech2_lightning_amd.config import Stats
+    from fastspeech2_lightning_amd.synthetic import DEFAULT_STATS
+    from oracle import fs2_oracle as O  # test infrastructure: used here only as the timed CPU baseline
+
+    torch.set_num_threads(host_cores())
+    sub = {}
+    src = batch["src_lens"][:sample_B]
+    mel = batch["mel_lens"][:sample_B]
+    Ts, Tm = int(src.max()), int(mel.max())
+    for k, v in batch.items():
+        if torch.is_tensor(v) and v.dim() >= 1:
+            v = v[:sample_B]
+            if k in ("text", "duration", "pitch", "energy"):
+                v = v[:, :Ts]
+            if k == "mel":
+                v = v[:, :Tm]
+            sub[k] = v.clone()
+        else:
+            sub[k] = v
+    sub["max_src_len"], sub["max_mel_len"] = Ts, Tm
+    model = O.FastSpeech2Oracle(config, Stats(**DEFAULT_STATS), n_symbols=64)
+    model.train()
+    o = config.training.optimizer
+    opt = torch.optim.AdamW(model.parameters(), o.learning_rate, betas=tuple(o.betas), eps=o.eps,
+                            weight_decay=o.weight_decay)
+
+    def step():
+        opt.zero_grad()
+        out = model(sub)
+        model.loss(out, sub, 0)["total"].backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+
+    step()  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    dt = (time.perf_counter() - t0) / iters
+    frames = int(mel.sum())
+    return {"value": round(frames / dt, 1), "unit": "mel-frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"first {sample_B} utterances of the benchmark batch ({frames} frames, Ts={Ts}, Tm={Tm}), "
+                      f"1 warm-up + {iters} timed fwd+loss+bwd+clip+AdamW steps, fp32, {dt:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+
+    from fastspeech2_lightning_amd import hip as H
+    from fastspeech2_lightning_amd.config import Stats
+    from fastspeech2_lightning_amd.model import FastSpeech2
+    from fastspeech2_lightning_amd.parallel import GradSync
+    from fastspeech2_lightning_amd.synthetic import DEFAULT_STATS, synthetic_batch
+
+    config = make_config()
+    model = FastSpeech2(config, Stats(**DEFAULT_STATS), device=f"cuda:{local}", seed=1234)
+    model.train()
+    opt = model.configure_optimizers()[0][0]
+    batch = synthetic_batch(B=args.batch, ts_lo=96, ts_hi=128, n_symbols=64, n_mels=80, seed=1234 + rank, dur_hi=9)
+    sync = None
+    if world > 1:
+        sync = GradSync(model.store)
+        sync.broadcast_parameters(0)
+        model.grad_sync = sync
+        opt.grad_scale = sync.grad_scale
+    dev_batch = model.prepare_batch(batch)  # inputs resident in HBM before the timed region
+    frames = int(batch["mel_lens"].sum())
+    padded = int(batch["mel"].shape[0] * batch["mel"].shape[1])
+
+    def step():
+        model.training_step(dev_batch)
+        if sync:
+            sync.wait()
+        opt.step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    log(f"model built ({model.store.num_trainable} parameters), batch resident: {frames} frames, padded {padded}")
+    for i in range(max(args.warmup, 1)):
+        t_w = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        log(f"warm-up step {i}: {(time.perf_counter() - t_w) * 1e3:.1f} ms")
+
+    use_graph = not args.no_graph and world == 1
+    graph = None
+    if use_graph:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        graph.replay()  # one untimed replay
+        torch.cuda.synchronize()
+        log("hipGraph captured and replayed once")
+    run = graph.replay if graph is not None else step
+
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=f"cuda:{local}", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+        f = torch.tensor([frames, padded], device=f"cuda:{local}", dtype=torch.float64)
+        dist.all_reduce(f, op=dist.ReduceOp.SUM)
+        frames_all, padded_all = int(f[0]), int(f[1])
+    else:
+        frames_all, padded_all = frames, padded
+    losses = {k: float(v) for k, v in model.last_losses.items()}
+    log(f"timed region: {elapsed / args.steps * 1e3:.2f} ms/step")
+
+    roofline = None
+    if not args.no_roofline and rank == 0:
+        # live measurement of the dominant kernel: HIP events around every GEMM launch of two eager steps
+        H.GEMM_PROFILE = []
+        step()
+        H.GEMM_PROFILE = []
+        step()
+        torch.cuda.synchronize()
+        prof, H.GEMM_PROFILE = H.GEMM_PROFILE, None
+        ms = sum(e0.elapsed_time(e1) for e0, e1, *_ in prof)
+        flops = sum(p[2] for p in prof)
+        achieved = flops / (ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "kernel": "gemm_kernel<128,128|64> (fp32 v_mfma_f32_32x32x2_f32)", "launches_per_step": len(prof),
+                    "avg_launch_us": round(ms * 1e3 / len(prof), 2), "flops_per_launch": round(flops / len(prof)),
+                    "gemm_ms_per_step": round(ms, 3)}
+
+    log("roofline pass done")
+    cpu = None
+    if not args.no_cpu_baseline and rank == 0 and world == 1:
+        cpu = cpu_baseline(config, batch)
+        log("cpu baseline done")
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        line = {
+            "metric": "mel-frames/sec (train fwd+bwd+optimizer, whole job)",
+            "value": round(frames_all * args.steps / elapsed, 1), "unit": "mel-frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: fp32 train step, batch=32/GPU, LJSpeech-shaped synthetic "
+                                   "(96-128 phonemes, 80 x ~600 mel), learn_alignment=False, dropout on",
+                       "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                       "real_frames_per_step": frames_all, "padded_frames_per_step": padded_all,
+                       "parallelism": f"dp{world}", "hipgraph": bool(graph is not None),
+                       "parameters": model.store.num_trainable},
+            "per_gpu_value": round(frames_all * args.steps / elapsed / world, 1),
+            "padded_frames_per_s": round(padded_all * args.steps / elapsed, 1),
+            "loss_total": round(losses.get("total", float("nan")), 5),
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -178,12 +178,25 @@ def _workspace(n: int, device) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------
 # GEMM family
 # ------------------------------------------------------------------------------------------
+#: when a list, every GEMM launch appends (start_event, end_event, algorithmic_flops, Mc, Nc, R):
+#: bench.py's live roofline measurement of the dominant kernel (HIP events on the launch stream)
+GEMM_PROFILE = None
+
+
 def _gemm(**kw):
     a = GemmArgs()
     a.taps, a.alpha, a.res_scale, a.splitk = 1, 1.0, 1.0, 1
     for k, v in kw.items():
         setattr(a, k, v)
+    if GEMM_PROFILE is None:
+        _ok(lib().fs2hip_gemm(C.byref(a), _stream()), "gemm")
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     _ok(lib().fs2hip_gemm(C.byref(a), _stream()), "gemm")
+    e1.record()
+    ntap = a.taps if a.shift_operand == 1 else 1
+    GEMM_PROFILE.append((e0, e1, 2.0 * a.Mc * a.Nc * a.R * ntap, a.Mc, a.Nc, a.R * ntap))
 
 
 def linear_fwd(x, w, bias=None, *, epi=EPI_STORE, act=None, resid=None, res_scale=1.0, out_pre=None,

@@ -498,53 +498,8 @@ class FastSpeech2Oracle(nn.Module):
         return fastspeech2_loss(self.config, output, batch, current_epoch)
 
 
-# --------------------------------------------------------------------------- #
-# synthetic LJSpeech-shaped batch -- shared by tests and bench
-# --------------------------------------------------------------------------- #
-def synthetic_batch(B=2, ts_lo=48, ts_hi=64, n_symbols=64, n_mels=80, seed=1234,
-                    learn_alignment=False, dur_hi=9, frame_level=False):
-    g = torch.Generator().manual_seed(seed)
-    src_lens = torch.randint(ts_lo, ts_hi + 1, (B,), generator=g, dtype=torch.int32)
-    src_lens[0] = ts_hi
-    Ts = int(src_lens.max())
-    text = torch.randint(1, n_symbols, (B, Ts), generator=g, dtype=torch.int32)
-    dur = torch.randint(1, dur_hi + 1, (B, Ts), generator=g, dtype=torch.int32)
-    smask = torch.arange(Ts)[None, :] < src_lens[:, None]
-    text = text * smask
-    dur = dur * smask
-    mel_lens = dur.sum(1).to(torch.int32)
-    Tm = int(mel_lens.max())
-    tmask = torch.arange(Tm)[None, :] < mel_lens[:, None]
-    mel = torch.randn(B, Tm, n_mels, generator=g) * tmask[..., None]
-    lvl_frames = learn_alignment or frame_level
-    if lvl_frames:
-        pitch = torch.randn(B, Tm, generator=g) * tmask
-        energy = torch.randn(B, Tm, generator=g) * tmask
-    else:
-        pitch = torch.randn(B, Ts, generator=g) * smask
-        energy = torch.randn(B, Ts, generator=g) * smask
-    batch = dict(text=text, src_lens=src_lens, max_src_len=Ts, mel=mel, mel_lens=mel_lens,
-                 max_mel_len=Tm, pitch=pitch, energy=energy,
-                 speaker_id=torch.zeros(B, dtype=torch.int32),
-                 language_id=torch.zeros(B, dtype=torch.int32))
-    if learn_alignment:
-        batch["duration"] = beta_binomial_prior(mel_lens, src_lens, Tm, Ts)
-    else:
-        batch["duration"] = dur
-    return batch
-
-
-def beta_binomial_prior(mel_lens, src_lens, Tm, Ts, scaling=1.0):
-    """Attention prior of the aligner's data pipeline (beta-binomial over text
-    positions for each frame), zero padded to (B, Tm, Ts)."""
-    from scipy.stats import betabinom
-
-    out = torch.zeros(len(mel_lens), Tm, Ts)
-    for b, (t1, t2) in enumerate(zip(mel_lens.tolist(), src_lens.tolist())):
-        k = np.arange(t2)
-        rows = [betabinom(t2 - 1, scaling * i, scaling * (t1 + 1 - i)).pmf(k) for i in range(1, t1 + 1)]
-        out[b, :t1, :t2] = torch.tensor(np.array(rows), dtype=torch.float32)
-    return out
+# synthetic LJSpeech-shaped batches are defined once, in the product package
+from fastspeech2_lightning_amd.synthetic import beta_binomial_prior, synthetic_batch  # noqa: E402,F401
 
 
 # --------------------------------------------------------------------------- #

@@ -5,6 +5,7 @@ import re
 from pathlib import Path
 
 import pytest
+import torch  # noqa: F401  (before the library: one HIP runtime per process)
 
 REPO = Path(__file__).resolve().parent.parent
 
