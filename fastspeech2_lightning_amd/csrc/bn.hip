@@ -5,51 +5,84 @@
 // fs2/model.py:193, :241) and nn.BatchNorm1d + tanh + F.dropout in PostNet (fs2/layers.py:204-212).
 //
 //   statistics : colstats (or the depthwise-conv kernel's fused partials)  -> partial[nparts][2][C]
-//   finalize   : fp64 finish of the partials, running-stat update, per-channel scale/shift
+//   finalize   : fp64 finish of the partials (64 channels x 16 part lanes per workgroup),
+//                running-stat update, per-channel scale/shift
 //   apply      : out = dropout(act(y*scale + shift))                         (one pass)
 //   backward   : reduce (sum dz, sum dz*xhat) -> finalize (dgamma, dbeta, means) -> apply
+// The statistics passes sweep whole rows (contiguous >= 1 KiB per wavefront instruction).
 #include "common.h"
 
 namespace {
 
-constexpr int CS_ROWS = 256;  // rows per workgroup in the column-statistics passes
+constexpr int CS_ROWS = 128;  // rows per workgroup in the column-statistics passes
 
-__global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__ y, int M, int C,
-                                                        float* __restrict__ partial) {
-  __shared__ float red[4][2][64];
-  const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
-  const int r0 = blockIdx.y * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
-  float s1 = 0.f, s2 = 0.f;
-  if (c < C)
-    for (int r = r0 + rl; r < r1; r += 4) {
-      float v = y[(long long)r * C + c];
-      s1 += v;
-      s2 += v * v;
+// thread -> (row lane rl, float4 column c4): tpr = C/4 threads per row, rpi = 256/tpr rows per pass
+struct WideMap {
+  int tpr, rpi;
+};
+
+__global__ __launch_bounds__(256) void colstats_wide_kernel(const float* __restrict__ y, int M, int C,
+                                                             float* __restrict__ partial, WideMap wm) {
+  __shared__ float4 red[2][256];
+  const int tid = threadIdx.x;
+  const int rl = tid / wm.tpr, c4 = tid - rl * wm.tpr;
+  const int r0 = blockIdx.x * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
+  float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
+  if (rl < wm.rpi)
+    for (int r = r0 + rl; r < r1; r += wm.rpi) {
+      float4 v = *reinterpret_cast<const float4*>(y + (long long)r * C + c4 * 4);
+      s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+      s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
     }
-  red[rl][0][lane] = s1;
-  red[rl][1][lane] = s2;
+  red[0][tid] = s1;
+  red[1][tid] = s2;
   __syncthreads();
-  if (rl == 0 && c < C) {
-    partial[((long long)blockIdx.y * 2 + 0) * C + c] = red[0][0][lane] + red[1][0][lane] + red[2][0][lane] + red[3][0][lane];
-    partial[((long long)blockIdx.y * 2 + 1) * C + c] = red[0][1][lane] + red[1][1][lane] + red[2][1][lane] + red[3][1][lane];
+  if (rl == 0) {
+    for (int l = 1; l < wm.rpi; ++l) {
+      float4 a = red[0][l * wm.tpr + c4], b = red[1][l * wm.tpr + c4];
+      s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
+      s2.x += b.x; s2.y += b.y; s2.z += b.z; s2.w += b.w;
+    }
+    *reinterpret_cast<float4*>(partial + ((long long)blockIdx.x * 2 + 0) * C + c4 * 4) = s1;
+    *reinterpret_cast<float4*>(partial + ((long long)blockIdx.x * 2 + 1) * C + c4 * 4) = s2;
   }
 }
 
-// stats layout (per channel): [0]=scale (gamma*invstd) [1]=shift (beta-mean*scale) [2]=mean [3]=invstd
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nparts, long long count,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
-                                   int training, float* __restrict__ stats, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float mean, invstd;
-  if (training) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int p = 0; p < nparts; ++p) {
-      s1 += (double)partial[((long long)p * 2 + 0) * C + c];
-      s2 += (double)partial[((long long)p * 2 + 1) * C + c];
+// fp64 sum over parts of partial[p][2][C] for 64 channels: lanes 0..15 split the parts
+__device__ __forceinline__ void reduce_parts(const float* __restrict__ partial, int nparts, int C, int c, int rl,
+                                             int lane, double (&red)[2][16][64], double& s1, double& s2) {
+  double a = 0.0, b = 0.0;
+  if (c < C)
+    for (int p = rl; p < nparts; p += 16) {
+      a += (double)partial[((long long)p * 2 + 0) * C + c];
+      b += (double)partial[((long long)p * 2 + 1) * C + c];
     }
+  red[0][rl][lane] = a;
+  red[1][rl][lane] = b;
+  __syncthreads();
+  s1 = 0.0;
+  s2 = 0.0;
+  if (rl == 0)
+    for (int l = 0; l < 16; ++l) {
+      s1 += red[0][l][lane];
+      s2 += red[1][l][lane];
+    }
+}
+
+// stats layout (per channel): [0]=scale (gamma*invstd) [1]=shift (beta-mean*scale) [2]=mean [3]=invstd
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ partial, int nparts,
+                                                            long long count, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ rmean,
+                                                            float* __restrict__ rvar, float momentum, float eps,
+                                                            int training, float* __restrict__ stats, int C) {
+  __shared__ double red[2][16][64];
+  const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  float mean = 0.f, invstd = 0.f;
+  if (training) {
+    double s1, s2;
+    reduce_parts(partial, nparts, C, c, rl, lane, red, s1, s2);
+    if (rl != 0 || c >= C) return;
     double mu = s1 / (double)count;
     double var = s2 / (double)count - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -61,6 +94,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int nparts
       rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
     }
   } else {
+    if (rl != 0 || c >= C) return;
     mean = rmean[c];
     invstd = 1.f / sqrtf(rvar[c] + eps);
   }
@@ -90,46 +124,59 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
   }
 }
 
+__device__ __forceinline__ float dz_of(float dout, float v, float sc, float sh, int act, const Fs2Drop& drop,
+                                       unsigned long long idx) {
+  return dout * fs2_drop_factor(drop, idx) * fs2_dact(act, fmaf(v, sc, sh));
+}
+
 // dz = dout * dropmask * act'(y*scale+shift) ; partial[blk][0][C] = sum dz, [1] = sum dz * xhat
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dout, const float* __restrict__ y,
                                                              const float* __restrict__ stats, int M, int C, int act,
-                                                             Fs2Drop drop_in, float* __restrict__ partial) {
+                                                             Fs2Drop drop_in, float* __restrict__ partial, WideMap wm) {
   const Fs2Drop drop = fs2_resolve_drop(drop_in);
-  __shared__ float red[4][2][64];
-  const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
-  const int r0 = blockIdx.y * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
-  float s1 = 0.f, s2 = 0.f;
-  if (c < C) {
-    const float sc = stats[c], sh = stats[C + c], mean = stats[2 * C + c], invstd = stats[3 * C + c];
-    for (int r = r0 + rl; r < r1; r += 4) {
-      const long long idx = (long long)r * C + c;
-      const float v = y[idx];
-      const float dz = dout[idx] * fs2_drop_factor(drop, (unsigned long long)idx) * fs2_dact(act, fmaf(v, sc, sh));
-      s1 += dz;
-      s2 += dz * (v - mean) * invstd;
+  __shared__ float4 red[2][256];
+  const int tid = threadIdx.x;
+  const int rl = tid / wm.tpr, c4 = tid - rl * wm.tpr;
+  const int r0 = blockIdx.x * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
+  float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
+  if (rl < wm.rpi) {
+    const float4 sc = reinterpret_cast<const float4*>(stats)[c4], sh = reinterpret_cast<const float4*>(stats + C)[c4];
+    const float4 mu = reinterpret_cast<const float4*>(stats + 2 * C)[c4], is = reinterpret_cast<const float4*>(stats + 3 * C)[c4];
+    for (int r = r0 + rl; r < r1; r += wm.rpi) {
+      const long long idx = (long long)r * C + c4 * 4;
+      const float4 v = *reinterpret_cast<const float4*>(y + idx);
+      const float4 d = *reinterpret_cast<const float4*>(dout + idx);
+      float dz;
+      dz = dz_of(d.x, v.x, sc.x, sh.x, act, drop, idx + 0); s1.x += dz; s2.x += dz * (v.x - mu.x) * is.x;
+      dz = dz_of(d.y, v.y, sc.y, sh.y, act, drop, idx + 1); s1.y += dz; s2.y += dz * (v.y - mu.y) * is.y;
+      dz = dz_of(d.z, v.z, sc.z, sh.z, act, drop, idx + 2); s1.z += dz; s2.z += dz * (v.z - mu.z) * is.z;
+      dz = dz_of(d.w, v.w, sc.w, sh.w, act, drop, idx + 3); s1.w += dz; s2.w += dz * (v.w - mu.w) * is.w;
     }
   }
-  red[rl][0][lane] = s1;
-  red[rl][1][lane] = s2;
+  red[0][tid] = s1;
+  red[1][tid] = s2;
   __syncthreads();
-  if (rl == 0 && c < C) {
-    partial[((long long)blockIdx.y * 2 + 0) * C + c] = red[0][0][lane] + red[1][0][lane] + red[2][0][lane] + red[3][0][lane];
-    partial[((long long)blockIdx.y * 2 + 1) * C + c] = red[0][1][lane] + red[1][1][lane] + red[2][1][lane] + red[3][1][lane];
+  if (rl == 0) {
+    for (int l = 1; l < wm.rpi; ++l) {
+      float4 a = red[0][l * wm.tpr + c4], b = red[1][l * wm.tpr + c4];
+      s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
+      s2.x += b.x; s2.y += b.y; s2.z += b.z; s2.w += b.w;
+    }
+    *reinterpret_cast<float4*>(partial + ((long long)blockIdx.x * 2 + 0) * C + c4 * 4) = s1;
+    *reinterpret_cast<float4*>(partial + ((long long)blockIdx.x * 2 + 1) * C + c4 * 4) = s2;
   }
 }
 
 // dgamma = sum dz*xhat, dbeta = sum dz; coef[0][c] = mean(dz), coef[1][c] = mean(dz*xhat)
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nparts, long long count,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                       float* __restrict__ coef, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int p = 0; p < nparts; ++p) {
-    s1 += (double)partial[((long long)p * 2 + 0) * C + c];
-    s2 += (double)partial[((long long)p * 2 + 1) * C + c];
-  }
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nparts,
+                                                                long long count, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta, float* __restrict__ coef, int C) {
+  __shared__ double red[2][16][64];
+  const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  double s1, s2;
+  reduce_parts(partial, nparts, C, c, rl, lane, red, s1, s2);
+  if (rl != 0 || c >= C) return;
   dbeta[c] = (float)s1;
   dgamma[c] = (float)s2;
   coef[c] = (float)(s1 / (double)count);
@@ -139,20 +186,37 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int np
 // dy = scale * (dz - mean(dz) - xhat * mean(dz*xhat))   [training]   or scale * dz   [eval]
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ y,
                                                             const float* __restrict__ stats, const float* __restrict__ coef,
-                                                            float* __restrict__ dy, long long n, int C, int act,
+                                                            float* __restrict__ dy, long long n4, int C, int act,
                                                             Fs2Drop drop_in, int training) {
   const Fs2Drop drop = fs2_resolve_drop(drop_in);
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    const float sc = stats[c], sh = stats[C + c];
-    const float v = y[i];
-    float dz = dout[i] * fs2_drop_factor(drop, (unsigned long long)i) * fs2_dact(act, fmaf(v, sc, sh));
+  const int c4n = C >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % c4n);
+    const float4 sc = reinterpret_cast<const float4*>(stats)[c4], sh = reinterpret_cast<const float4*>(stats + C)[c4];
+    const float4 v = reinterpret_cast<const float4*>(y)[i];
+    const float4 d = reinterpret_cast<const float4*>(dout)[i];
+    float4 dz;
+    dz.x = dz_of(d.x, v.x, sc.x, sh.x, act, drop, (unsigned long long)(i * 4 + 0));
+    dz.y = dz_of(d.y, v.y, sc.y, sh.y, act, drop, (unsigned long long)(i * 4 + 1));
+    dz.z = dz_of(d.z, v.z, sc.z, sh.z, act, drop, (unsigned long long)(i * 4 + 2));
+    dz.w = dz_of(d.w, v.w, sc.w, sh.w, act, drop, (unsigned long long)(i * 4 + 3));
     if (training) {
-      const float xhat = (v - stats[2 * C + c]) * stats[3 * C + c];
-      dz = dz - coef[c] - xhat * coef[C + c];
+      const float4 mu = reinterpret_cast<const float4*>(stats + 2 * C)[c4], is = reinterpret_cast<const float4*>(stats + 3 * C)[c4];
+      const float4 k1 = reinterpret_cast<const float4*>(coef)[c4], k2 = reinterpret_cast<const float4*>(coef + C)[c4];
+      dz.x = dz.x - k1.x - (v.x - mu.x) * is.x * k2.x;
+      dz.y = dz.y - k1.y - (v.y - mu.y) * is.y * k2.y;
+      dz.z = dz.z - k1.z - (v.z - mu.z) * is.z * k2.z;
+      dz.w = dz.w - k1.w - (v.w - mu.w) * is.w * k2.w;
     }
-    dy[i] = sc * dz;
+    reinterpret_cast<float4*>(dy)[i] = make_float4(sc.x * dz.x, sc.y * dz.y, sc.z * dz.z, sc.w * dz.w);
   }
+}
+
+bool wide_ok(int C, WideMap& wm) {
+  if ((C % 4) || C > 1024) return false;
+  wm.tpr = C / 4;
+  wm.rpi = 256 / wm.tpr;
+  return true;
 }
 
 }  // namespace
@@ -160,8 +224,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 extern "C" int fs2hip_colstats_parts(int M) { return (M + CS_ROWS - 1) / CS_ROWS; }
 
 extern "C" int fs2hip_colstats(const float* y, int M, int C, float* partial, void* stream) {
-  if (M <= 0 || C <= 0) return FS2HIP_EINVAL;
-  colstats_kernel<<<dim3((C + 63) / 64, fs2hip_colstats_parts(M)), dim3(256), 0, (hipStream_t)stream>>>(y, M, C, partial);
+  WideMap wm;
+  if (M <= 0 || C <= 0 || !wide_ok(C, wm) || ((uintptr_t)y % 16) || ((uintptr_t)partial % 16)) return FS2HIP_EINVAL;
+  colstats_wide_kernel<<<dim3(fs2hip_colstats_parts(M)), dim3(256), 0, (hipStream_t)stream>>>(y, M, C, partial, wm);
   FS2_LAUNCH_CHECK();
   return 0;
 }
@@ -171,7 +236,7 @@ extern "C" int fs2hip_bn_finalize(const float* partial, int nparts, long long co
                                   float eps, int training, float* stats, int C, void* stream) {
   if (C <= 0 || (training && (nparts <= 0 || count <= 0 || !partial)) || (!training && (!running_mean || !running_var)))
     return FS2HIP_EINVAL;
-  bn_finalize_kernel<<<dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream>>>(
+  bn_finalize_kernel<<<dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream>>>(
       partial, nparts, count, gamma, beta, running_mean, running_var, momentum, eps, training, stats, C);
   FS2_LAUNCH_CHECK();
   return 0;
@@ -190,23 +255,27 @@ extern "C" int fs2hip_bn_act_fwd(const float* y, const float* stats, float* out,
   return 0;
 }
 
-// partial: [fs2hip_colstats_parts(M)][2][C]; coef: [2][C] scratch
+// partial: [fs2hip_colstats_parts(M)][2][C]; coef: [2][C] scratch (16-byte aligned)
 extern "C" int fs2hip_bn_act_bwd(const float* dout, const float* y, const float* stats, float* partial, float* coef,
                                  float* dgamma, float* dbeta, float* dy, int M, int C, int act, float drop_p,
                                  unsigned long long drop_seed, const unsigned long long* drop_step, int training,
                                  void* stream) {
-  if (M <= 0 || C <= 0) return FS2HIP_EINVAL;
+  WideMap wm;
+  if (M <= 0 || C <= 0 || !wide_ok(C, wm)) return FS2HIP_EINVAL;
+  if (((uintptr_t)dout % 16) || ((uintptr_t)y % 16) || ((uintptr_t)stats % 16) || ((uintptr_t)partial % 16) ||
+      ((uintptr_t)coef % 16) || ((uintptr_t)dy % 16))
+    return FS2HIP_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const Fs2Drop drop = fs2_make_drop(drop_p, drop_seed, drop_step);
   const int nparts = fs2hip_colstats_parts(M);
-  bn_bwd_reduce_kernel<<<dim3((C + 63) / 64, nparts), dim3(256), 0, s>>>(dout, y, stats, M, C, act, drop, partial);
+  bn_bwd_reduce_kernel<<<dim3(nparts), dim3(256), 0, s>>>(dout, y, stats, M, C, act, drop, partial, wm);
   FS2_LAUNCH_CHECK();
-  bn_bwd_finalize_kernel<<<dim3((C + 63) / 64), dim3(64), 0, s>>>(partial, nparts, (long long)M, dgamma, dbeta, coef, C);
+  bn_bwd_finalize_kernel<<<dim3((C + 63) / 64), dim3(1024), 0, s>>>(partial, nparts, (long long)M, dgamma, dbeta, coef, C);
   FS2_LAUNCH_CHECK();
-  const long long n = (long long)M * C;
-  long long blocks = (n + 255) / 256;
+  const long long n4 = (long long)M * C / 4;
+  long long blocks = (n4 + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  bn_bwd_apply_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(dout, y, stats, coef, dy, n, C, act, drop, training);
+  bn_bwd_apply_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(dout, y, stats, coef, dy, n4, C, act, drop, training);
   FS2_LAUNCH_CHECK();
   return 0;
 }

@@ -89,3 +89,8 @@ __device__ __forceinline__ float fs2_wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+
+// ---- shared host-side launchers (reduce.hip) ----------------------------------------------------
+// out0[c] = sum over rows of src[r*stride + c] for c < n0, out1[c - n0] for n0 <= c < n
+int fs2_reduce_rows(const float* src, int rows, int n, long long stride, float* out0, int n0, float* out1,
+                    hipStream_t s);

@@ -231,86 +231,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   }
 }
 
-template <bool VEC>
-__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out, long long n,
-                                    int nslabs, long long stride) {
-  if (VEC) {
-    long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    const long long step = (long long)gridDim.x * blockDim.x * 4;
-    for (; i < n; i += step) {
-      if (i + 3 < n) {
-        float4 s = *reinterpret_cast<const float4*>(slabs + i);
-        for (int k = 1; k < nslabs; ++k) {
-          float4 v = *reinterpret_cast<const float4*>(slabs + k * stride + i);
-          s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        }
-        *reinterpret_cast<float4*>(out + i) = s;
-      } else {
-        for (long long e = i; e < n; ++e) {
-          float s = slabs[e];
-          for (int k = 1; k < nslabs; ++k) s += slabs[k * stride + e];
-          out[e] = s;
-        }
-      }
-    }
-  } else {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long step = (long long)gridDim.x * blockDim.x;
-    for (; i < n; i += step) {
-      float s = slabs[i];
-      for (int k = 1; k < nslabs; ++k) s += slabs[k * stride + i];
-      out[i] = s;
-    }
-  }
-}
-
-// column sums: block (64 columns) x row stripes; 256 threads = 4 row lanes x 64 columns
-constexpr int COLSUM_ROWS_PER_BLOCK = 512;
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int ldx, int M, int N,
-                                                      float* __restrict__ partial) {
-  __shared__ float red[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int rl = threadIdx.x >> 6;
-  const int r0 = blockIdx.y * COLSUM_ROWS_PER_BLOCK;
-  const int r1 = min(M, r0 + COLSUM_ROWS_PER_BLOCK);
-  float s = 0.f;
-  if (c < N)
-    for (int r = r0 + rl; r < r1; r += 4) s += x[(long long)r * ldx + c];
-  red[rl][threadIdx.x & 63] = s;
-  __syncthreads();
-  if (rl == 0 && c < N)
-    partial[(long long)blockIdx.y * N + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-}
-
 }  // namespace
 
 extern "C" int fs2hip_version(void) { return 1; }
-
-extern "C" int fs2hip_reduce_slabs(const float* slabs, float* out, long long n, int nslabs,
-                                   long long slab_stride, void* stream) {
-  if (n <= 0) return 0;
-  if (nslabs < 1) return FS2HIP_EINVAL;
-  const bool vec = (slab_stride % 4) == 0 && ((uintptr_t)slabs % 16) == 0 && ((uintptr_t)out % 16) == 0;
-  long long blocks = ((vec ? n / 4 : n) + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
-  if (blocks < 1) blocks = 1;
-  if (vec)
-    reduce_slabs_kernel<true><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(slabs, out, n, nslabs, slab_stride);
-  else
-    reduce_slabs_kernel<false><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(slabs, out, n, nslabs, slab_stride);
-  FS2_LAUNCH_CHECK();
-  return 0;
-}
-
-extern "C" int fs2hip_colsum_rows(int M) { return (M + COLSUM_ROWS_PER_BLOCK - 1) / COLSUM_ROWS_PER_BLOCK; }
-
-extern "C" int fs2hip_colsum(const float* x, int ldx, int M, int N, float* partial, float* out, void* stream) {
-  if (M <= 0 || N <= 0) return FS2HIP_EINVAL;
-  int gy = fs2hip_colsum_rows(M);
-  colsum_kernel<<<dim3((N + 63) / 64, gy), dim3(256), 0, (hipStream_t)stream>>>(x, ldx, M, N, partial);
-  FS2_LAUNCH_CHECK();
-  return fs2hip_reduce_slabs(partial, out, N, gy, N, stream);
-}
 
 extern "C" int fs2hip_gemm(const Fs2GemmArgs* args, void* stream) {
   GemmP p;
@@ -323,8 +246,10 @@ extern "C" int fs2hip_gemm(const Fs2GemmArgs* args, void* stream) {
   // floats and rows start 16-byte aligned
   if ((a.lda % 4) || (a.ldb % 4)) return FS2HIP_EINVAL;
   if (((uintptr_t)a.A % 16) || ((uintptr_t)a.B % 16)) return FS2HIP_EINVAL;
-  if (a.a_kcontig ? (a.R / (a.shift_operand == 0 ? a.taps : 1)) % 4 : a.Mc % 4) return FS2HIP_EINVAL;
-  if (a.b_kcontig ? (a.R / (a.shift_operand == 0 ? a.taps : 1)) % 4 : a.Nc % 4) return FS2HIP_EINVAL;
+  // (a reduction-major operand may have a row count that is not a multiple of 4 as long as its leading
+  // dimension covers the rounded-up width: the float4 that straddles the edge stays inside the row)
+  if (a.a_kcontig ? (a.R / (a.shift_operand == 0 ? a.taps : 1)) % 4 : a.lda < ((a.Mc + 3) / 4) * 4) return FS2HIP_EINVAL;
+  if (a.b_kcontig ? (a.R / (a.shift_operand == 0 ? a.taps : 1)) % 4 : a.ldb < ((a.Nc + 3) / 4) * 4) return FS2HIP_EINVAL;
   p.Rper = a.R;
   if (a.taps > 1) {
     if (a.T <= 0 || a.Mc <= 0) return FS2HIP_EINVAL;

@@ -48,25 +48,16 @@ __global__ __launch_bounds__(256) void embedding_fwd_kernel(const int* __restric
   for (int i = lane; i < (D >> 2); i += 64) dst[i] = src[i];
 }
 
-// dW[v,:] = sum_{m: idx[m]==v} dy[m,:]   (padding row -> 0).  Deterministic: one workgroup per
-// (vocabulary row, 256-channel chunk) scans the index vector.
-__global__ __launch_bounds__(256) void embedding_bwd_kernel(const int* __restrict__ idx, const float* __restrict__ dy,
-                                                             float* __restrict__ dW, int M, int V, int D, int padding_idx) {
-  __shared__ int sidx[1024];
-  const int v = blockIdx.x;
-  const int c = blockIdx.y * 256 + threadIdx.x;
-  float acc = 0.f;
-  for (int m0 = 0; m0 < M; m0 += 1024) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < 1024; i += 256) sidx[i] = (m0 + i < M) ? idx[m0 + i] : -1;
-    __syncthreads();
-    if (c < D) {
-      const int lim = min(1024, M - m0);
-      for (int i = 0; i < lim; ++i)
-        if (sidx[i] == v) acc += dy[(long long)(m0 + i) * D + c];
-    }
+// one-hot rows for the embedding backward: dW = onehot^T @ dy runs as a weight-gradient GEMM on the
+// matrix cores (deterministic).  out is [M][Vp]; the padding row never gets a 1 (its gradient is 0).
+__global__ __launch_bounds__(256) void onehot_kernel(const int* __restrict__ idx, float* __restrict__ out, int M,
+                                                      int Vp, int padding_idx) {
+  const long long n = (long long)M * Vp;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int m = (int)(i / Vp), v = (int)(i % Vp);
+    const int k = idx[m];
+    out[i] = (k == v && k != padding_idx) ? 1.f : 0.f;
   }
-  if (c < D) dW[(long long)v * D + c] = (v == padding_idx) ? 0.f : acc;
 }
 
 // fs2/variance_adaptor.py:197-205, :322, :343  torch.bucketize (right=False) + embedding + add
@@ -379,10 +370,9 @@ extern "C" int fs2hip_embedding_fwd(const int* idx, const float* W, float* out, 
   return 0;
 }
 
-extern "C" int fs2hip_embedding_bwd(const int* idx, const float* dy, float* dW, int M, int V, int D, int padding_idx,
-                                    void* stream) {
-  if (M <= 0 || V <= 0 || D <= 0) return FS2HIP_EINVAL;
-  embedding_bwd_kernel<<<dim3(V, (D + 255) / 256), dim3(256), 0, S_>>>(idx, dy, dW, M, V, D, padding_idx);
+extern "C" int fs2hip_onehot(const int* idx, float* out, int M, int Vp, int padding_idx, void* stream) {
+  if (M <= 0 || Vp <= 0 || (Vp % 4)) return FS2HIP_EINVAL;
+  onehot_kernel<<<dim3(grid_for((long long)M * Vp, 256, 8192)), dim3(256), 0, S_>>>(idx, out, M, Vp, padding_idx);
   FS2_LAUNCH_CHECK();
   return 0;
 }

@@ -5,7 +5,7 @@
 namespace {
 
 constexpr int LN_MAX_CH = 4;           // C <= 1024: at most 4 float4 chunks per lane
-constexpr int LN_BWD_ROWS = 32;        // rows per workgroup in the backward (4 waves x 8 rows)
+constexpr int LN_BWD_ROWS = 128;       // rows per workgroup in the backward (4 waves x 32 rows)
 
 template <int NCH>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
@@ -131,16 +131,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   }
 }
 
-// dgamma/dbeta finish: out[k][c] = sum_blk partial[blk][k][c]
-__global__ void ln_bwd_finish_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
-                                     float* __restrict__ dbeta, int nblk, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= 2 * C) return;
-  float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += partial[(long long)b * 2 * C + c];
-  if (c < C) dgamma[c] = s; else dbeta[c - C] = s;
-}
-
 }  // namespace
 
 extern "C" int fs2hip_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
@@ -176,7 +166,6 @@ extern "C" int fs2hip_layernorm_bwd(const float* dy, const float* x, const float
     default: ln_bwd_kernel<4><<<dim3(nblk), dim3(256), 0, s>>>(dy, x, gamma, mean, rstd, dx_add, dx, partial, M, C); break;
   }
   FS2_LAUNCH_CHECK();
-  ln_bwd_finish_kernel<<<dim3((2 * C + 255) / 256), dim3(256), 0, s>>>(partial, dgamma, dbeta, nblk, C);
-  FS2_LAUNCH_CHECK();
-  return 0;
+  // partial is [nblk][2][C]: columns [0, C) -> dgamma, [C, 2C) -> dbeta
+  return fs2_reduce_rows(partial, nblk, 2 * C, 2LL * C, dgamma, C, dbeta, s);
 }

@@ -1,0 +1,157 @@
+// Row reductions of dense [rows][n] fp32 matrices (bias gradients, split-K slabs, per-workgroup
+// partial sums of the norm / conv kernels).  HBM-bound; deterministic (fixed summation order).
+//
+//   wide   : [M][N] with M large, N <= 1024: a workgroup sweeps whole rows (every wavefront
+//            instruction is a contiguous >= 1 KiB piece) and leaves one partial row per 128 rows;
+//   small  : few hundred rows, n <= 16384: 64 columns x 16 row lanes per 1024-thread workgroup;
+//   slabs  : few slabs of a large n (split-K): column-parallel float4.
+#include "common.h"
+
+namespace {
+
+constexpr int WIDE_ROWS = 128;
+
+// NACC accumulators per thread: 1 = sum(x); 2 = (sum x, sum x*x)
+__global__ __launch_bounds__(256) void colsum_wide_kernel(const float* __restrict__ x, int ldx, int M, int N,
+                                                           float* __restrict__ partial, int tpr, int rpi) {
+  __shared__ float4 red[256];
+  const int tid = threadIdx.x;
+  const int rl = tid / tpr, c4 = tid - rl * tpr;
+  const bool active = rl < rpi;
+  const int r0 = blockIdx.x * WIDE_ROWS, r1 = min(M, r0 + WIDE_ROWS);
+  float4 acc = make_float4(0, 0, 0, 0);
+  if (active)
+    for (int r = r0 + rl; r < r1; r += rpi) {
+      float4 v = *reinterpret_cast<const float4*>(x + (long long)r * ldx + c4 * 4);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  red[tid] = acc;
+  __syncthreads();
+  if (rl == 0) {
+    for (int l = 1; l < rpi; ++l) {
+      float4 v = red[l * tpr + c4];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(partial + (long long)blockIdx.x * N + c4 * 4) = acc;
+  }
+}
+
+// generic strided fallback (N not a multiple of 4 or wider than 1024)
+__global__ __launch_bounds__(256) void colsum_strided_kernel(const float* __restrict__ x, int ldx, int M, int N,
+                                                              float* __restrict__ partial) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * WIDE_ROWS, r1 = min(M, r0 + WIDE_ROWS);
+  float s = 0.f;
+  if (c < N)
+    for (int r = r0 + rl; r < r1; r += 4) s += x[(long long)r * ldx + c];
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < N)
+    partial[(long long)blockIdx.y * N + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(1024) void reduce_rows_small_kernel(const float* __restrict__ src, int rows, int n,
+                                                                  long long stride, float* __restrict__ out0, int n0,
+                                                                  float* __restrict__ out1) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (c < n) {
+    int r = rl;
+    for (; r + 48 < rows; r += 64) {
+      float a = src[(long long)r * stride + c], b = src[(long long)(r + 16) * stride + c];
+      float d = src[(long long)(r + 32) * stride + c], e = src[(long long)(r + 48) * stride + c];
+      s += (a + b) + (d + e);
+    }
+    for (; r < rows; r += 16) s += src[(long long)r * stride + c];
+  }
+  red[rl][lane] = s;
+  __syncthreads();
+  if (rl == 0 && c < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) t += red[l][lane];
+    if (c < n0) out0[c] = t; else out1[c - n0] = t;
+  }
+}
+
+template <bool VEC>
+__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out, long long n,
+                                    int nslabs, long long stride) {
+  if (VEC) {
+    long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const long long step = (long long)gridDim.x * blockDim.x * 4;
+    for (; i < n; i += step) {
+      if (i + 3 < n) {
+        float4 s = *reinterpret_cast<const float4*>(slabs + i);
+        for (int k = 1; k < nslabs; ++k) {
+          float4 v = *reinterpret_cast<const float4*>(slabs + k * stride + i);
+          s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *reinterpret_cast<float4*>(out + i) = s;
+      } else {
+        for (long long e = i; e < n; ++e) {
+          float s = slabs[e];
+          for (int k = 1; k < nslabs; ++k) s += slabs[k * stride + e];
+          out[e] = s;
+        }
+      }
+    }
+  } else {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += step) {
+      float s = slabs[i];
+      for (int k = 1; k < nslabs; ++k) s += slabs[k * stride + i];
+      out[i] = s;
+    }
+  }
+}
+
+}  // namespace
+
+// internal (declared in common.h): out0[c] for c < n0, out1[c - n0] otherwise
+int fs2_reduce_rows(const float* src, int rows, int n, long long stride, float* out0, int n0, float* out1,
+                    hipStream_t s) {
+  if (rows <= 0 || n <= 0) return FS2HIP_EINVAL;
+  reduce_rows_small_kernel<<<dim3((n + 63) / 64), dim3(1024), 0, s>>>(src, rows, n, stride, out0, n0, out1);
+  FS2_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fs2hip_reduce_slabs(const float* slabs, float* out, long long n, int nslabs,
+                                   long long slab_stride, void* stream) {
+  if (n <= 0) return 0;
+  if (nslabs < 1) return FS2HIP_EINVAL;
+  if (n <= 16384 && nslabs >= 8)
+    return fs2_reduce_rows(slabs, nslabs, (int)n, slab_stride, out, (int)n, nullptr, (hipStream_t)stream);
+  const bool vec = (slab_stride % 4) == 0 && ((uintptr_t)slabs % 16) == 0 && ((uintptr_t)out % 16) == 0;
+  long long blocks = ((vec ? n / 4 : n) + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  if (vec)
+    reduce_slabs_kernel<true><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(slabs, out, n, nslabs, slab_stride);
+  else
+    reduce_slabs_kernel<false><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(slabs, out, n, nslabs, slab_stride);
+  FS2_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fs2hip_colsum_rows(int M) { return (M + WIDE_ROWS - 1) / WIDE_ROWS; }
+
+extern "C" int fs2hip_colsum(const float* x, int ldx, int M, int N, float* partial, float* out, void* stream) {
+  if (M <= 0 || N <= 0) return FS2HIP_EINVAL;
+  const int gy = fs2hip_colsum_rows(M);
+  hipStream_t s = (hipStream_t)stream;
+  if ((N % 4) == 0 && N <= 1024 && (ldx % 4) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)partial % 16) == 0) {
+    const int tpr = N / 4, rpi = 256 / tpr;
+    colsum_wide_kernel<<<dim3(gy), dim3(256), 0, s>>>(x, ldx, M, N, partial, tpr, rpi);
+  } else {
+    colsum_strided_kernel<<<dim3((N + 63) / 64, gy), dim3(256), 0, s>>>(x, ldx, M, N, partial);
+  }
+  FS2_LAUNCH_CHECK();
+  return fs2_reduce_rows(partial, gy, N, N, out, N, nullptr, s);
+}

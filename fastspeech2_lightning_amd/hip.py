@@ -67,7 +67,7 @@ SIGNATURES = {
     "fs2hip_posenc_table": "ppiip",
     "fs2hip_add_posenc": "ppppiiip",
     "fs2hip_embedding_fwd": "pppiiip",
-    "fs2hip_embedding_bwd": "pppiiiip",
+    "fs2hip_onehot": "ppiiip",
     "fs2hip_bucket_embed_add": "pfpippppiip",
     "fs2hip_length_regulate_fwd": "pppppppiiiip",
     "fs2hip_length_regulate_bwd": "pppiiiip",
@@ -183,12 +183,12 @@ def _workspace(n: int, device) -> torch.Tensor:
 GEMM_PROFILE = None
 
 
-def _gemm(**kw):
+def _gemm(_algorithmic=True, **kw):
     a = GemmArgs()
     a.taps, a.alpha, a.res_scale, a.splitk = 1, 1.0, 1.0, 1
     for k, v in kw.items():
         setattr(a, k, v)
-    if GEMM_PROFILE is None:
+    if GEMM_PROFILE is None or not _algorithmic:  # (the one-hot embedding GEMM's flops are not algorithmic)
         _ok(lib().fs2hip_gemm(C.byref(a), _stream()), "gemm")
         return
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -272,26 +272,28 @@ def pick_splitk(Mc: int, Nc: int, R: int, taps: int = 1) -> int:
     return s
 
 
-def linear_bwd_weight(dy, x, out, *, taps=1, T=0):
+def linear_bwd_weight(dy, x, out, *, taps=1, T=0, n_valid=None):
     """dw[N, K] = dy[M, N]^T @ x[M, K]  (or dw[taps, N, Kper] for the k-tap conv).
-    Written into ``out`` (a view of the flat gradient buffer)."""
+    Written into ``out`` (a view of the flat gradient buffer).  ``n_valid``: only the first
+    n_valid columns of dy produce output rows (dy's row length may be padded to a multiple of 4)."""
     _chk(dy, name="dy"); _chk(x, name="x"); _chk(out, name="out")
-    M, N, K = _rows(dy), dy.shape[-1], x.shape[-1]
-    _req(_rows(x) == M, "linear_bwd_weight: row mismatch")
+    M, lda, K = _rows(dy), dy.shape[-1], x.shape[-1]
+    N = lda if n_valid is None else int(n_valid)
+    _req(_rows(x) == M and N <= lda, "linear_bwd_weight: row mismatch")
     _req(out.numel() == taps * N * K, "linear_bwd_weight: bad gradient shape")
     _req(taps == 1 or (T > 0 and M % T == 0), "linear_bwd_weight: rows must be a multiple of T")
     S = pick_splitk(N, K, M, taps)
-    kw = dict(A=_p(dy), B=_p(x), C=_p(out), Mc=N, Nc=K, R=M, lda=N, ldb=K, ldc=K, a_kcontig=0, b_kcontig=0,
+    kw = dict(A=_p(dy), B=_p(x), C=_p(out), Mc=N, Nc=K, R=M, lda=lda, ldb=K, ldc=K, a_kcontig=0, b_kcontig=0,
               taps=taps, T=T if taps > 1 else 0, tap_mul=1, tap_add=-((taps - 1) // 2),
               shift_operand=1 if taps > 1 else 0, c_tap_stride=N * K, splitk=S)
     if S > 1:
         n = taps * N * K
         ws = _workspace(S * n, dy.device)
         kw["workspace"] = _p(ws)
-        _gemm(**kw)
+        _gemm(_algorithmic=n_valid is None, **kw)
         _ok(lib().fs2hip_reduce_slabs(_p(ws), _p(out), n, S, n, _stream()), "reduce_slabs")
     else:
-        _gemm(**kw)
+        _gemm(_algorithmic=n_valid is None, **kw)
     return out
 
 
@@ -489,12 +491,15 @@ def embedding_fwd(idx, W):
 
 
 def embedding_bwd(idx, dy, dW, padding_idx=-1):
+    """dW[v] = sum of dy rows whose index is v (row ``padding_idx`` stays 0): one-hot^T @ dy on the MFMA GEMM."""
     _chk(idx, torch.int32, "idx"); _chk(dy, name="dy"); _chk(dW, name="dW")
     V, D = dW.shape
-    _req(_rows(dy) == idx.numel() and dy.shape[-1] == D, "embedding_bwd: shape mismatch")
-    _ok(lib().fs2hip_embedding_bwd(_p(idx), _p(dy), _p(dW), idx.numel(), V, D, padding_idx, _stream()),
-        "embedding_bwd")
-    return dW
+    M = idx.numel()
+    _req(_rows(dy) == M and dy.shape[-1] == D, "embedding_bwd: shape mismatch")
+    Vp = (V + 3) // 4 * 4
+    oh = torch.empty(M, Vp, device=dy.device, dtype=torch.float32)
+    _ok(lib().fs2hip_onehot(_p(idx), _p(oh), M, Vp, padding_idx, _stream()), "onehot")
+    return linear_bwd_weight(oh, dy, dW, n_valid=V)
 
 
 def bucket_embed_add(val, bins, W, x, control=1.0):

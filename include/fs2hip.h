@@ -177,8 +177,9 @@ int fs2hip_posenc_table(const float* inv_freq, float* table, int T, int D, void*
 int fs2hip_add_posenc(const float* x, const float* table, const int* lens, float* out, int B, int T, int D,
                       void* stream);
 int fs2hip_embedding_fwd(const int* idx, const float* W, float* out, int M, int V, int D, void* stream);
-int fs2hip_embedding_bwd(const int* idx, const float* dy, float* dW, int M, int V, int D, int padding_idx,
-                         void* stream);
+/* embedding backward = fs2hip_onehot + fs2hip_gemm (dW = onehot^T @ dy; split-K weight-gradient mode):
+ * out[m][v] = (idx[m] == v && v != padding_idx), row length Vp (multiple of 4, >= vocabulary) */
+int fs2hip_onehot(const int* idx, float* out, int M, int Vp, int padding_idx, void* stream);
 /* out = x + W[lower_bound(bins, val*control)]; idx_out (int32, bit-exact vs torch.bucketize) optional */
 int fs2hip_bucket_embed_add(const float* val, float control, const float* bins, int NB, const float* W,
                             const float* x, float* out, int* idx_out, int M, int D, void* stream);
