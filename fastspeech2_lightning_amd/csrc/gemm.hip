@@ -8,6 +8,8 @@
 // is a conflict-free ds_read_b32 of 32 consecutive floats per half-wave.  Global->LDS goes
 // through registers (the loader applies the conv-tap row shift / zero fill and transposes
 // k-contiguous sources on the way), issued one K-tile ahead of the MFMAs.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -272,9 +274,17 @@ extern "C" int fs2hip_gemm(const Fs2GemmArgs* args, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   // tile choice: wide N -> 128x128; narrow N (<= 96 columns left in the last tile would waste
   // matrix-core cycles) -> 128x64
-  const bool narrow = a.Nc <= 64 || (a.Nc % 128 != 0 && a.Nc % 128 <= 64) ||
-                      ((long long)((a.Mc + 127) / 128) * ((a.Nc + 127) / 128) * nz < 384);
-  if (narrow) {
+  bool narrow = a.Nc <= 64 || (a.Nc % 128 != 0 && a.Nc % 128 <= 64) ||
+                ((long long)((a.Mc + 127) / 128) * ((a.Nc + 127) / 128) * nz < 384);
+  static const int env_tile = getenv("FS2_GEMM_TILE") ? atoi(getenv("FS2_GEMM_TILE")) : 0;  // tuning aid
+  const int forced = a.tile ? a.tile : env_tile;
+  if (forced == 1) narrow = false;
+  if (forced == 2) narrow = true;
+  if (forced == 3) {
+    p.tiles_n = (a.Nc + 63) / 64;
+    dim3 grid(((a.Mc + 63) / 64) * p.tiles_n, 1, nz);
+    gemm_kernel<64, 64><<<grid, dim3(256), 0, s>>>(p);
+  } else if (narrow) {
     p.tiles_n = (a.Nc + 63) / 64;
     dim3 grid(((a.Mc + 127) / 128) * p.tiles_n, 1, nz);
     gemm_kernel<128, 64><<<grid, dim3(256), 0, s>>>(p);

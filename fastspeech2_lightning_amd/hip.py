@@ -38,7 +38,7 @@ class GemmArgs(C.Structure):
         ("aux", C.c_void_p), ("ldaux", C.c_int),
         ("out_pre", C.c_void_p), ("ldpre", C.c_int),
         ("drop_p", C.c_float), ("drop_seed", C.c_ulonglong), ("drop_step", C.c_void_p),
-        ("splitk", C.c_int), ("workspace", C.c_void_p),
+        ("splitk", C.c_int), ("workspace", C.c_void_p), ("tile", C.c_int),
     ]
 
 
@@ -183,11 +183,44 @@ def _workspace(n: int, device) -> torch.Tensor:
 GEMM_PROFILE = None
 
 
+#: workgroup-tile autotuner: (shape signature) -> tile id.  A signature is timed once (3 tile shapes x
+#: a few launches with HIP events) the first time it is launched outside a graph capture; the launch
+#: is idempotent (outputs are only overwritten), so re-running it for timing is safe.
+GEMM_TUNE = True
+_TILE_CACHE = {}
+
+
+def _tune_tile(a) -> int:
+    key = (a.Mc, a.Nc, a.R, a.taps, a.a_kcontig, a.b_kcontig, a.shift_operand, a.splitk, a.epi)
+    t = _TILE_CACHE.get(key)
+    if t is not None:
+        return t
+    if not GEMM_TUNE or torch.cuda.is_current_stream_capturing():
+        return 0
+    L, s = lib(), _stream()
+    best, best_ms = 0, float("inf")
+    for tile in (1, 2, 3):
+        a.tile = tile
+        _ok(L.fs2hip_gemm(C.byref(a), s), "gemm")  # warm
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            _ok(L.fs2hip_gemm(C.byref(a), s), "gemm")
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1)
+        if ms < best_ms:
+            best, best_ms = tile, ms
+    _TILE_CACHE[key] = best
+    return best
+
+
 def _gemm(_algorithmic=True, **kw):
     a = GemmArgs()
     a.taps, a.alpha, a.res_scale, a.splitk = 1, 1.0, 1.0, 1
     for k, v in kw.items():
         setattr(a, k, v)
+    a.tile = _tune_tile(a)
     if GEMM_PROFILE is None or not _algorithmic:  # (the one-hot embedding GEMM's flops are not algorithmic)
         _ok(lib().fs2hip_gemm(C.byref(a), _stream()), "gemm")
         return

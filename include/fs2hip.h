@@ -89,6 +89,7 @@ typedef struct {
   const unsigned long long* drop_step; /* device step counter mixed into the seed, or NULL */
   int splitk;
   float* workspace;
+  int tile; /* 0 = heuristic, 1 = 128x128, 2 = 128x64, 3 = 64x64 workgroup tile (chosen by the host autotuner) */
 } Fs2GemmArgs;
 
 int fs2hip_gemm(const Fs2GemmArgs* args, void* stream);
