@@ -14,7 +14,7 @@
 
 namespace {
 
-constexpr int CS_ROWS = 128;  // rows per workgroup in the column-statistics passes
+constexpr int CS_ROWS = 32;   // rows per workgroup in the column-statistics passes
 
 // thread -> (row lane rl, float4 column c4): tpr = C/4 threads per row, rpi = 256/tpr rows per pass
 struct WideMap {

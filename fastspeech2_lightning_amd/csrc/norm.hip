@@ -5,7 +5,7 @@
 namespace {
 
 constexpr int LN_MAX_CH = 4;           // C <= 1024: at most 4 float4 chunks per lane
-constexpr int LN_BWD_ROWS = 128;       // rows per workgroup in the backward (4 waves x 32 rows)
+constexpr int LN_BWD_ROWS = 32;        // rows per workgroup in the backward (4 waves x 8 rows)
 
 template <int NCH>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,

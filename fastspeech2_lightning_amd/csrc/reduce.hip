@@ -9,7 +9,7 @@
 
 namespace {
 
-constexpr int WIDE_ROWS = 128;
+constexpr int WIDE_ROWS = 64;
 
 // NACC accumulators per thread: 1 = sum(x); 2 = (sum x, sum x*x)
 __global__ __launch_bounds__(256) void colsum_wide_kernel(const float* __restrict__ x, int ldx, int M, int N,
@@ -20,11 +20,22 @@ __global__ __launch_bounds__(256) void colsum_wide_kernel(const float* __restric
   const bool active = rl < rpi;
   const int r0 = blockIdx.x * WIDE_ROWS, r1 = min(M, r0 + WIDE_ROWS);
   float4 acc = make_float4(0, 0, 0, 0);
-  if (active)
-    for (int r = r0 + rl; r < r1; r += rpi) {
+  if (active) {
+    int r = r0 + rl;
+    for (; r + 3 * rpi < r1; r += 4 * rpi) {  // four independent loads in flight per thread
+      const float* q = x + (long long)r * ldx + c4 * 4;
+      float4 v0 = *reinterpret_cast<const float4*>(q);
+      float4 v1 = *reinterpret_cast<const float4*>(q + (long long)rpi * ldx);
+      float4 v2 = *reinterpret_cast<const float4*>(q + 2LL * rpi * ldx);
+      float4 v3 = *reinterpret_cast<const float4*>(q + 3LL * rpi * ldx);
+      acc.x += (v0.x + v1.x) + (v2.x + v3.x); acc.y += (v0.y + v1.y) + (v2.y + v3.y);
+      acc.z += (v0.z + v1.z) + (v2.z + v3.z); acc.w += (v0.w + v1.w) + (v2.w + v3.w);
+    }
+    for (; r < r1; r += rpi) {
       float4 v = *reinterpret_cast<const float4*>(x + (long long)r * ldx + c4 * 4);
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
+  }
   red[tid] = acc;
   __syncthreads();
   if (rl == 0) {
