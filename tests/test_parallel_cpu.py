@@ -1,0 +1,88 @@
+"""CPU (gloo, world_size 2): the bucketed gradient exchange of parallel.GradSync over a flat
+gradient buffer -- bucket ranges tile the buffer, every bucket is summed across ranks exactly
+once, parameters/buffers are broadcast from rank 0, and the 1/world factor is exposed for the
+fused optimizer's clip coefficient."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from fastspeech2_lightning_amd import params as P
+from fastspeech2_lightning_amd.parallel import GradSync
+
+
+def make_store():
+    S = P.ParamStore()
+    S.add("a.weight", (7, 5), "id", P.init_normal)
+    S.add("a.bias", (7,), "id", P.init_zeros)
+    S.next_bucket()
+    S.add("b.conv.weight", (6, 4, 3), "convk", P.init_normal)
+    S.add_buffer("b.running_mean", torch.zeros(6))
+    S.next_bucket()
+    S.add("c.dw.weight", (8, 1, 9), "dw", P.init_normal)
+    S.next_bucket()
+    S.add("d.weight", (3, 3), "id", P.init_normal)
+    return S
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        S = make_store().finalize("cpu", seed=100 + rank)  # different weights per rank before the broadcast
+        S.buffers["b.running_mean"].fill_(float(rank + 1))
+        sync = GradSync(S)
+        sync.broadcast_parameters(0)
+        S.grad.copy_(torch.arange(S.total, dtype=torch.float32) * (rank + 1))
+        for b in (3, 2, 1, 0):  # the backward pass completes buckets from the last to the first
+            sync.bucket_ready(b)
+        sync.wait()
+        out[rank] = dict(flat=S.flat.clone(), grad=S.grad.clone(), buf=S.buffers["b.running_mean"].clone(),
+                         scale=sync.grad_scale, ranges=sync.ranges)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucket_ranges_tile_the_buffer():
+    S = make_store().finalize("cpu", seed=0)
+    r = S.bucket_ranges()
+    assert len(r) == 4 and r[0][0] == 0 and r[-1][1] == S.total
+    for (s0, e0), (s1, e1) in zip(r, r[1:]):
+        assert e0 == s1 and s0 < e0
+    assert all(s % S.ALIGN == 0 for s, _ in r)
+
+
+def test_state_dict_layout_round_trip_cpu():
+    S = make_store().finalize("cpu", seed=1)
+    sd = S.state_dict()
+    assert sd["b.conv.weight"].shape == (6, 4, 3) and S.p("b.conv.weight").shape == (3, 6, 4)
+    assert sd["c.dw.weight"].shape == (8, 1, 9) and S.p("c.dw.weight").shape == (9, 8)
+    assert torch.equal(S.p("b.conv.weight")[2, 5, 1], sd["b.conv.weight"][5, 1, 2])
+    S2 = make_store().finalize("cpu", seed=2)
+    S2.load_state_dict(sd)
+    assert torch.equal(S2.flat, S.flat)
+    with pytest.raises(RuntimeError):
+        S2.load_state_dict({k: v for k, v in sd.items() if k != "a.bias"})
+
+
+def test_gradsync_world2_gloo():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    r0, r1 = out[0], out[1]
+    total = r0["grad"].numel()
+    expect = torch.arange(total, dtype=torch.float32) * 3  # (1 + 2) x arange: each element summed exactly once
+    assert torch.equal(r0["grad"], expect) and torch.equal(r1["grad"], expect)
+    assert torch.equal(r0["flat"], r1["flat"])  # rank 0's weights everywhere
+    assert float(r1["buf"][0]) == 1.0  # BatchNorm buffers too
+    assert r0["scale"] == 0.5
