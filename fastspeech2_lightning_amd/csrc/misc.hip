@@ -397,6 +397,13 @@ extern "C" int fs2hip_length_regulate_fwd(const float* x, const int* dur, const 
   return 0;
 }
 
+extern "C" int fs2hip_duration_cumsum(const int* dur, int* cum, int* out_lens, int B, int Ts, int Tm, void* stream) {
+  if (B <= 0 || Ts <= 0) return FS2HIP_EINVAL;
+  lr_cumsum_kernel<<<dim3((B + 63) / 64), dim3(64), 0, S_>>>(dur, cum, out_lens, B, Ts, Tm);
+  FS2_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int fs2hip_length_regulate_bwd(const float* dy, const int* cum, float* dx, int B, int Ts, int Tm, int D,
                                           void* stream) {
   if (B <= 0 || Ts <= 0 || Tm <= 0 || D <= 0 || (D % 4)) return FS2HIP_EINVAL;

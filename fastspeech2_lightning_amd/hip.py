@@ -71,6 +71,7 @@ SIGNATURES = {
     "fs2hip_bucket_embed_add": "pfpippppiip",
     "fs2hip_length_regulate_fwd": "pppppppiiiip",
     "fs2hip_length_regulate_bwd": "pppiiiip",
+    "fs2hip_duration_cumsum": "pppiiip",
     "fs2hip_rowdot_fwd": "pppppiiip",
     "fs2hip_rowdot_blocks": "i",
     "fs2hip_rowdot_bwd": "ppppppppiiip",
@@ -83,6 +84,14 @@ SIGNATURES = {
     "fs2hip_dact_mul": "pppqip",
     "fs2hip_mask_from_lens": "ppiip",
     "fs2hip_sum_slots": "pipp",
+    "fs2hip_attn_dist": "pppiiiip",
+    "fs2hip_attn_softmax": "pppppiiip",
+    "fs2hip_mas": "pippppppiiip",
+    "fs2hip_avg_variance": "pppiiip",
+    "fs2hip_attn_ctc_loss": "pppppppfpiiip",
+    "fs2hip_attn_bin_loss": "pppfppiiip",
+    "fs2hip_attn_softmax_bwd": "ppppppiiip",
+    "fs2hip_attn_dist_bwd": "pppppiiiip",
 }
 EXPORTS = list(SIGNATURES)
 
@@ -691,3 +700,116 @@ def sum_slots(x, n, out):
     _chk(x, name="x"); _chk(out, name="out")
     _req(x.numel() >= n and out.numel() == 1, "sum_slots: size mismatch")
     _ok(lib().fs2hip_sum_slots(_p(x), n, _p(out), _stream()), "sum_slots")
+
+
+# ------------------------------------------------------------------------------------------
+# learned alignment (aligner.hip)
+# ------------------------------------------------------------------------------------------
+def attn_dist(q, k):
+    """logits[b,t1,t2] = -0.0005 * sum_c (q[b,t1,c] - k[b,t2,c])^2."""
+    _chk(q, name="q"); _chk(k, name="k")
+    B, T1, Cc = q.shape
+    _req(k.dim() == 3 and k.shape[0] == B and k.shape[2] == Cc, "attn_dist: shape mismatch")
+    T2 = k.shape[1]
+    logits = torch.empty(B, T1, T2, device=q.device, dtype=torch.float32)
+    _ok(lib().fs2hip_attn_dist(_p(q), _p(k), _p(logits), B, T1, T2, Cc, _stream()), "attn_dist")
+    return logits
+
+
+def attn_softmax(logits, prior, key_lens):
+    _chk(logits, name="logits"); _chk(prior, name="prior"); _chk(key_lens, torch.int32, "key_lens")
+    B, T1, T2 = logits.shape
+    _req(prior.shape == logits.shape and key_lens.numel() == B, "attn_softmax: shape mismatch")
+    logprob, soft = torch.empty_like(logits), torch.empty_like(logits)
+    _ok(lib().fs2hip_attn_softmax(_p(logits), _p(prior), _p(key_lens), _p(logprob), _p(soft), B, T1, T2, _stream()),
+        "attn_softmax")
+    return logprob, soft
+
+
+def mas(x, in_lens, out_lens, is_log=False):
+    """Monotonic alignment search.  x [B, Tm, Ts] = attn_soft (or log-probabilities when ``is_log``).
+    Returns (hard [B,Tm,Ts] fp32 0/1, hard_idx [B,Tm] int32, dur [B,Ts] int32)."""
+    _chk(x, name="x"); _chk(in_lens, torch.int32, "in_lens"); _chk(out_lens, torch.int32, "out_lens")
+    B, Tm, Ts = x.shape
+    _req(in_lens.numel() == B and out_lens.numel() == B, "mas: lens size")
+    hard = torch.empty_like(x)
+    hard_idx = torch.empty(B, Tm, device=x.device, dtype=torch.int32)
+    dur = torch.empty(B, Ts, device=x.device, dtype=torch.int32)
+    W = (Ts + 31) // 32
+    dirs = torch.empty(B * Tm * W, device=x.device, dtype=torch.int32)
+    _ok(lib().fs2hip_mas(_p(x), int(is_log), _p(in_lens), _p(out_lens), _p(hard), _p(hard_idx), _p(dur), _p(dirs), B, Tm,
+                         Ts, _stream()), "mas")
+    return hard, hard_idx, dur
+
+
+def duration_cumsum(dur, Tm):
+    """(cum [B, Ts] inclusive cumulative durations, lens [B] = min(total, Tm))."""
+    _chk(dur, torch.int32, "dur")
+    B, Ts = dur.shape
+    cum = torch.empty(B, Ts, device=dur.device, dtype=torch.int32)
+    lens = torch.empty(B, device=dur.device, dtype=torch.int32)
+    _ok(lib().fs2hip_duration_cumsum(_p(dur), _p(cum), _p(lens), B, Ts, int(Tm), _stream()), "duration_cumsum")
+    return cum, lens
+
+
+def avg_variance(var, cum):
+    _chk(var, name="var"); _chk(cum, torch.int32, "cum")
+    B, Tm = var.shape
+    Ts = cum.shape[1]
+    _req(cum.shape[0] == B, "avg_variance: shape mismatch")
+    out = torch.empty(B, Ts, device=var.device, dtype=torch.float32)
+    _ok(lib().fs2hip_avg_variance(_p(var), _p(cum), _p(out), B, Tm, Ts, _stream()), "avg_variance")
+    return out
+
+
+def attn_ctc_loss(logprob, key_lens, query_lens, weight, loss_out, want_grad=True):
+    _chk(logprob, name="logprob"); _chk(key_lens, torch.int32, "key_lens"); _chk(query_lens, torch.int32, "query_lens")
+    _chk(loss_out, name="loss_out")
+    B, Tm, Ts = logprob.shape
+    _req(key_lens.numel() == B and query_lens.numel() == B and loss_out.numel() == 1, "attn_ctc_loss: shape mismatch")
+    _req(2 * (2 * Ts + 1) * 4 + 16 <= 64 * 1024, "attn_ctc_loss: too many tokens for the on-chip state")
+    alpha = torch.empty(B * Tm * (2 * Ts + 1) + B * Tm + B, device=logprob.device, dtype=torch.float32)
+    lse = alpha[B * Tm * (2 * Ts + 1):]
+    nll = lse[B * Tm:]
+    d = torch.empty_like(logprob) if want_grad else None
+    _ok(lib().fs2hip_attn_ctc_loss(_p(logprob), _p(key_lens), _p(query_lens), _p(alpha), lse.data_ptr(), nll.data_ptr(),
+                                   _p(d), weight, _p(loss_out), B, Tm, Ts, _stream()), "attn_ctc_loss")
+    return d
+
+
+def attn_bin_loss(soft, hard_idx, weight, loss_out):
+    """Writes loss_out[0]; returns the 1-element coefficient tensor the softmax backward consumes."""
+    _chk(soft, name="soft"); _chk(hard_idx, torch.int32, "hard_idx"); _chk(loss_out, name="loss_out")
+    B, Tm, Ts = soft.shape
+    _req(hard_idx.shape == (B, Tm) and loss_out.numel() == 1, "attn_bin_loss: shape mismatch")
+    ws = _workspace(1024, soft.device)
+    coef = torch.empty(1, device=soft.device, dtype=torch.float32)
+    _ok(lib().fs2hip_attn_bin_loss(_p(soft), _p(hard_idx), _p(ws), weight, _p(loss_out), _p(coef), B, Tm, Ts, _stream()),
+        "attn_bin_loss")
+    return coef
+
+
+def attn_softmax_bwd(logits, soft, dlogprob, hard_idx, bin_coef):
+    _chk(logits, name="logits"); _chk(soft, name="soft")
+    B, T1, T2 = logits.shape
+    if dlogprob is not None:
+        _chk(dlogprob, name="dlogprob")
+        _req(dlogprob.shape == logits.shape, "attn_softmax_bwd: dlogprob shape")
+    if hard_idx is not None:
+        _chk(hard_idx, torch.int32, "hard_idx"); _chk(bin_coef, name="bin_coef")
+        _req(hard_idx.shape == (B, T1), "attn_softmax_bwd: hard_idx shape")
+    d = torch.empty_like(logits)
+    _ok(lib().fs2hip_attn_softmax_bwd(_p(logits), _p(soft), _p(dlogprob), _p(hard_idx), _p(bin_coef), _p(d), B, T1, T2,
+                                      _stream()), "attn_softmax_bwd")
+    return d
+
+
+def attn_dist_bwd(dlogits, q, k, want_dq=True, want_dk=True):
+    _chk(dlogits, name="dlogits"); _chk(q, name="q"); _chk(k, name="k")
+    B, T1, Cc = q.shape
+    T2 = k.shape[1]
+    _req(dlogits.shape == (B, T1, T2) and k.shape == (B, T2, Cc), "attn_dist_bwd: shape mismatch")
+    dq = torch.empty_like(q) if want_dq else None
+    dk = torch.empty_like(k) if want_dk else None
+    _ok(lib().fs2hip_attn_dist_bwd(_p(dlogits), _p(q), _p(k), _p(dq), _p(dk), B, T1, T2, Cc, _stream()), "attn_dist_bwd")
+    return dq, dk

@@ -49,6 +49,9 @@ class VarianceAdaptor:
         self.pitch_predictor = M.VariancePredictor(S, env, pre + "pitch_predictor.", d, vp.pitch)
         S.add(pre + "pitch_embedding.weight", (vp.pitch.n_bins, vp.pitch.input_dim), "id", P.init_normal)
         self.duration_predictor = M.VariancePredictor(S, env, pre + "duration_predictor.", d, vp.duration)
+        self.aligner = None
+        if config.model.learn_alignment:
+            self.aligner = M.Aligner(S, env, pre + "attention.", config.preprocessing.audio.n_mels, d)
         S.add_buffer(pre + "pitch_bins", torch.linspace(stats.pitch.norm_min, stats.pitch.norm_max, vp.pitch.n_bins - 1))
         S.add_buffer(pre + "energy_bins", torch.linspace(stats.energy.norm_min, stats.energy.norm_max, vp.energy.n_bins - 1))
         self.pre = pre
@@ -65,19 +68,41 @@ class VarianceAdaptor:
             out, idx = H.bucket_embed_add(target, S.b(pre + f"{name}_bins"), S.p(pre + f"{name}_embedding.weight"), x)
         return pred, out, (pctx, idx)
 
-    def fwd(self, x, batch, src_lens, table, Tm, control, inference, teacher_forcing):
+    def fwd(self, x, batch, src_lens, table, Tm, control, inference, teacher_forcing, text_emb=None):
         cfg = self.config.model.variance_predictors
         B, Ts, D = x.shape
         c = {}
         energy_t = None if inference else batch["energy"]
         pitch_t = None if inference else batch["pitch"]
         energy_p = pitch_p = None
+        attn = dict(attn_logprob=None, attn_soft=None, attn_hard=None)
+        dur_aligned = None
+        if self.aligner is not None and (teacher_forcing or not inference):
+            # fs2/variance_adaptor.py:249-305: soft alignment, MAS, durations, phone-level targets
+            mel, mel_lens = batch["mel"], batch["mel_lens"]
+            Tm_ = mel.shape[1]
+            logprob, soft, hard, hard_idx, dur_aligned, c["align"] = self.aligner.fwd(
+                mel, text_emb, batch["duration"], src_lens, mel_lens)
+            attn = dict(attn_logprob=logprob.view(B, 1, Tm_, Ts), attn_soft=soft.view(B, 1, Tm_, Ts),
+                        attn_hard=hard.view(B, 1, Tm_, Ts))
+            c["hard_idx"] = hard_idx
+            for name, tgt in (("energy", energy_t), ("pitch", pitch_t)):
+                if tgt is not None and tgt.shape[1] == Ts and Ts != Tm_:
+                    raise ValueError("pitch/energy targets are already phone-averaged: learned alignment needs "
+                                     "frame-level targets (fs2/variance_adaptor.py:269-279)")
+            cum_a, _ = H.duration_cumsum(dur_aligned, Tm_)
+            if energy_t is not None and cfg.energy.level.value == "phone":
+                energy_t = H.avg_variance(energy_t, cum_a)
+            if pitch_t is not None and cfg.pitch.level.value == "phone":
+                pitch_t = H.avg_variance(pitch_t, cum_a)
         if cfg.energy.level.value == "phone":
             energy_p, x, c["energy"] = self._variance("energy", x, energy_t, src_lens, control.energy, inference)
         if cfg.pitch.level.value == "phone":
             pitch_p, x, c["pitch"] = self._variance("pitch", x, pitch_t, src_lens, control.pitch, inference)
         logd, c["duration"] = self.duration_predictor.fwd(x, src_lens)
-        if teacher_forcing or not inference:
+        if dur_aligned is not None:
+            dur = dur_aligned
+        elif teacher_forcing or not inference:
             dur = batch["duration"]
         else:
             # fs2/variance_adaptor.py:360-366: clamp(round(exp(logd) - 1) * control, min=0).int()
@@ -95,7 +120,7 @@ class VarianceAdaptor:
             x = H.add_posenc(x, table(Tm), tgt_lens, B, Tm)
         return dict(output=x, duration_prediction=logd, duration_target=dur if (teacher_forcing or not inference) else None,
                     duration_rounded=dur, pitch_prediction=pitch_p, pitch_target=pitch_t, energy_prediction=energy_p,
-                    energy_target=energy_t, tgt_lens=tgt_lens, Tm=Tm), c
+                    energy_target=energy_t, tgt_lens=tgt_lens, Tm=Tm, **attn), c
 
     def bwd(self, d_dec_in, dpred, c):
         """d_dec_in: gradient of the decoder input; dpred: {'pitch','energy','duration'} loss gradients."""
@@ -118,7 +143,10 @@ class VarianceAdaptor:
             d = variance_bwd("pitch", d)
         if cfg.energy.level.value == "phone":
             d = variance_bwd("energy", d)
-        return d
+        d_text = None
+        if "align" in c:
+            d_text = self.aligner.bwd(dpred.get("attn_ctc"), dpred.get("attn_bin"), c["align"])
+        return d, d_text
 
 
 class FastSpeech2Loss:
@@ -158,6 +186,18 @@ class FastSpeech2Loss:
         term("spec", output["output"], mel, tgt_lens, Tm, n_mels, cfg.mel_loss.value, t.mel_loss_weight)
         if cfg.use_postnet:
             term("postnet", output["postnet_output"], mel, tgt_lens, Tm, n_mels, cfg.mel_loss.value, t.postnet_loss_weight)
+        if cfg.learn_alignment and output.get("attn_logprob") is not None:
+            # fs2/loss.py:109-122
+            lp, soft = output["attn_logprob"], output["attn_soft"]
+            Bm, _, Tmm, Tss = lp.shape
+            i = LOSS_KEYS.index("attn_ctc")
+            grads["attn_ctc"] = H.attn_ctc_loss(lp.view(Bm, Tmm, Tss), batch["src_lens"], batch["mel_lens"],
+                                                t.attn_ctc_loss_weight, slots[i:i + 1], want_grad=want)
+            losses["attn_ctc"] = slots[i]
+            w = min(current_epoch / t.attn_bin_loss_warmup_epochs, 1.0) * t.attn_bin_loss_weight
+            i = LOSS_KEYS.index("attn_bin")
+            grads["attn_bin"] = H.attn_bin_loss(soft.view(Bm, Tmm, Tss), m._hard_idx, float(w), slots[i:i + 1])
+            losses["attn_bin"] = slots[i]
         H.sum_slots(slots, len(LOSS_KEYS), slots[len(LOSS_KEYS):])
         losses["total"] = slots[len(LOSS_KEYS)]
         m._loss_grads = grads if want else None
@@ -190,8 +230,6 @@ class FastSpeech2(_Base):
         self.lang2id, self.speaker2id = lang2id or {}, speaker2id or {}
         self.current_epoch_ = 0
         m = config.model
-        if m.learn_alignment:
-            raise NotImplementedError("learn_alignment=True (aligner path, SURVEY A14-A17) is not built yet")
         if m.use_global_style_token_module:
             raise NotImplementedError("GST style encoder (SURVEY A18) is not built yet")
         if m.target_text_representation_level == TargetTrainingTextRepresentationLevel.phonological_features:
@@ -235,7 +273,7 @@ class FastSpeech2(_Base):
         self._reorder_state_dict_keys()
         self.loss = FastSpeech2Loss(self)
         self._tables = {}
-        self._ctx = self._loss_grads = self._loss_slots = None
+        self._ctx = self._loss_grads = self._loss_slots = self._hard_idx = None
         self.grad_sync = None  # set by parallel.GradSync for data-parallel training
         self.training = False
         self.env.training = False
@@ -306,7 +344,9 @@ class FastSpeech2(_Base):
             if b.get(k) is not None:
                 b[k] = self._dev(b[k], torch.float32)
         if b.get("duration") is not None and torch.is_tensor(b["duration"]):
-            b["duration"] = self._dev(b["duration"], torch.int32)
+            # learned alignment: "duration" carries the (B, Tm, Ts) attention prior (fs2/dataset.py:274-281)
+            prior = self.config.model.learn_alignment and b["duration"].dim() == 3
+            b["duration"] = self._dev(b["duration"], torch.float32 if prior else torch.int32)
         return b
 
     # ---- forward (fs2/model.py:153-268) -------------------------------------------------------------
@@ -331,7 +371,8 @@ class FastSpeech2(_Base):
             x = H.add_rowvec(x, H.embedding_fwd(batch["language_id"], S.p("language_embedding.weight")), B, Ts)
         Tm = batch["max_mel_len"]
         va, va_ctx = self.variance_adaptor.fwd(x, batch, src_lens, self._table, int(Tm), control, inference,
-                                               teacher_forcing)
+                                               teacher_forcing, text_emb=inputs)
+        self._hard_idx = va_ctx.get("hard_idx")
         Tm, tgt_lens = va["Tm"], va["tgt_lens"]
         if (teacher_forcing or not inference) and batch.get("mel") is not None and batch["mel"].shape[1] != Tm:
             raise ValueError("max_mel_len must equal the padded mel length")
@@ -348,7 +389,7 @@ class FastSpeech2(_Base):
             "output": output, "postnet_output": postnet_output,
             "src_mask": H.mask_from_lens(src_lens, Ts), "src_lens": src_lens,
             "tgt_mask": H.mask_from_lens(tgt_lens, Tm), "tgt_lens": tgt_lens,
-            "attn_logprob": None, "attn_soft": None, "attn_hard": None,
+            "attn_logprob": va["attn_logprob"], "attn_soft": va["attn_soft"], "attn_hard": va["attn_hard"],
             "duration_prediction": va["duration_prediction"], "duration_target": va["duration_target"],
             "energy_prediction": va["energy_prediction"], "energy_target": va["energy_target"],
             "pitch_prediction": va["pitch_prediction"], "pitch_target": va["pitch_target"],
@@ -377,7 +418,7 @@ class FastSpeech2(_Base):
         d = self.decoder.bwd(d, c["dec"])
         if sync:
             sync.bucket_ready(2)
-        d = self.variance_adaptor.bwd(d, g, c["va"])
+        d, d_text = self.variance_adaptor.bwd(d, g, c["va"])
         if m.multispeaker:
             self._rowvec_embedding_bwd("speaker_embedding.weight", c["batch"]["speaker_id"], d)
         if m.multilingual:
@@ -385,6 +426,8 @@ class FastSpeech2(_Base):
         if sync:
             sync.bucket_ready(1)
         d = self.encoder.bwd(d, c["enc"])
+        if d_text is not None:  # the aligner's keys are the raw text embedding (fs2/variance_adaptor.py:254)
+            d = H.axpby(d, d_text)
         H.embedding_bwd(c["text"].reshape(-1), d, S.g("text_input_layer.weight"), self.padding_idx)
         if sync:
             sync.bucket_ready(0)

@@ -338,6 +338,78 @@ class VariancePredictor:
 
 
 # ------------------------------------------------------------------------------------------------
+# ConvAttention aligner  fs2/attn/attention.py:101-251 (built at fs2/variance_adaptor.py:151-158)
+# ------------------------------------------------------------------------------------------------
+class Aligner:
+    """key_proj: Conv1d(n_text, 2 n_text, 3) -> ReLU -> Conv1d(2 n_text, n_att, 1);
+    query_proj: Conv1d(n_mel, 2 n_mel, 3) -> ReLU -> Conv1d(2 n_mel, n_mel, 1) -> ReLU -> Conv1d(n_mel, n_att, 1);
+    attn = -0.0005 * ||q - k||^2 -> log_softmax + log prior -> masked softmax -> MAS."""
+
+    def __init__(self, S, env: Env, prefix, n_mel, n_text, n_att=80):
+        self.S, self.env = S, env
+        k, q = prefix + "key_proj.", prefix + "query_proj."
+        self.names = dict(k0=(k + "0.conv.weight", k + "0.conv.bias"), k2=(k + "2.conv.weight", k + "2.conv.bias"),
+                          q0=(q + "0.conv.weight", q + "0.conv.bias"), q2=(q + "2.conv.weight", q + "2.conv.bias"),
+                          q4=(q + "4.conv.weight", q + "4.conv.bias"))
+
+        def conv(key, cout, cin, ksz, gain):
+            w, b = self.names[key]
+            S.add(w, (cout, cin, ksz), "convk" if ksz > 1 else "pw", P.init_xavier(gain))
+            S.add(b, (cout,), "id", P.init_bias_for(cin * ksz))
+
+        conv("k0", 2 * n_text, n_text, 3, "relu")
+        conv("k2", n_att, 2 * n_text, 1, "linear")
+        conv("q0", 2 * n_mel, n_mel, 3, "relu")
+        conv("q2", n_mel, 2 * n_mel, 1, "linear")
+        conv("q4", n_att, n_mel, 1, "linear")
+
+    def _w(self, key):
+        w, b = self.names[key]
+        return self.S.p(w), self.S.p(b)
+
+    def fwd(self, mel, text_emb, prior, src_lens, mel_lens):
+        B, Tm, _ = mel.shape
+        Ts = text_emb.shape[1]
+        k1 = H.linear_fwd(text_emb, *self._w("k0"), epi=H.EPI_ACT, act="relu", taps=3, T=Ts)
+        kenc = H.linear_fwd(k1, *self._w("k2"))
+        q1 = H.linear_fwd(mel, *self._w("q0"), epi=H.EPI_ACT, act="relu", taps=3, T=Tm)
+        q2 = H.linear_fwd(q1, *self._w("q2"), epi=H.EPI_ACT, act="relu")
+        qenc = H.linear_fwd(q2, *self._w("q4"))
+        logits = H.attn_dist(qenc, kenc)
+        logprob, soft = H.attn_softmax(logits, prior, src_lens)
+        hard, hard_idx, dur = H.mas(soft, src_lens, mel_lens)
+        ctx = Ctx(mel=mel, text_emb=text_emb, k1=k1, kenc=kenc, q1=q1, q2=q2, qenc=qenc, logits=logits, soft=soft,
+                  hard_idx=hard_idx)
+        return logprob, soft, hard, hard_idx, dur, ctx
+
+    def bwd(self, dlogprob, bin_coef, c):
+        """dlogprob: CTC gradient (or None); bin_coef: binarisation-loss coefficient (or None).
+        Returns the gradient of text_emb."""
+        S = self.S
+        B, Tm, _ = c.mel.shape
+        Ts = c.text_emb.shape[1]
+        dlogits = H.attn_softmax_bwd(c.logits, c.soft, dlogprob, c.hard_idx if bin_coef is not None else None, bin_coef)
+        dq, dk = H.attn_dist_bwd(dlogits, c.qenc, c.kenc)
+        g = lambda key: (S.g(self.names[key][0]), S.g(self.names[key][1]))  # noqa: E731
+        # query branch (the mel input needs no gradient)
+        gw, gb = g("q4")
+        H.linear_bwd_weight(dq, c.q2, gw); H.colsum(dq, gb)
+        d = H.linear_bwd_data(dq, self._w("q4")[0], epi=H.EPI_DACT, act="relu", aux=c.q2)
+        gw, gb = g("q2")
+        H.linear_bwd_weight(d, c.q1, gw); H.colsum(d, gb)
+        d = H.linear_bwd_data(d, self._w("q2")[0], epi=H.EPI_DACT, act="relu", aux=c.q1)
+        gw, gb = g("q0")
+        H.linear_bwd_weight(d, c.mel, gw, taps=3, T=Tm); H.colsum(d, gb)
+        # key branch
+        gw, gb = g("k2")
+        H.linear_bwd_weight(dk, c.k1, gw); H.colsum(dk, gb)
+        d = H.linear_bwd_data(dk, self._w("k2")[0], epi=H.EPI_DACT, act="relu", aux=c.k1)
+        gw, gb = g("k0")
+        H.linear_bwd_weight(d, c.text_emb, gw, taps=3, T=Ts); H.colsum(d, gb)
+        return H.linear_bwd_data(d, self._w("k0")[0], taps=3, T=Ts)
+
+
+# ------------------------------------------------------------------------------------------------
 # PostNet  fs2/layers.py:143-212
 # ------------------------------------------------------------------------------------------------
 class PostNet:

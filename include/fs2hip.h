@@ -198,6 +198,8 @@ int fs2hip_length_regulate_fwd(const float* x, const int* dur, const float* pose
                                void* stream);
 int fs2hip_length_regulate_bwd(const float* dy, const int* cum, float* dx, int B, int Ts, int Tm, int D,
                                void* stream);
+/* cum [B][Ts] inclusive cumulative durations, out_lens [B] = min(total, Tm) (the first half of the forward) */
+int fs2hip_duration_cumsum(const int* dur, int* cum, int* out_lens, int B, int Ts, int Tm, void* stream);
 
 /* predictor head (fs2/variance_adaptor.py:53-62): out[m] = (x[m,:].w + b) * (t < lens[b]) */
 int fs2hip_rowdot_fwd(const float* x, const float* w, const float* bias, const int* lens, float* out, int M,
@@ -234,6 +236,38 @@ int fs2hip_add_rowvec(const float* x, const float* e, float* out, int B, int T, 
 int fs2hip_dact_mul(const float* dy, const float* aux, float* out, long long n, int act, void* stream);
 int fs2hip_mask_from_lens(const int* lens, unsigned char* mask, int B, int T, void* stream);
 int fs2hip_sum_slots(const float* x, int n, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Learned alignment (fs2/attn/attention.py:195-251, fs2/attn/alignment.py:48-74,
+ * fs2/attn/attention_loss.py:22-73, fs2/variance_adaptor.py:160-222, :267-268).
+ * All attention maps are dense [B][T1 = frames][T2 = tokens] fp32.
+ *   attn_dist       logits = -0.0005 * sum_c (q - k)^2      q [B][T1][C], k [B][T2][C]
+ *   attn_softmax    logprob = log_softmax(logits) + log(prior + 1e-8); soft = softmax over keys < key_lens[b]
+ *   mas             hard 0/1 map, hard_idx [B][T1] (token of each frame, -1 on padding), dur [B][T2] int32;
+ *                   `in` = attn_soft (is_log 0) or log-probabilities (is_log 1); DP in fp32 adds/max only:
+ *                   bit-exact against mas_width1 on the same input.  dirs_ws: B*T1*ceil(T2/32) uint32.
+ *   avg_variance    phone-level mean of a frame-level track over each token's frames (non-zero count)
+ *   attn_ctc_loss   AttentionCTCLoss value (loss_out[0], weight applied) and d/d logprob (may be NULL)
+ *                   alpha_ws B*T1*(2*T2+1), lse_ws B*T1, nll_ws B floats
+ *   attn_bin_loss   AttentionBinarizationLoss value and the coefficient the backward needs
+ *   attn_softmax_bwd  d logits from d logprob (CTC) and the binarisation term (hard_idx, bin_coef)
+ *   attn_dist_bwd   dq, dk from d logits (either may be NULL)
+ * ------------------------------------------------------------------------------------ */
+int fs2hip_attn_dist(const float* q, const float* k, float* logits, int B, int T1, int T2, int C, void* stream);
+int fs2hip_attn_softmax(const float* logits, const float* prior, const int* key_lens, float* logprob,
+                        float* soft, int B, int T1, int T2, void* stream);
+int fs2hip_mas(const float* in, int is_log, const int* in_lens, const int* out_lens, float* hard,
+               int* hard_idx, int* dur, unsigned* dirs_ws, int B, int Tm, int Ts, void* stream);
+int fs2hip_avg_variance(const float* var, const int* cum, float* out, int B, int Tm, int Ts, void* stream);
+int fs2hip_attn_ctc_loss(const float* logprob, const int* key_lens, const int* query_lens, float* alpha_ws,
+                         float* lse_ws, float* nll_ws, float* dlogprob, float weight, float* loss_out, int B,
+                         int Tm, int Ts, void* stream);
+int fs2hip_attn_bin_loss(const float* soft, const int* hard_idx, float* partial, float weight, float* loss_out,
+                         float* bin_coef, int B, int Tm, int Ts, void* stream);
+int fs2hip_attn_softmax_bwd(const float* logits, const float* soft, const float* dlogprob, const int* hard_idx,
+                            const float* bin_coef, float* dlogits, int B, int T1, int T2, void* stream);
+int fs2hip_attn_dist_bwd(const float* dlogits, const float* q, const float* k, float* dq, float* dk, int B,
+                         int T1, int T2, int C, void* stream);
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,7 @@ from oracle import fs2_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-GPU_CASES = [n for n, (ckw, _, _) in C.CASES.items() if not ckw.get("learn_alignment")]
+GPU_CASES = list(C.CASES)
 
 
 def build_model(name):
