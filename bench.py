@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--learn-alignment", action="store_true",
+                    help="reference default config: jointly learned alignment (aligner + MAS + CTC/bin losses)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -130,11 +132,12 @@ def main():
     from fastspeech2_lightning_amd.parallel import GradSync
     from fastspeech2_lightning_amd.synthetic import DEFAULT_STATS, synthetic_batch
 
-    config = make_config()
+    config = make_config(args.learn_alignment)
     model = FastSpeech2(config, Stats(**DEFAULT_STATS), device=f"cuda:{local}", seed=1234)
     model.train()
     opt = model.configure_optimizers()[0][0]
-    batch = synthetic_batch(B=args.batch, ts_lo=96, ts_hi=128, n_symbols=64, n_mels=80, seed=1234 + rank, dur_hi=9)
+    batch = synthetic_batch(B=args.batch, ts_lo=96, ts_hi=128, n_symbols=64, n_mels=80, seed=1234 + rank, dur_hi=9,
+                            learn_alignment=args.learn_alignment)
     sync = None
     if world > 1:
         sync = GradSync(model.store)
@@ -225,7 +228,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: fp32 train step, batch=32/GPU, LJSpeech-shaped synthetic "
-                                   "(96-128 phonemes, 80 x ~600 mel), learn_alignment=False, dropout on",
+                                   "(96-128 phonemes, 80 x ~600 mel), learn_alignment=" + str(args.learn_alignment) + ", dropout on",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "real_frames_per_step": frames_all, "padded_frames_per_step": padded_all,
                        "parallelism": f"dp{world}", "hipgraph": bool(graph is not None),
