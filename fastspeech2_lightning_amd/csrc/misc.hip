@@ -337,6 +337,15 @@ __global__ void sum_slots_kernel(const float* __restrict__ x, int n, float* __re
   out[0] = s;
 }
 
+// fs2/variance_adaptor.py:360-366: clamp(round(exp(logd) - 1) * control, min=0).int(); torch.round is
+// round-half-to-even = rintf; .int() truncates
+__global__ void duration_round_kernel(const float* __restrict__ logd, float control, int* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = rintf(expf(logd[i]) - 1.f) * control;
+  out[i] = (int)fmaxf(v, 0.f);
+}
+
 inline unsigned grid_for(long long n, int per_block = 256, long long cap = 4096) {
   long long b = (n + per_block - 1) / per_block;
   if (b > cap) b = cap;
@@ -500,6 +509,13 @@ extern "C" int fs2hip_mask_from_lens(const int* lens, unsigned char* mask, int B
 extern "C" int fs2hip_sum_slots(const float* x, int n, float* out, void* stream) {
   if (n <= 0) return FS2HIP_EINVAL;
   sum_slots_kernel<<<dim3(1), dim3(1), 0, S_>>>(x, n, out);
+  FS2_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fs2hip_duration_round(const float* logd, float control, int* out, int n, void* stream) {
+  if (n <= 0) return FS2HIP_EINVAL;
+  duration_round_kernel<<<dim3((n + 255) / 256), dim3(256), 0, S_>>>(logd, control, out, n);
   FS2_LAUNCH_CHECK();
   return 0;
 }

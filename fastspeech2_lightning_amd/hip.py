@@ -83,6 +83,7 @@ SIGNATURES = {
     "fs2hip_add_rowvec": "pppiiip",
     "fs2hip_dact_mul": "pppqip",
     "fs2hip_mask_from_lens": "ppiip",
+    "fs2hip_duration_round": "pfpip",
     "fs2hip_sum_slots": "pipp",
     "fs2hip_attn_dist": "pppiiiip",
     "fs2hip_attn_softmax": "pppppiiip",
@@ -813,3 +814,11 @@ def attn_dist_bwd(dlogits, q, k, want_dq=True, want_dk=True):
     dk = torch.empty_like(k) if want_dk else None
     _ok(lib().fs2hip_attn_dist_bwd(_p(dlogits), _p(q), _p(k), _p(dq), _p(dk), B, T1, T2, Cc, _stream()), "attn_dist_bwd")
     return dq, dk
+
+
+def duration_round(logd, control=1.0):
+    """Inference durations: int(max(round_half_even(exp(logd) - 1) * control, 0))."""
+    _chk(logd, name="logd")
+    out = torch.empty(logd.shape, device=logd.device, dtype=torch.int32)
+    _ok(lib().fs2hip_duration_round(_p(logd), float(control), _p(out), logd.numel(), _stream()), "duration_round")
+    return out

@@ -106,8 +106,9 @@ class VarianceAdaptor:
             dur = batch["duration"]
         else:
             # fs2/variance_adaptor.py:360-366: clamp(round(exp(logd) - 1) * control, min=0).int()
-            dur = torch.clamp(torch.round(torch.exp(logd) - 1) * control.duration, min=0).int()
-            Tm = int(min(int(dur.sum(1).max()), int(Tm)))  # host sync: inference only
+            dur = H.duration_round(logd, control.duration)
+            _, totals = H.duration_cumsum(dur, 1 << 30)
+            Tm = int(min(int(totals.max()), int(Tm)))  # host sync (output size): inference only
             Tm = max(Tm, 1)
         frame_level = cfg.energy.level.value == "frame" or cfg.pitch.level.value == "frame"
         x, cum, tgt_lens = H.length_regulate_fwd(x, dur, Tm, None if frame_level else table(Tm))

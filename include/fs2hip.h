@@ -234,6 +234,8 @@ int fs2hip_add_rowvec(const float* x, const float* e, float* out, int B, int T, 
 /* out = dy * act'(aux) (aux = activation output for ReLU, input otherwise); bool mask t < lens[b]
  * (fs2/utils/heavy.py:11-15); out[0] = sum of n loss slots (fs2/loss.py:125) */
 int fs2hip_dact_mul(const float* dy, const float* aux, float* out, long long n, int act, void* stream);
+/* inference durations (fs2/variance_adaptor.py:360-366): out = int(max(rint(exp(logd) - 1) * control, 0)) */
+int fs2hip_duration_round(const float* logd, float control, int* out, int n, void* stream);
 int fs2hip_mask_from_lens(const int* lens, unsigned char* mask, int B, int T, void* stream);
 int fs2hip_sum_slots(const float* x, int n, float* out, void* stream);
 

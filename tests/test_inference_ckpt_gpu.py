@@ -1,0 +1,75 @@
+"""GPU: the inference branch (fs2/model.py:226-230, fs2/variance_adaptor.py:359-369: predicted durations
+rounded half-to-even, mel lengths derived from them, control factors) and the checkpoint hooks
+(fs2/model.py:270-378) against the oracle / the reference's checkpoint layout."""
+import numpy as np
+import pytest
+import torch
+
+from fastspeech2_lightning_amd.config import InferenceControl, Stats
+from oracle import cases as C
+from oracle import fs2_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def build_pair(name="e2e_noalign_eval"):
+    from fastspeech2_lightning_amd.model import FastSpeech2
+    config, batch, _ = C.build(name)
+    model = FastSpeech2(config, Stats(**C.STATS))
+    oracle = O.FastSpeech2Oracle(config, Stats(**C.STATS), n_symbols=C.N_SYMBOLS)
+    sd = O.seeded_state_dict(oracle.state_dict())
+    # make the duration predictor produce a useful spread of durations
+    sd["variance_adaptor.duration_predictor.linear.bias"] = torch.tensor([1.2])
+    oracle.load_state_dict(sd)
+    model.load_state_dict(sd)
+    model.eval(); oracle.eval()
+    return model, oracle, batch, config
+
+
+@pytest.mark.parametrize("control", [InferenceControl(), InferenceControl(duration=1.3, pitch=0.9, energy=1.1)])
+def test_free_inference_matches_oracle(control):
+    model, oracle, batch, _ = build_pair()
+    infer = {k: v for k, v in batch.items() if k not in ("mel", "pitch", "energy", "duration")}
+    infer.update(mel=None, mel_lens=None, max_mel_len=1_000_000, duration=None)
+    with torch.no_grad():
+        ref = oracle(dict(infer), control, inference=True)
+    out = model.predict_step(dict(infer)) if control == InferenceControl() else model(dict(infer), control, inference=True)
+    assert torch.equal(out["tgt_lens"].cpu(), ref["tgt_lens"].cpu().int())
+    assert torch.equal(out["tgt_mask"].cpu(), ref["tgt_mask"])
+    assert int(out["tgt_lens"].max()) > 4
+    for k in ("output", "postnet_output", "duration_prediction", "pitch_prediction", "energy_prediction"):
+        a, b = out[k].cpu().numpy(), ref[k].numpy()
+        assert a.shape == b.shape, k
+        assert np.abs(a - b).max() < 1e-4 * max(1.0, np.abs(b).max()), k
+
+
+def test_teacher_forced_inference_matches_oracle():
+    model, oracle, batch, _ = build_pair()
+    with torch.no_grad():
+        ref = oracle(dict(batch), inference=True)
+    out = model(dict(batch), inference=True)
+    assert torch.equal(out["tgt_lens"].cpu(), batch["mel_lens"])
+    a, b = out["postnet_output"].cpu().numpy(), ref["postnet_output"].numpy()
+    assert np.abs(a - b).max() < 1e-4 * max(1.0, np.abs(b).max())
+
+
+def test_checkpoint_round_trip(tmp_path):
+    from fastspeech2_lightning_amd.model import FastSpeech2
+    model, oracle, batch, config = build_pair()
+    path = tmp_path / "m.ckpt"
+    model.save_checkpoint(path, global_step=7)
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    assert ckpt["model_info"] == {"name": "FastSpeech2", "version": "1.2"}
+    assert ckpt["global_step"] == 7 and "stats" in ckpt["hyper_parameters"]
+    # the stored state dict is in the reference's layout: it loads into the (reference-keyed) oracle
+    oracle.load_state_dict(ckpt["state_dict"])
+    m2 = FastSpeech2.load_from_checkpoint(path)
+    m2.eval()
+    o1, o2 = model(dict(batch)), m2(dict(batch))
+    assert torch.equal(o1["postnet_output"], o2["postnet_output"])
+    # version gates (fs2/model.py:270-299)
+    bad = dict(ckpt, model_info={"name": "FastSpeech2", "version": "99.0"})
+    with pytest.raises(ValueError):
+        model.on_load_checkpoint(bad)
+    with pytest.raises(TypeError):
+        model.on_load_checkpoint(dict(ckpt, model_info={"name": "HiFiGAN", "version": "1.0"}))

@@ -238,3 +238,12 @@ def test_axpby_and_rowvec(H):
     B, T, D = 2, 5, 8
     xx, e = rnd(B, T, D, seed=3), rnd(B, D, seed=4)
     close(H.add_rowvec(xx.cuda(), e.cuda(), B, T), xx + e[:, None], msg="rowvec")
+
+
+def test_duration_round_half_to_even(H, golden_dir):
+    g = dict(np.load(golden_dir / "units.npz"))
+    out = H.duration_round(torch.tensor(g["round/logd"]).cuda())
+    np.testing.assert_array_equal(out.cpu().numpy(), g["round/out"])
+    logd = torch.log(torch.tensor([0.5, 1.5, 2.5, 3.5, 0.2]) + 1)
+    ref = torch.clamp(torch.round(torch.exp(logd) - 1) * 1.7, min=0).int()
+    assert torch.equal(H.duration_round(logd.cuda(), 1.7).cpu(), ref)
