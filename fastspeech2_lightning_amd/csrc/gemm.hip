@@ -10,20 +10,12 @@
 // k-contiguous sources on the way), issued one K-tile ahead of the MFMAs.
 #include <cstdlib>
 
-#include "common.h"
+#include "gemm_common.h"
 
 namespace {
 
 constexpr int BK = 16;
 constexpr int LDS_PAD = 4;
-
-struct GemmP {
-  Fs2GemmArgs a;
-  int Rper;        // reduction length per tap (shift_operand == 0) or R
-  int tiles_n;     // number of tiles along Nc
-  int r_chunk;     // split-K chunk (multiple of BK)
-  Fs2Drop drop;
-};
 
 template <int BM, int BN>
 struct Tile {
@@ -186,51 +178,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     cur ^= 1;
   }
 
-  // ---- epilogue -----------------------------------------------------------------------------
-  float* C = a.C;
-  if (a.splitk > 1) {
-    C = a.workspace + ((long long)split * a.taps + tapz) * ((long long)a.Mc * a.Nc);
-  } else if (a.shift_operand == 1) {
-    C += (long long)tapz * a.c_tap_stride;
-  }
-  const int ldc = a.splitk > 1 ? a.Nc : a.ldc;
-  const bool plain = a.splitk > 1;
-  const Fs2Drop drop = fs2_resolve_drop(p.drop);
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
-      if (n >= a.Nc) continue;
-      const float bias = (!plain && a.bias) ? a.bias[n] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m >= a.Mc) continue;
-        float v = acc[i][j][r];
-        const long long o = (long long)m * ldc + n;
-        if (plain) {
-          C[o] = v;
-          continue;
-        }
-        v = a.alpha * v + bias;
-        switch (a.epi) {
-          case FS2_EPI_ACT:
-            if (a.out_pre) a.out_pre[(long long)m * a.ldpre + n] = v;
-            v = fs2_act(a.act, v) * fs2_drop_factor(drop, (unsigned long long)o);
-            break;
-          case FS2_EPI_RESID:
-            v = a.resid[(long long)m * a.ldr + n] + a.res_scale * (v * fs2_drop_factor(drop, (unsigned long long)o));
-            break;
-          case FS2_EPI_DACT:
-            v = v * fs2_dact(a.act, a.aux[(long long)m * a.ldaux + n]) * fs2_drop_factor(drop, (unsigned long long)o);
-            break;
-          default: break;
-        }
-        C[o] = v;
-      }
-    }
-  }
+  gemm_epilogue<BM, BN>(p, acc, m0, n0, wm, wn, lane, split, tapz);
 }
 
 }  // namespace
@@ -258,7 +206,6 @@ extern "C" int fs2hip_gemm(const Fs2GemmArgs* args, void* stream) {
     if (a.shift_operand == 0) {
       if (!a.a_kcontig || a.R % a.taps) return FS2HIP_EINVAL;
       p.Rper = a.R / a.taps;
-      if (p.Rper % BK) return FS2HIP_EINVAL;  // a K tile never straddles two taps
       if (a.Mc % a.T) return FS2HIP_EINVAL;
     } else {
       if (a.a_kcontig || a.b_kcontig || a.R % a.T) return FS2HIP_EINVAL;
@@ -272,19 +219,28 @@ extern "C" int fs2hip_gemm(const Fs2GemmArgs* args, void* stream) {
   p.r_chunk = ((chunk + BK - 1) / BK) * BK;
   const int nz = (a.shift_operand == 1 ? a.taps : 1) * a.splitk;
   hipStream_t s = (hipStream_t)stream;
-  // tile choice: wide N -> 128x128; narrow N (<= 96 columns left in the last tile would waste
-  // matrix-core cycles) -> 128x64
-  bool narrow = a.Nc <= 64 || (a.Nc % 128 != 0 && a.Nc % 128 <= 64) ||
-                ((long long)((a.Mc + 127) / 128) * ((a.Nc + 127) / 128) * nz < 384);
   static const int env_tile = getenv("FS2_GEMM_TILE") ? atoi(getenv("FS2_GEMM_TILE")) : 0;  // tuning aid
-  const int forced = a.tile ? a.tile : env_tile;
-  if (forced == 1) narrow = false;
-  if (forced == 2) narrow = true;
-  if (forced == 3) {
+  int tile = a.tile ? a.tile : env_tile;
+  // core v2 (direct-to-LDS, BK = 32) handles NT / NN / TN; core v1 (register-staged, BK = 16) additionally
+  // needs conv taps aligned to its K-tile
+  const bool v2_ok = a.a_kcontig || !a.b_kcontig;
+  const bool v1_ok = !(a.taps > 1 && a.shift_operand == 0 && (p.Rper % BK));
+  if (tile == 0) {
+    // heuristic (the host autotuner normally picks): v2, 128x128 unless few tiles / a narrow or ragged N
+    const bool narrow = a.Nc <= 64 || (a.Nc % 128 != 0 && a.Nc % 128 <= 64) ||
+                        ((long long)((a.Mc + 127) / 128) * ((a.Nc + 127) / 128) * nz < 384);
+    tile = v2_ok ? (narrow ? 5 : 4) : (narrow ? 2 : 1);
+  }
+  if (tile >= 4) {
+    if (!v2_ok) return FS2HIP_EINVAL;
+    return fs2_gemm2_launch(p, tile, nz, s);
+  }
+  if (!v1_ok) return FS2HIP_EINVAL;
+  if (tile == 3) {
     p.tiles_n = (a.Nc + 63) / 64;
     dim3 grid(((a.Mc + 63) / 64) * p.tiles_n, 1, nz);
     gemm_kernel<64, 64><<<grid, dim3(256), 0, s>>>(p);
-  } else if (narrow) {
+  } else if (tile == 2) {
     p.tiles_n = (a.Nc + 63) / 64;
     dim3 grid(((a.Mc + 127) / 128) * p.tiles_n, 1, nz);
     gemm_kernel<128, 64><<<grid, dim3(256), 0, s>>>(p);

@@ -89,7 +89,8 @@ typedef struct {
   const unsigned long long* drop_step; /* device step counter mixed into the seed, or NULL */
   int splitk;
   float* workspace;
-  int tile; /* 0 = heuristic, 1 = 128x128, 2 = 128x64, 3 = 64x64 workgroup tile (chosen by the host autotuner) */
+  int tile; /* 0 = heuristic; workgroup tile chosen by the host autotuner: 1/2/3 = 128x128, 128x64, 64x64 on the
+               register-staged BK=16 core, 4/5/6 = the same tiles on the direct-to-LDS BK=32 core */
 } Fs2GemmArgs;
 
 int fs2hip_gemm(const Fs2GemmArgs* args, void* stream);

@@ -13,9 +13,13 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def H():
+    import os
     from fastspeech2_lightning_amd import hip
     assert torch.cuda.is_available()
     hip.lib()
+    if os.environ.get("FS2_TEST_GEMM_TILES"):  # e.g. "4" or "5,6": restrict the autotuner to these tiles
+        hip.GEMM_TILES = tuple(int(t) for t in os.environ["FS2_TEST_GEMM_TILES"].split(","))
+        hip._TILE_CACHE.clear()
     return hip
 
 
