@@ -199,12 +199,23 @@ def main():
     roofline = None
     if not args.no_roofline and rank == 0:
         # live measurement of the dominant kernel: HIP events around every GEMM launch of two eager steps
-        H.GEMM_PROFILE = []
-        step()
+        # (a GPU-side spin first, so that the host runs ahead and the events bracket device time only,
+        # as in the replayed graph, not the host's launch latency)
         H.GEMM_PROFILE = []
         step()
         torch.cuda.synchronize()
+        H.GEMM_PROFILE = []
+        torch.cuda._sleep(int(0.06 * 2.0e9))
+        step()
+        torch.cuda.synchronize()
         prof, H.GEMM_PROFILE = H.GEMM_PROFILE, None
+        if os.environ.get("FS2_BENCH_GEMM_BREAKDOWN"):
+            by = {}
+            for e0, e1, fl, mc, nc, r in prof:
+                t, f, n = by.get((mc, nc, r), (0.0, 0.0, 0))
+                by[(mc, nc, r)] = (t + e0.elapsed_time(e1), f + fl, n + 1)
+            for (mc, nc, r), (t, f, n) in sorted(by.items(), key=lambda kv: -kv[1][0])[:24]:
+                log(f"gemm Mc={mc:6d} Nc={nc:5d} R={r:6d} x{n:3d}: {t:7.3f} ms  {f / t / 1e9:6.1f} TFLOP/s")
         ms = sum(e0.elapsed_time(e1) for e0, e1, *_ in prof)
         flops = sum(p[2] for p in prof)
         achieved = flops / (ms * 1e-3) / 1e12

@@ -9,9 +9,10 @@
 //        a valid fp32 reduction order as long as A and B agree);
 //      - reduction-major operands ([k][rows]) land as [32][rows] and are read with conflict-free ds_read_b32;
 //    rows/taps outside the matrix read a 16-byte zero page instead (conv 'same' padding, M/N/K edges);
-//  * two LDS stages, ONE barrier per K-tile: the barrier (which drains the LDS-DMA) publishes tile kt and
-//    retires every wave's reads of the other stage, the DMA of tile kt+1 is issued right after it and
-//    flies under the 32 x TM x TN MFMAs of tile kt;
+//  * an LDS ring of NST stages with NST-1 K-tiles of DMA in flight: per K-tile ONE raw s_barrier behind a
+//    COUNTED `s_waitcnt vmcnt(N)` (N = loads of the newer tiles, never 0 in steady state) -- the wait
+//    retires this wave's oldest tile, the barrier publishes everybody's and also retires all reads of the
+//    stage that the next DMA (issued right after it) overwrites;
 //  * XCD-aware workgroup order (tiles sharing an M-tile's A rows run on one XCD's L2).
 #include "gemm_common.h"
 
@@ -81,11 +82,66 @@ __device__ __forceinline__ void issue_tile(float* __restrict__ tile, const GemmP
   }
 }
 
-template <int BM, int BN, bool AKC, bool BKC>
+// Loop-invariant part of the per-piece source addresses (no conv taps): computed once per workgroup so
+// that a K-tile's DMA issue is one 64-bit add + one compare per piece instead of multiplies, swizzle and
+// bounds logic competing with the wave's own MFMA issue.
+template <int ROWS>
+struct Pieces {
+  const float* base[ROWS / 32];  // address of the piece in K-tile 0
+  int koff[ROWS / 32];           // reduction offset of the piece inside a K-tile (k-contiguous: swizzled chunk)
+  bool ok[ROWS / 32];            // row / column inside the matrix
+};
+
+template <int ROWS, bool KC, bool IS_A>
+__device__ __forceinline__ void setup_pieces(Pieces<ROWS>& pc_, const GemmP& p, int row0, int r_begin, int tid) {
+  const Fs2GemmArgs& a = p.a;
+  const float* src = IS_A ? a.A : a.B;
+  const int ld = IS_A ? a.lda : a.ldb;
+  const int nrows = IS_A ? a.Mc : a.Nc;
+#pragma unroll
+  for (int it = 0; it < ROWS / 32; ++it) {
+    const int pidx = it * 256 + tid;
+    if (KC) {
+      const int row = pidx >> 3, pc = pidx & 7, gr = row0 + row;
+      pc_.koff[it] = (pc ^ (row & 7)) << 2;
+      pc_.ok[it] = gr < nrows;
+      pc_.base[it] = src + (long long)gr * ld + r_begin + pc_.koff[it];
+    } else {
+      const int k = pidx / (ROWS / 4), col = row0 + (pidx % (ROWS / 4)) * 4;
+      pc_.koff[it] = k;
+      pc_.ok[it] = col < nrows;
+      pc_.base[it] = src + (long long)(r_begin + k) * ld + col;
+    }
+  }
+}
+
+// kstep = floats between consecutive K-tiles of a piece (32 for k-contiguous, 32*ld otherwise);
+// rem = reduction elements left from the start of this K-tile
+template <int ROWS>
+__device__ __forceinline__ void issue_fast(float* __restrict__ tile, const Pieces<ROWS>& pc_, long long koffset, int rem,
+                                           int wave) {
+#pragma unroll
+  for (int it = 0; it < ROWS / 32; ++it) {
+    const bool ok = pc_.ok[it] && pc_.koff[it] < rem;
+    glds16(ok ? pc_.base[it] + koffset : fs2_zero_page, tile + (it * 256 + wave * 64) * 4);
+  }
+}
+
+// wait until at most N of this wave's vector-memory operations (here: LDS-DMA pieces) are outstanding, then
+// the workgroup barrier.  One asm statement with a memory clobber: the compiler tracks neither the DMA's
+// LDS writes nor the counter, so no LDS access may move across it.
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, bool AKC, bool BKC, int NST>
 __global__ __launch_bounds__(256) void gemm2_kernel(GemmP p) {
   constexpr int TM = BM / 64, TN = BN / 64;
-  constexpr int A_TILE = BM * BK2, B_TILE = BN * BK2;
-  __shared__ __attribute__((aligned(16))) float lds[2 * (A_TILE + B_TILE)];
+  constexpr int A_TILE = BM * BK2, B_TILE = BN * BK2, STAGE = A_TILE + B_TILE;
+  constexpr int L = BM / 32 + BN / 32;  // LDS-DMA instructions per thread per K-tile
+  static_assert(NST >= 2 && NST <= 4 && (NST - 2) * L < 64, "ring depth");
+  __shared__ __attribute__((aligned(16))) float lds[NST * STAGE];
   const Fs2GemmArgs& a = p.a;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -112,21 +168,38 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  auto issue = [&](int kt, int buf) {
-    float* At = lds + buf * (A_TILE + B_TILE);
+  const bool tapmode = a.taps > 1;  // conv taps: per-tile address decode; otherwise hoisted pointers
+  Pieces<BM> pa;
+  Pieces<BN> pb;
+  if (!tapmode) {
+    setup_pieces<BM, AKC, true>(pa, p, m0, r_begin, tid);
+    setup_pieces<BN, BKC, false>(pb, p, n0, r_begin, tid);
+  }
+  const long long stepA = AKC ? BK2 : (long long)BK2 * a.lda, stepB = BKC ? BK2 : (long long)BK2 * a.ldb;
+  auto issue = [&](int kt, int stage) {
+    float* At = lds + stage * STAGE;
     float* Bt = At + A_TILE;
     const int r0 = r_begin + kt * BK2;
-    issue_tile<BM, AKC, true>(At, p, m0, r0, r_end, shift_z, tid, wave);
-    issue_tile<BN, BKC, false>(Bt, p, n0, r0, r_end, shift_z, tid, wave);
+    if (tapmode) {
+      issue_tile<BM, AKC, true>(At, p, m0, r0, r_end, shift_z, tid, wave);
+      issue_tile<BN, BKC, false>(Bt, p, n0, r0, r_end, shift_z, tid, wave);
+    } else {
+      issue_fast<BM>(At, pa, kt * stepA, r_end - r0, wave);
+      issue_fast<BN>(Bt, pb, kt * stepB, r_end - r0, wave);
+    }
   };
 
   const int l31 = lane & 31, h = lane >> 5;
-  if (nkt > 0) issue(0, 0);
-  int cur = 0;
+  for (int kt = 0; kt < NST - 1 && kt < nkt; ++kt) issue(kt, kt);
+  int stage = 0;
   for (int kt = 0; kt < nkt; ++kt) {
-    __syncthreads();  // drains this wave's LDS-DMA (vmcnt(0)) and publishes tile kt; retires reads of the other stage
-    if (kt + 1 < nkt) issue(kt + 1, cur ^ 1);
-    const float* At = lds + cur * (A_TILE + B_TILE);
+    // tile kt is this wave's oldest outstanding DMA; min(NST-2, tiles left) newer ones may stay in flight
+    const int newer = min(NST - 2, nkt - 1 - kt);
+    if (NST >= 4 && newer == 2) wait_vmcnt_barrier<2 * L>();
+    else if (NST >= 3 && newer == 1) wait_vmcnt_barrier<L>();
+    else wait_vmcnt_barrier<0>();
+    if (kt + NST - 1 < nkt) issue(kt + NST - 1, stage == 0 ? NST - 1 : stage - 1);  // the stage read in iteration kt-1
+    const float* At = lds + stage * STAGE;
     const float* Bt = At + A_TILE;
 #pragma unroll
     for (int g = 0; g < BK2 / 8; ++g) {
@@ -161,20 +234,20 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmP p) {
           for (int jn = 0; jn < TN; ++jn)
             acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][j], bv[jn][j], acc[i][jn], 0, 0, 0);
     }
-    cur ^= 1;
+    stage = stage + 1 == NST ? 0 : stage + 1;
   }
   gemm_epilogue<BM, BN>(p, acc, m0, n0, wm, wn, lane, split, tapz);
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int NST>
 int launch_tile(GemmP& p, int nz, hipStream_t s) {
   const Fs2GemmArgs& a = p.a;
   p.tiles_m = (a.Mc + BM - 1) / BM;
   p.tiles_n = (a.Nc + BN - 1) / BN;
   dim3 grid(p.tiles_m * p.tiles_n, 1, nz), block(256);
-  if (a.a_kcontig && a.b_kcontig) gemm2_kernel<BM, BN, true, true><<<grid, block, 0, s>>>(p);
-  else if (a.a_kcontig && !a.b_kcontig) gemm2_kernel<BM, BN, true, false><<<grid, block, 0, s>>>(p);
-  else if (!a.a_kcontig && !a.b_kcontig) gemm2_kernel<BM, BN, false, false><<<grid, block, 0, s>>>(p);
+  if (a.a_kcontig && a.b_kcontig) gemm2_kernel<BM, BN, true, true, NST><<<grid, block, 0, s>>>(p);
+  else if (a.a_kcontig && !a.b_kcontig) gemm2_kernel<BM, BN, true, false, NST><<<grid, block, 0, s>>>(p);
+  else if (!a.a_kcontig && !a.b_kcontig) gemm2_kernel<BM, BN, false, false, NST><<<grid, block, 0, s>>>(p);
   else return FS2HIP_EINVAL;
   FS2_LAUNCH_CHECK();
   return 0;
@@ -189,9 +262,10 @@ int fs2_gemm2_launch(GemmP& p, int tile, int nz, hipStream_t s) {
   const int chunk = (a.R + a.splitk - 1) / a.splitk;
   p.r_chunk = ((chunk + BK2 - 1) / BK2) * BK2;
   switch (tile) {
-    case 4: return launch_tile<128, 128>(p, nz, s);
-    case 5: return launch_tile<128, 64>(p, nz, s);
-    case 6: return launch_tile<64, 64>(p, nz, s);
+    case 4: return launch_tile<128, 128, 3>(p, nz, s);  // 96 KiB ring, 1 workgroup / CU
+    case 5: return launch_tile<128, 64, 3>(p, nz, s);   // 72 KiB ring, 2 workgroups / CU
+    case 6: return launch_tile<64, 64, 4>(p, nz, s);    // 64 KiB ring, 2 workgroups / CU
+    case 7: return launch_tile<64, 64, 2>(p, nz, s);    // 32 KiB, 5 workgroups / CU (occupancy instead of depth)
     default: return FS2HIP_EINVAL;
   }
 }
