@@ -211,7 +211,7 @@ def main():
         prof, H.GEMM_PROFILE = H.GEMM_PROFILE, None
         if os.environ.get("FS2_BENCH_GEMM_BREAKDOWN"):
             by = {}
-            for e0, e1, fl, mc, nc, r in prof:
+            for e0, e1, fl, mc, nc, r, _nb in prof:
                 t, f, n = by.get((mc, nc, r), (0.0, 0.0, 0))
                 by[(mc, nc, r)] = (t + e0.elapsed_time(e1), f + fl, n + 1)
             for (mc, nc, r), (t, f, n) in sorted(by.items(), key=lambda kv: -kv[1][0])[:24]:
@@ -219,9 +219,15 @@ def main():
         ms = sum(e0.elapsed_time(e1) for e0, e1, *_ in prof)
         flops = sum(p[2] for p in prof)
         achieved = flops / (ms * 1e-3) / 1e12
+        traffic, traffic_src = None, None
+        tfile = REPO / "profiles" / "r01_gemm_traffic.json"
+        if tfile.exists():  # HBM-side bytes per launch from the two rocprofv3 --pmc passes (tools/pmc_traffic.py)
+            traffic = round(json.loads(tfile.read_text())["hbm_bytes_per_launch"])
+            traffic_src = "profiles/r01_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled)"
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                    "kernel": "gemm_kernel<128,128|64> (fp32 v_mfma_f32_32x32x2_f32)", "launches_per_step": len(prof),
+                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": round(sum(q[6] for q in prof) / len(prof)),
+                    "kernel": "gemm_kernel / gemm2_kernel family (fp32 v_mfma_f32_32x32x2_f32), tile autotuned per shape", "launches_per_step": len(prof),
                     "avg_launch_us": round(ms * 1e3 / len(prof), 2), "flops_per_launch": round(flops / len(prof)),
                     "gemm_ms_per_step": round(ms, 3)}
 

@@ -99,7 +99,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int tile_m = blockIdx.x / p.tiles_n, tile_n = blockIdx.x % p.tiles_n;
+  const int wg = fs2_xcd_remap(blockIdx.x, gridDim.x);  // tiles sharing an M-tile's A rows on one XCD's L2
+  const int tile_m = wg / p.tiles_n, tile_n = wg % p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // reduction range of this workgroup

@@ -243,7 +243,11 @@ def _gemm(_algorithmic=True, **kw):
     _ok(lib().fs2hip_gemm(C.byref(a), _stream()), "gemm")
     e1.record()
     ntap = a.taps if a.shift_operand == 1 else 1
-    GEMM_PROFILE.append((e0, e1, 2.0 * a.Mc * a.Nc * a.R * ntap, a.Mc, a.Nc, a.R * ntap))
+    # algorithmic bytes: every operand element read once, every output element written once
+    ra = a.R // a.taps if (a.taps > 1 and a.shift_operand == 0) else a.R
+    nbytes = 4.0 * (a.Mc * ra + a.Nc * a.R + a.Mc * a.Nc * ntap
+                    + (a.Mc * a.Nc if a.resid else 0) + (a.Mc * a.Nc if a.aux else 0) + (a.Mc * a.Nc if a.out_pre else 0))
+    GEMM_PROFILE.append((e0, e1, 2.0 * a.Mc * a.Nc * a.R * ntap, a.Mc, a.Nc, a.R * ntap, nbytes))
 
 
 def linear_fwd(x, w, bias=None, *, epi=EPI_STORE, act=None, resid=None, res_scale=1.0, out_pre=None,

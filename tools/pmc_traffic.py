@@ -1,0 +1,43 @@
+"""Per-launch HBM traffic of the GEMM kernels from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
+
+Usage (on the GPU box, separate passes as MI355X_MICROARCH.md prescribes):
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d OUT/fetch -- python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-graph --no-roofline
+  rocprofv3 --pmc WRITE_SIZE ... -d OUT/write -- (same)
+  python tools/pmc_traffic.py OUT/fetch OUT/write N_GEMM_PER_STEP
+
+Only the LAST step's GEMM dispatches are used (earlier ones include the tile autotuner's timing launches).
+gfx950 corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 64 B per 128-B request for wide coalesced
+reads -> doubled; WRITE_SIZE is exact; both are in KiB.
+"""
+import csv
+import glob
+import json
+import sys
+
+
+def last_step(dirname, counter, n):
+    f = glob.glob(f"{dirname}/*/*_counter_collection.csv")[0]
+    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and "gemm" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    rows = rows[-n:]
+    return sum(float(r["Counter_Value"]) for r in rows), len(rows)
+
+
+def main():
+    fetch_dir, write_dir, n = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    fetch_kib, nf = last_step(fetch_dir, "FETCH_SIZE", n)
+    write_kib, nw = last_step(write_dir, "WRITE_SIZE", n)
+    out = {
+        "launches": nf,
+        "fetch_bytes_per_launch_raw": fetch_kib * 1024 / nf,
+        "fetch_bytes_per_launch_corrected": 2 * fetch_kib * 1024 / nf,
+        "write_bytes_per_launch": write_kib * 1024 / nw,
+        "hbm_bytes_per_launch": (2 * fetch_kib + write_kib) * 1024 / nf,
+        "note": "last benchmark step only; FETCH_SIZE doubled (gfx950 counts 64 B per 128-B request); L2-side "
+                "counters, Infinity-Cache hits included",
+    }
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
