@@ -120,11 +120,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # FS2_BENCH_BACKEND=gloo rehearses the N > 1 control flow on a box with fewer GPUs than ranks (ranks then
+    # share devices; RCCL itself refuses duplicate devices).  The driver's runs use RCCL ("nccl").
+    backend = os.environ.get("FS2_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(backend)
 
     from fastspeech2_lightning_amd import hip as H
     from fastspeech2_lightning_amd.config import Stats
@@ -197,18 +205,20 @@ def main():
     log(f"timed region: {elapsed / args.steps * 1e3:.2f} ms/step")
 
     roofline = None
-    if not args.no_roofline and rank == 0:
-        # live measurement of the dominant kernel: HIP events around every GEMM launch of two eager steps
-        # (a GPU-side spin first, so that the host runs ahead and the events bracket device time only,
-        # as in the replayed graph, not the host's launch latency)
-        H.GEMM_PROFILE = []
+    if not args.no_roofline:
+        # live measurement of the dominant kernel: HIP events around every GEMM launch of an eager step.
+        # Every rank runs the steps (they contain the collectives); rank 0 records.  A GPU-side spin first,
+        # so that the host runs ahead and the events bracket device time only, as in the replayed graph.
+        rec = rank == 0
+        H.GEMM_PROFILE = [] if rec else None
         step()
         torch.cuda.synchronize()
-        H.GEMM_PROFILE = []
+        H.GEMM_PROFILE = [] if rec else None
         torch.cuda._sleep(int(0.06 * 2.0e9))
         step()
         torch.cuda.synchronize()
         prof, H.GEMM_PROFILE = H.GEMM_PROFILE, None
+    if roofline is None and not args.no_roofline and rank == 0:
         if os.environ.get("FS2_BENCH_GEMM_BREAKDOWN"):
             by = {}
             for e0, e1, fl, mc, nc, r, _nb in prof:
@@ -216,8 +226,8 @@ def main():
                 by[(mc, nc, r)] = (t + e0.elapsed_time(e1), f + fl, n + 1)
             for (mc, nc, r), (t, f, n) in sorted(by.items(), key=lambda kv: -kv[1][0])[:24]:
                 log(f"gemm Mc={mc:6d} Nc={nc:5d} R={r:6d} x{n:3d}: {t:7.3f} ms  {f / t / 1e9:6.1f} TFLOP/s")
-        ms = sum(e0.elapsed_time(e1) for e0, e1, *_ in prof)
-        flops = sum(p[2] for p in prof)
+        ms = sum(q[0].elapsed_time(q[1]) for q in prof)
+        flops = sum(q[2] for q in prof)
         achieved = flops / (ms * 1e-3) / 1e12
         traffic, traffic_src = None, None
         tfile = REPO / "profiles" / "r01_gemm_traffic.json"
@@ -227,7 +237,8 @@ def main():
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": round(sum(q[6] for q in prof) / len(prof)),
-                    "kernel": "gemm_kernel / gemm2_kernel family (fp32 v_mfma_f32_32x32x2_f32), tile autotuned per shape", "launches_per_step": len(prof),
+                    "kernel": "gemm_kernel / gemm2_kernel family (fp32 v_mfma_f32_32x32x2_f32), tile autotuned per shape",
+                    "launches_per_step": len(prof),
                     "avg_launch_us": round(ms * 1e3 / len(prof), 2), "flops_per_launch": round(flops / len(prof)),
                     "gemm_ms_per_step": round(ms, 3)}
 
