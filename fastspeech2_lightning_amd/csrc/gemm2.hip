@@ -266,6 +266,8 @@ int fs2_gemm2_launch(GemmP& p, int tile, int nz, hipStream_t s) {
     case 5: return launch_tile<128, 64, 3>(p, nz, s);   // 72 KiB ring, 2 workgroups / CU
     case 6: return launch_tile<64, 64, 4>(p, nz, s);    // 64 KiB ring, 2 workgroups / CU
     case 7: return launch_tile<64, 64, 2>(p, nz, s);    // 32 KiB, 5 workgroups / CU (occupancy instead of depth)
+    case 8: return launch_tile<128, 64, 2>(p, nz, s);   // 48 KiB, 3 workgroups / CU
+    case 9: return launch_tile<128, 128, 2>(p, nz, s);  // 64 KiB, 2 workgroups / CU
     default: return FS2HIP_EINVAL;
   }
 }

@@ -71,5 +71,6 @@ __device__ __forceinline__ int fs2_xcd_remap(int orig, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
 }
 
-// v2 core launcher (gemm2.hip); tile: 4 = 128x128 (3-stage ring), 5 = 128x64 (3), 6 = 64x64 (4), 7 = 64x64 (2)
+// v2 core launcher (gemm2.hip); tile: 4 = 128x128 (3-stage ring), 5 = 128x64 (3), 6 = 64x64 (4),
+// 7 = 64x64 (2), 8 = 128x64 (2), 9 = 128x128 (2)
 int fs2_gemm2_launch(GemmP& p, int tile, int nz, hipStream_t s);

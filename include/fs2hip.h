@@ -90,7 +90,8 @@ typedef struct {
   int splitk;
   float* workspace;
   int tile; /* 0 = heuristic; workgroup tile chosen by the host autotuner: 1/2/3 = 128x128, 128x64, 64x64 on the
-               register-staged BK=16 core, 4/5/6 = the same tiles on the direct-to-LDS BK=32 core */
+               register-staged BK=16 core, 4..9 = direct-to-LDS BK=32 core (128x128, 128x64, 64x64 with a 3/3/4-stage LDS
+               ring; 7/8/9 = 64x64, 128x64, 128x128 with 2 stages and more workgroups per CU) */
 } Fs2GemmArgs;
 
 int fs2hip_gemm(const Fs2GemmArgs* args, void* stream);
