@@ -283,6 +283,64 @@ def attention_bin_loss(hard, soft, eps=1e-12):
 
 
 # --------------------------------------------------------------------------- #
+# GST style encoder: fs2/gst/model.py:14-280, fs2/gst/attn.py:48-194
+# --------------------------------------------------------------------------- #
+class _GstMHA(nn.Module):
+    def __init__(self, q_dim, k_dim, v_dim, n_head, n_feat):
+        super().__init__()
+        self.d_k, self.h = n_feat // n_head, n_head
+        self.linear_q, self.linear_k = nn.Linear(q_dim, n_feat), nn.Linear(k_dim, n_feat)
+        self.linear_v, self.linear_out = nn.Linear(v_dim, n_feat), nn.Linear(n_feat, n_feat)
+
+    def forward(self, query, key, value):
+        B = query.size(0)
+        q = self.linear_q(query).view(B, -1, self.h, self.d_k).transpose(1, 2)
+        k = self.linear_k(key).view(B, -1, self.h, self.d_k).transpose(1, 2)
+        v = self.linear_v(value).view(B, -1, self.h, self.d_k).transpose(1, 2)
+        p = torch.softmax(q @ k.transpose(-2, -1) / math.sqrt(self.d_k), dim=-1)
+        x = (p @ v).transpose(1, 2).contiguous().view(B, -1, self.h * self.d_k)
+        return self.linear_out(x)
+
+
+class _ReferenceEncoder(nn.Module):
+    def __init__(self, idim=80, chans=(32, 32, 64, 64, 128, 128), gru_units=128):
+        super().__init__()
+        convs, cin, f = [], 1, idim
+        for c in chans:
+            convs += [nn.Conv2d(cin, c, 3, stride=2, padding=1, bias=False), nn.BatchNorm2d(c), nn.ReLU(inplace=True)]
+            cin, f = c, (f - 3 + 2) // 2 + 1
+        self.convs = nn.Sequential(*convs)
+        self.gru = nn.GRU(f * chans[-1], gru_units, 1, batch_first=True)
+
+    def forward(self, speech):  # (B, Lmax, idim)
+        hs = self.convs(speech.unsqueeze(1)).transpose(1, 2)  # (B, L', C, F')
+        hs = hs.contiguous().view(speech.size(0), hs.size(1), -1)
+        _, h = self.gru(hs)
+        return h[-1]
+
+
+class _StyleTokenLayer(nn.Module):
+    def __init__(self, ref_dim=128, tokens=10, token_dim=256, heads=4):
+        super().__init__()
+        self.gst_embs = nn.Parameter(torch.randn(tokens, token_dim // heads))
+        self.mha = _GstMHA(ref_dim, token_dim // heads, token_dim // heads, heads, token_dim)
+
+    def forward(self, ref):
+        g = torch.tanh(self.gst_embs).unsqueeze(0).expand(ref.size(0), -1, -1)
+        return self.mha(ref.unsqueeze(1), g, g).squeeze(1)
+
+
+class StyleEncoder(nn.Module):
+    def __init__(self, idim=80):
+        super().__init__()
+        self.ref_enc = _ReferenceEncoder(idim)
+        self.stl = _StyleTokenLayer()
+
+    def forward(self, speech):
+        return self.stl(self.ref_enc(speech))
+
+
+# --------------------------------------------------------------------------- #
 # fs2/layers.py:143-212
 # --------------------------------------------------------------------------- #
 class PostNet(nn.Module):
@@ -445,7 +503,7 @@ class FastSpeech2Oracle(nn.Module):
             self.text_input_layer = nn.Embedding(n_symbols, d, padding_idx=padding_idx)
         self.position_embedding = PositionalEmbedding(d)
         if m.use_global_style_token_module:
-            raise NotImplementedError("GST branch (SURVEY A18) is restated in a later round")
+            self.gst = StyleEncoder(idim=config.preprocessing.audio.n_mels)
 
         def conformer(c):
             return Conformer(c.input_dim, c.heads, c.feedforward_dim, c.layers, c.conv_kernel_size, c.dropout)
@@ -474,6 +532,8 @@ class FastSpeech2Oracle(nn.Module):
         inputs = self.text_input_layer(text)
         pos = self.position_embedding(torch.arange(max_src_len).to(inputs.dtype)) * src_mask.unsqueeze(2)
         x, _ = self.encoder(inputs + pos, src_lens)
+        if m.use_global_style_token_module:  # fs2/model.py:196-203 (training / teacher forcing: the target mel)
+            x = x + self.gst(batch["mel"]).unsqueeze(1)
         if self.speaker_embedding is not None:
             x = x + self.speaker_embedding(batch["speaker_id"]).unsqueeze(1)
         if self.language_embedding is not None:

@@ -129,7 +129,8 @@ def dump_case(name: str, config, batch, train_mode: bool, out_dir: Path):
     from fs2.model import FastSpeech2 as RefFastSpeech2
 
     torch.manual_seed(0)
-    ref = RefFastSpeech2(config, stats=STATS)
+    kw = dict(lang2id=C.LANG2ID, speaker2id=C.SPEAKER2ID) if config.model.multispeaker else {}
+    ref = RefFastSpeech2(config, stats=STATS, **kw)
     # parameter values come from a name-keyed seeded generator (regenerated by the
     # tests), so the fixture carries no weights
     ref.load_state_dict(O.seeded_state_dict(ref.state_dict()))
@@ -218,8 +219,12 @@ def main():
     out_dir = REPO / "tests" / "golden"
     out_dir.mkdir(parents=True, exist_ok=True)
     install_stand_ins()
-    dump_units(out_dir)
+    if len(sys.argv) <= 1:
+        dump_units(out_dir)
+    only = set(sys.argv[1:])
     for name in C.CASES:
+        if only and name not in only:
+            continue
         config, batch, train = C.build(name)
         dump_case(name, config, batch, train, out_dir)
 
