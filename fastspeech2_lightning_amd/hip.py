@@ -93,6 +93,15 @@ SIGNATURES = {
     "fs2hip_attn_bin_loss": "pppfppiiip",
     "fs2hip_attn_softmax_bwd": "ppppppiiip",
     "fs2hip_attn_dist_bwd": "pppppiiiip",
+    "fs2hip_conv2d_s2_fwd": "pppiiiiip",
+    "fs2hip_conv2d_s2_bwd_data": "pppiiiiip",
+    "fs2hip_conv2d_s2_wgrad_parts": "iii",
+    "fs2hip_conv2d_s2_bwd_weight": "ppppiiiiip",
+    "fs2hip_gru_gate_fwd": "pqppppiip",
+    "fs2hip_gru_gate_bwd": "ppppqppiip",
+    "fs2hip_gst_attn_fwd": "pppppiiip",
+    "fs2hip_gst_attn_bwd": "ppppppppiiip",
+    "fs2hip_act_apply": "ppqip",
 }
 EXPORTS = list(SIGNATURES)
 
@@ -829,4 +838,87 @@ def duration_round(logd, control=1.0):
     _chk(logd, name="logd")
     out = torch.empty(logd.shape, device=logd.device, dtype=torch.int32)
     _ok(lib().fs2hip_duration_round(_p(logd), float(control), _p(out), logd.numel(), _stream()), "duration_round")
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# GST style encoder (gst.hip)
+# ------------------------------------------------------------------------------------------
+def conv2d_s2_fwd(x, w):
+    """x [B, H, W, Cin] channels-last, w [3, 3, Cin, Cout] -> y [B, (H-1)//2+1, (W-1)//2+1, Cout]."""
+    _chk(x, name="x"); _chk(w, name="w")
+    B, Hh, Ww, Cin = x.shape
+    _req(w.shape[:3] == (3, 3, Cin), "conv2d_s2_fwd: weight shape")
+    Cout = w.shape[3]
+    y = torch.empty(B, (Hh - 1) // 2 + 1, (Ww - 1) // 2 + 1, Cout, device=x.device, dtype=torch.float32)
+    _ok(lib().fs2hip_conv2d_s2_fwd(_p(x), _p(w), _p(y), B, Hh, Ww, Cin, Cout, _stream()), "conv2d_s2_fwd")
+    return y
+
+
+def conv2d_s2_bwd(dy, x, w, dw, need_dx=True):
+    """Writes dw [3,3,Cin,Cout]; returns dx (or None)."""
+    _chk(dy, name="dy"); _chk(x, name="x"); _chk(w, name="w"); _chk(dw, name="dw")
+    B, Hh, Ww, Cin = x.shape
+    Cout = w.shape[3]
+    _req(dy.shape == (B, (Hh - 1) // 2 + 1, (Ww - 1) // 2 + 1, Cout) and dw.numel() == w.numel(), "conv2d_s2_bwd: shapes")
+    parts = lib().fs2hip_conv2d_s2_wgrad_parts(B, Hh, Ww)
+    ws = _workspace(parts * w.numel(), x.device)
+    _ok(lib().fs2hip_conv2d_s2_bwd_weight(_p(x), _p(dy), _p(ws), _p(dw), B, Hh, Ww, Cin, Cout, _stream()), "conv2d_s2_bwd_weight")
+    if not need_dx:
+        return None
+    dx = torch.empty_like(x)
+    _ok(lib().fs2hip_conv2d_s2_bwd_data(_p(dy), _p(w), _p(dx), B, Hh, Ww, Cin, Cout, _stream()), "conv2d_s2_bwd_data")
+    return dx
+
+
+def gru_gate_fwd(gi_t, gi_stride, gh, hprev, U, hnew=None):
+    """gi_t: view of the step's input projections (first row), rows ``gi_stride`` floats apart."""
+    _chk(gh, name="gh"); _chk(hprev, name="hprev")
+    B = hprev.shape[0]
+    hnew = torch.empty_like(hprev) if hnew is None else _chk(hnew, name="hnew")
+    gates = torch.empty(B, 4 * U, device=gh.device, dtype=torch.float32)
+    _ok(lib().fs2hip_gru_gate_fwd(gi_t.data_ptr(), gi_stride, _p(gh), _p(hprev), _p(hnew), _p(gates), B, U, _stream()),
+        "gru_gate_fwd")
+    return hnew, gates
+
+
+def gru_gate_bwd(dh, gates, hprev, dgi_t, dgi_stride, U, dgh=None):
+    _chk(dh, name="dh"); _chk(gates, name="gates"); _chk(hprev, name="hprev")
+    B = hprev.shape[0]
+    dgh = torch.empty(B, 3 * U, device=dh.device, dtype=torch.float32) if dgh is None else _chk(dgh, name="dgh")
+    dhprev = torch.empty_like(hprev)
+    _ok(lib().fs2hip_gru_gate_bwd(_p(dh), _p(gates), _p(hprev), dgi_t.data_ptr(), dgi_stride, _p(dgh), _p(dhprev), B, U,
+                                  _stream()), "gru_gate_bwd")
+    return dgh, dhprev
+
+
+def gst_attn_fwd(q, k, v, heads):
+    _chk(q, name="q"); _chk(k, name="k"); _chk(v, name="v")
+    B, F = q.shape
+    NT = k.shape[0]
+    _req(F == heads * 64 and k.shape == (NT, F) and v.shape == (NT, F), "gst_attn_fwd: shapes")
+    p = torch.empty(B, heads, NT, device=q.device, dtype=torch.float32)
+    ctx = torch.empty_like(q)
+    _ok(lib().fs2hip_gst_attn_fwd(_p(q), _p(k), _p(v), _p(p), _p(ctx), B, NT, heads, _stream()), "gst_attn_fwd")
+    return p, ctx
+
+
+def gst_attn_bwd(dctx, q, k, v, p, heads):
+    """Returns dq [B,F] and per-utterance dk, dv [B, NT, F] (sum over the batch with colsum)."""
+    for n, t in (("dctx", dctx), ("q", q), ("k", k), ("v", v), ("p", p)):
+        _chk(t, name=n)
+    B, F = q.shape
+    NT = k.shape[0]
+    dq = torch.empty_like(q)
+    dk = torch.empty(B, NT, F, device=q.device, dtype=torch.float32)
+    dv = torch.empty_like(dk)
+    _ok(lib().fs2hip_gst_attn_bwd(_p(dctx), _p(q), _p(k), _p(v), _p(p), _p(dq), _p(dk), _p(dv), B, NT, heads, _stream()),
+        "gst_attn_bwd")
+    return dq, dk, dv
+
+
+def act_apply(x, act):
+    _chk(x, name="x")
+    out = torch.empty_like(x)
+    _ok(lib().fs2hip_act_apply(_p(x), _p(out), x.numel(), _ACT[act], _stream()), "act_apply")
     return out

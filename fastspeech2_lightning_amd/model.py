@@ -231,8 +231,6 @@ class FastSpeech2(_Base):
         self.lang2id, self.speaker2id = lang2id or {}, speaker2id or {}
         self.current_epoch_ = 0
         m = config.model
-        if m.use_global_style_token_module:
-            raise NotImplementedError("GST style encoder (SURVEY A18) is not built yet")
         if m.target_text_representation_level == TargetTrainingTextRepresentationLevel.phonological_features:
             raise NotImplementedError("phonological-feature input layer is not built yet")
         d = m.encoder.input_dim
@@ -244,6 +242,9 @@ class FastSpeech2(_Base):
         S.add_buffer("position_embedding.inv_freq", 1 / (10000 ** (torch.arange(0.0, d, 2.0) / d)))
         self.encoder = M.Conformer(S, self.env, "encoder.", m.encoder)
         S.next_bucket()
+        self.gst = None
+        if m.use_global_style_token_module:
+            self.gst = M.StyleEncoder(S, self.env, "gst.", config.preprocessing.audio.n_mels)
         if m.multispeaker:
             if len(self.speaker2id) == 0:
                 print("Your model is multispeaker but speaker2id LookupTable is empty", file=sys.stderr)
@@ -286,7 +287,7 @@ class FastSpeech2(_Base):
 
     def _reorder_state_dict_keys(self):
         """state_dict() lists keys in the reference's module registration order."""
-        groups = ["text_input_layer.", "position_embedding.", "encoder.", "variance_adaptor.duration_predictor.",
+        groups = ["text_input_layer.", "position_embedding.", "gst.", "encoder.", "variance_adaptor.duration_predictor.",
                   "variance_adaptor.pitch_predictor.", "variance_adaptor.pitch_embedding.", "variance_adaptor.pitch_bins",
                   "variance_adaptor.energy_predictor.", "variance_adaptor.energy_embedding.", "variance_adaptor.energy_bins",
                   "variance_adaptor.attention.", "decoder.", "mel_linear.", "postnet.", "speaker_embedding.",
@@ -366,6 +367,13 @@ class FastSpeech2(_Base):
         inputs = H.embedding_fwd(text, S.p("text_input_layer.weight"))
         x = H.add_posenc(inputs, self._table(Ts), src_lens, B, Ts)
         x, enc_ctx = self.encoder.fwd(x, src_lens)
+        gst_ctx = None
+        if self.gst is not None:
+            # fs2/model.py:196-203: training / teacher forcing condition on the target mel
+            if batch.get("mel") is None:
+                raise NotImplementedError("GST inference without a reference mel (condition_on_gst_tokens) is not built yet")
+            style, gst_ctx = self.gst.fwd(batch["mel"])
+            x = H.add_rowvec(x, style, B, Ts)
         if m.multispeaker:
             x = H.add_rowvec(x, H.embedding_fwd(batch["speaker_id"], S.p("speaker_embedding.weight")), B, Ts)
         if m.multilingual:
@@ -385,7 +393,7 @@ class FastSpeech2(_Base):
             postnet_output = H.axpby(output, post)
         if save:
             self._ctx = dict(text=text, enc=enc_ctx, va=va_ctx, dec=dec_ctx, dec_out=y, post=post_ctx, B=B, Ts=Ts, Tm=Tm,
-                             batch=batch)
+                             batch=batch, gst=gst_ctx)
         return {
             "output": output, "postnet_output": postnet_output,
             "src_mask": H.mask_from_lens(src_lens, Ts), "src_lens": src_lens,
@@ -420,6 +428,8 @@ class FastSpeech2(_Base):
         if sync:
             sync.bucket_ready(2)
         d, d_text = self.variance_adaptor.bwd(d, g, c["va"])
+        if c.get("gst") is not None:
+            self.gst.bwd(self._rowsum(d), c["gst"])
         if m.multispeaker:
             self._rowvec_embedding_bwd("speaker_embedding.weight", c["batch"]["speaker_id"], d)
         if m.multilingual:
@@ -434,12 +444,16 @@ class FastSpeech2(_Base):
             sync.bucket_ready(0)
         self._ctx = self._loss_grads = None
 
-    def _rowvec_embedding_bwd(self, name, ids, d):
+    def _rowsum(self, d):
+        """[B, T, D] -> [B, D]: gradient of a per-utterance vector that was broadcast over time."""
         B, T, D = d.shape
         summed = torch.empty(B, D, device=d.device, dtype=torch.float32)
         for b in range(B):  # config-5 path; one column-sum per utterance
             H.colsum(d[b], summed[b])
-        H.embedding_bwd(ids, summed, self.store.g(name))
+        return summed
+
+    def _rowvec_embedding_bwd(self, name, ids, d):
+        H.embedding_bwd(ids, self._rowsum(d), self.store.g(name))
 
     # ---- Lightning-style hooks ----------------------------------------------------------------------
     def training_step(self, batch, batch_idx=0):

@@ -410,6 +410,120 @@ class Aligner:
 
 
 # ------------------------------------------------------------------------------------------------
+# GST style encoder  fs2/gst/model.py:14-280 (BASELINE config 5)
+# ------------------------------------------------------------------------------------------------
+class StyleEncoder:
+    """ReferenceEncoder (6 x [Conv2d 3x3 s2 -> BatchNorm2d -> ReLU] -> GRU(128)) -> StyleTokenLayer (10 tanh'd
+    tokens of 64 dims, 4-head attention, 256-dim output).  Channels-last throughout; the GRU input weights are
+    stored with their columns permuted to the channels-last feature order."""
+    CHANS, U, TOKENS, TOKEN_DIM, HEADS = (32, 32, 64, 64, 128, 128), 128, 10, 256, 4
+
+    def __init__(self, S, env: Env, prefix, idim):
+        self.S, self.env = S, env
+        self.convs, cin, f = [], 1, idim
+        for i, c in enumerate(self.CHANS):
+            w = f"{prefix}ref_enc.convs.{3 * i}.weight"
+            S.add(w, (c, cin, 3, 3), "conv2d", P.init_linear_weight)
+            self.convs.append((w, BatchNorm(S, f"{prefix}ref_enc.convs.{3 * i + 1}.", c), c))
+            cin, f = c, (f - 1) // 2 + 1
+        if f != 2:
+            raise NotImplementedError("GST: the reference encoder must leave 2 frequency bins (n_mels in 65..128)")
+        g = prefix + "ref_enc.gru."
+        U, ub = self.U, P.init_bias_for(self.U)
+        self.wih, self.whh, self.bih, self.bhh = g + "weight_ih_l0", g + "weight_hh_l0", g + "bias_ih_l0", g + "bias_hh_l0"
+        S.add(self.wih, (3 * U, f * cin), "gru_ih_w2", ub)
+        S.add(self.whh, (3 * U, U), "id", ub)
+        S.add(self.bih, (3 * U,), "id", ub)
+        S.add(self.bhh, (3 * U,), "id", ub)
+        self.embs = prefix + "stl.gst_embs"
+        S.add(self.embs, (self.TOKENS, self.TOKEN_DIM // self.HEADS), "id", P.init_normal)
+        m = prefix + "stl.mha."
+        self.lin = {}
+        for name, n_in in (("q", U), ("k", self.TOKEN_DIM // self.HEADS), ("v", self.TOKEN_DIM // self.HEADS),
+                           ("out", self.TOKEN_DIM)):
+            self.lin[name] = (f"{m}linear_{name}.weight", f"{m}linear_{name}.bias")
+            decl_linear(S, f"{m}linear_{name}.", self.TOKEN_DIM, n_in)
+
+    def _lw(self, name):
+        w, b = self.lin[name]
+        return self.S.p(w), self.S.p(b)
+
+    def fwd(self, mel):
+        S, env, U = self.S, self.env, self.U
+        B, T, F = mel.shape
+        x = mel.view(B, T, F, 1)
+        conv_saved = []
+        for w, bn, c in self.convs:
+            raw = H.conv2d_s2_fwd(x, S.p(w))
+            rows = raw.numel() // c
+            partial, nparts = H.colstats(raw.view(rows, c)) if env.training else (None, 0)
+            stats = bn.stats(partial, nparts, rows, env.training)
+            y = H.bn_act_fwd(raw.view(rows, c), stats, "relu").view(raw.shape)
+            conv_saved.append((x, raw, stats))
+            x = y
+        _, Hh, Ww, C = x.shape
+        feat = x.view(B * Hh, Ww * C)
+        gi = H.linear_fwd(feat, S.p(self.wih), S.p(self.bih))            # rows (b, t)
+        hs = torch.zeros(Hh + 1, B, U, device=mel.device, dtype=torch.float32)
+        gates = []
+        for t in range(Hh):
+            gh = H.linear_fwd(hs[t], S.p(self.whh), S.p(self.bhh))
+            _, g = H.gru_gate_fwd(gi.view(-1)[t * 3 * U:], Hh * 3 * U, gh, hs[t], U, hnew=hs[t + 1])
+            gates.append(g)
+        ref = hs[Hh]
+        q = H.linear_fwd(ref, *self._lw("q"))
+        tk = H.act_apply(S.p(self.embs), "tanh")
+        k = H.linear_fwd(tk, *self._lw("k"))
+        v = H.linear_fwd(tk, *self._lw("v"))
+        p, ctx = H.gst_attn_fwd(q, k, v, self.HEADS)
+        style = H.linear_fwd(ctx, *self._lw("out"))
+        return style, Ctx(conv=conv_saved, feat=feat, hs=hs, gates=gates, q=q, tk=tk, k=k, v=v, p=p, ctx=ctx,
+                          shape=(B, Hh, Ww, C))
+
+    def bwd(self, d_style, c):
+        S, env, U = self.S, self.env, self.U
+        B, Hh, Ww, C = c.shape
+        g = lambda name: (S.g(self.lin[name][0]), S.g(self.lin[name][1]))  # noqa: E731
+        gw, gb = g("out")
+        H.linear_bwd_weight(d_style, c.ctx, gw); H.colsum(d_style, gb)
+        dctx = H.linear_bwd_data(d_style, self._lw("out")[0])
+        dq, dkp, dvp = H.gst_attn_bwd(dctx, c.q, c.k, c.v, c.p, self.HEADS)
+        NT, Fd = c.k.shape
+        dk = torch.empty(NT, Fd, device=dq.device, dtype=torch.float32)
+        dv = torch.empty_like(dk)
+        H.colsum(dkp.view(B, NT * Fd), dk.view(-1))
+        H.colsum(dvp.view(B, NT * Fd), dv.view(-1))
+        gw, gb = g("k")
+        H.linear_bwd_weight(dk, c.tk, gw); H.colsum(dk, gb)
+        dtk = H.linear_bwd_data(dk, self._lw("k")[0])
+        gw, gb = g("v")
+        H.linear_bwd_weight(dv, c.tk, gw); H.colsum(dv, gb)
+        dtk = H.axpby(dtk, H.linear_bwd_data(dv, self._lw("v")[0]))
+        H.axpby(H.dact_mul(dtk, S.p(self.embs), "tanh"), None, 1.0, 0.0, out=S.g(self.embs))
+        gw, gb = g("q")
+        H.linear_bwd_weight(dq, c.hs[Hh], gw); H.colsum(dq, gb)
+        dh = H.linear_bwd_data(dq, self._lw("q")[0])
+        # GRU backward through time
+        dgi = torch.empty(B * Hh, 3 * U, device=dh.device, dtype=torch.float32)
+        dgh_all = torch.empty(Hh, B, 3 * U, device=dh.device, dtype=torch.float32)
+        for t in range(Hh - 1, -1, -1):
+            _, dhprev = H.gru_gate_bwd(dh, c.gates[t], c.hs[t], dgi.view(-1)[t * 3 * U:], Hh * 3 * U, U, dgh=dgh_all[t])
+            dh = H.axpby(dhprev, H.linear_bwd_data(dgh_all[t], S.p(self.whh)))
+        H.linear_bwd_weight(dgh_all.view(Hh * B, 3 * U), c.hs[:Hh].reshape(Hh * B, U), S.g(self.whh))
+        H.colsum(dgh_all.view(Hh * B, 3 * U), S.g(self.bhh))
+        H.linear_bwd_weight(dgi, c.feat, S.g(self.wih))
+        H.colsum(dgi, S.g(self.bih))
+        d = H.linear_bwd_data(dgi, S.p(self.wih)).view(B, Hh, Ww, C)
+        for i in range(len(self.convs) - 1, -1, -1):
+            w, bn, ch = self.convs[i]
+            x, raw, stats = c.conv[i]
+            rows = raw.numel() // ch
+            gg, gbb = bn.grads()
+            draw = H.bn_act_bwd(d.reshape(rows, ch), raw.view(rows, ch), stats, gg, gbb, "relu", training=env.training)
+            d = H.conv2d_s2_bwd(draw.view(raw.shape), x, S.p(w), S.g(w), need_dx=i > 0)
+
+
+# ------------------------------------------------------------------------------------------------
 # PostNet  fs2/layers.py:143-212
 # ------------------------------------------------------------------------------------------------
 class PostNet:

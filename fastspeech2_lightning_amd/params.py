@@ -27,12 +27,17 @@ _TO_NATIVE = {
     "convk": lambda t: t.permute(2, 0, 1),   # (Cout, Cin, K) -> [K][Cout][Cin]
     "dw": lambda t: t[:, 0, :].t(),           # (C, 1, K)     -> [K][C]
     "pw": lambda t: t[:, :, 0],               # (Cout, Cin, 1) -> [Cout][Cin]
+    "conv2d": lambda t: t.permute(2, 3, 1, 0),  # (Cout, Cin, kh, kw) -> [kh][kw][Cin][Cout]
+    # GRU input weights (3U, C*W) with columns c*W+w  ->  columns w*C+c (channels-last feature order); W = 2
+    "gru_ih_w2": lambda t: t.reshape(t.shape[0], -1, 2).transpose(1, 2).reshape(t.shape[0], -1),
 }
 _TO_REF = {
     "id": lambda t, shape: t,
     "convk": lambda t, shape: t.permute(1, 2, 0),
     "dw": lambda t, shape: t.t().unsqueeze(1),
     "pw": lambda t, shape: t.unsqueeze(-1),
+    "conv2d": lambda t, shape: t.permute(3, 2, 0, 1),
+    "gru_ih_w2": lambda t, shape: t.reshape(t.shape[0], 2, -1).transpose(1, 2).reshape(t.shape[0], -1),
 }
 
 
@@ -44,6 +49,8 @@ def native_shape(ref_shape, kind):
         return (s[2], s[0])
     if kind == "pw":
         return (s[0], s[1])
+    if kind == "conv2d":
+        return (s[2], s[3], s[1], s[0])
     return s
 
 

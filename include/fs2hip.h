@@ -273,6 +273,34 @@ int fs2hip_attn_softmax_bwd(const float* logits, const float* soft, const float*
 int fs2hip_attn_dist_bwd(const float* dlogits, const float* q, const float* k, float* dq, float* dk, int B,
                          int T1, int T2, int C, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * GST style encoder (fs2/gst/model.py:103-257, fs2/gst/attn.py:48-194; BASELINE config 5).
+ *   conv2d_s2_*     3x3 / stride 2 / pad 1 / no bias Conv2d on channels-last [B][H][W][C];
+ *                   weights [kh][kw][Cin][Cout]; output extent (n - 1) / 2 + 1 per spatial dim;
+ *                   weight gradient through partial[parts][9*Cin*Cout]
+ *   gru_gate_*      one nn.GRU time step (gate order r, z, n): gi rows (stride gi_stride) and gh
+ *                   [B][3U] come from the GEMM; gates [B][4U] keeps r, z, n, gh_n for the backward
+ *   gst_attn_*      softmax(q k^T / 8) v for one query per utterance against NT <= 32 style tokens,
+ *                   `heads` <= 4 heads of 64 dims; dk_part / dv_part are per-utterance [B][NT][F]
+ *   act_apply       out = act(x)  (tanh of the style tokens)
+ * ------------------------------------------------------------------------------------ */
+int fs2hip_conv2d_s2_fwd(const float* x, const float* w, float* y, int B, int H, int W, int Cin, int Cout,
+                         void* stream);
+int fs2hip_conv2d_s2_bwd_data(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Cout,
+                              void* stream);
+int fs2hip_conv2d_s2_wgrad_parts(int B, int H, int W);
+int fs2hip_conv2d_s2_bwd_weight(const float* x, const float* dy, float* partial, float* dw, int B, int H, int W,
+                                int Cin, int Cout, void* stream);
+int fs2hip_gru_gate_fwd(const float* gi, long long gi_stride, const float* gh, const float* hprev, float* hnew,
+                        float* gates, int B, int U, void* stream);
+int fs2hip_gru_gate_bwd(const float* dh, const float* gates, const float* hprev, float* dgi, long long dgi_stride,
+                        float* dgh, float* dhprev, int B, int U, void* stream);
+int fs2hip_gst_attn_fwd(const float* q, const float* k, const float* v, float* p, float* ctx, int B, int NT,
+                        int heads, void* stream);
+int fs2hip_gst_attn_bwd(const float* dctx, const float* q, const float* k, const float* v, const float* p,
+                        float* dq, float* dk_part, float* dv_part, int B, int NT, int heads, void* stream);
+int fs2hip_act_apply(const float* x, float* out, long long n, int act, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,7 +21,8 @@ GPU_CASES = list(C.CASES)
 def build_model(name):
     from fastspeech2_lightning_amd.model import FastSpeech2
     config, batch, train = C.build(name)
-    model = FastSpeech2(config, Stats(**C.STATS))
+    kw = dict(lang2id=C.LANG2ID, speaker2id=C.SPEAKER2ID) if config.model.multispeaker else {}
+    model = FastSpeech2(config, Stats(**C.STATS), **kw)
     model.load_state_dict(O.seeded_state_dict(model.state_dict()))
     model.train(train)
     model.postnet.dropout_p = 0.0  # goldens are generated with dropout as the identity
