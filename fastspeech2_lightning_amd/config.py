@@ -127,6 +127,7 @@ class FastSpeech2TrainingConfig(_Cfg):  # :193-243
 
 class AudioConfig(_Cfg):
     n_mels: int = 80
+    spec_type: str = "mel-librosa"
     input_sampling_rate: int = 22050
     output_sampling_rate: int = 22050
 
@@ -176,6 +177,27 @@ class TextProcessor:
             else:
                 i += 1  # unknown symbol: dropped
         return out
+
+
+    def encode_escaped_string_sequence(self, tokens) -> list[int]:
+        """Token sequence as stored by the preprocessor: symbols separated by '/' ('\\/' is a literal slash);
+        a list of symbols is accepted as well.  Unknown symbols are dropped."""
+        if isinstance(tokens, str):
+            parts, cur, i = [], "", 0
+            while i < len(tokens):
+                if tokens[i] == "\\" and i + 1 < len(tokens):
+                    cur += tokens[i + 1]
+                    i += 2
+                elif tokens[i] == "/":
+                    parts.append(cur)
+                    cur = ""
+                    i += 1
+                else:
+                    cur += tokens[i]
+                    i += 1
+            parts.append(cur)
+            tokens = parts
+        return [self._index[t] for t in tokens if t in self._index]
 
 
 class FastSpeech2Config(_Cfg):  # reference fs2/config/__init__.py:246-317

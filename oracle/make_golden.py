@@ -92,7 +92,23 @@ def install_stand_ins():
     _mod("everyvoice.text.utils", get_symbols_from_checkpoint_symbol_dict=None, symbol_sorter=None)
     _mod("everyvoice.utils", pydantic_validation_error_shortener=str, slugify=lambda s, **k: s)
     _mod("everyvoice.utils.heavy", expand=None)
-    _mod("everyvoice.exceptions", BadDataError=cfgmod.BadDataError)
+    _mod("everyvoice.exceptions", BadDataError=cfgmod.BadDataError, InvalidConfiguration=ValueError)
+    # --- stand-ins needed to import fs2/dataset.py (batch producer) -----------------------------
+    import enum
+
+    class DatasetTextRepresentation(str, enum.Enum):  # value strings of the parent toolkit's enum
+        characters = "characters"
+        ipa_phones = "phones"
+        arpabet = "arpabet"
+
+    sys.modules["everyvoice.config.type_definitions"].DatasetTextRepresentation = DatasetTextRepresentation
+    _mod("everyvoice.dataloader", BaseDataModule=object)
+    _mod("everyvoice.preprocessor", Preprocessor=None)
+    sys.modules["everyvoice.text.lookups"].lookuptables_from_config = None
+    ev_utils = sys.modules["everyvoice.utils"]
+    ev_utils._flatten = dict  # per-utterance items are flat dicts: flattening is a copy
+    ev_utils.check_dataset_size = None
+    ev_utils.filter_dataset_based_on_target_text_representation_level = None
     # the reference's fs2/config builds on everyvoice.config base classes that do
     # not exist here: the schema stand-in is the build's own re-declaration.
     sys.path.insert(0, str(REFERENCE))
@@ -215,12 +231,67 @@ def dump_units(out_dir: Path):
     print(f"units: {len(save)} arrays")
 
 
+def dump_data(out_dir: Path):
+    """Batch producer golden: the reference's ``FastSpeechDataset.__getitem__`` + ``collate_method`` run over
+    synthetic per-utterance feature files; the fixture holds the raw features and the collated result."""
+    import tempfile
+
+    from fs2.dataset import FastSpeech2DataModule, FastSpeechDataset
+
+    save = {}
+    g = torch.Generator().manual_seed(1234)
+    symbols = [f"s{i}" for i in range(12)] + ["/"]
+    utts = [("utt-a", "spk0", "eng", 7, 23), ("utt-b", "spk1", "fra", 4, 11), ("utt-c", "spk0", "eng", 9, 31)]
+    for learn_alignment in (True, False):
+        tag = "align" if learn_alignment else "noalign"
+        config = C.small_config(learn_alignment=learn_alignment, n_mels=8)
+        config.text.symbols = {"letters": symbols}
+        with tempfile.TemporaryDirectory() as tmp:
+            config.preprocessing.save_dir = tmp
+            entries = []
+            for bn, spk, lang, n_tok, n_frames in utts:
+                toks = [symbols[int(i)] for i in torch.randint(0, len(symbols), (n_tok,), generator=g)]
+                escaped = "/".join(t.replace("/", "\\/") for t in toks)
+                feats = {
+                    ("spec", f"spec-{config.preprocessing.audio.input_sampling_rate}-"
+                             f"{config.preprocessing.audio.spec_type}.pt"): torch.randn(8, n_frames, generator=g),
+                    ("energy", "energy.pt"): torch.randn(n_tok, generator=g),
+                    ("pitch", "pitch.pt"): torch.randn(n_tok, generator=g),
+                }
+                if learn_alignment:
+                    feats[("attn", "characters-attn-prior.pt")] = torch.rand(n_frames, n_tok, generator=g)
+                else:
+                    d = torch.ones(n_tok, dtype=torch.int64)
+                    d[0] += n_frames - n_tok
+                    feats[("duration", "duration.pt")] = d
+                for (kind, fn), t in feats.items():
+                    (Path(tmp) / kind).mkdir(exist_ok=True)
+                    torch.save(t, Path(tmp) / kind / "--".join([bn, spk, lang, fn]))
+                    save[f"{tag}/in/{bn}/{kind}"] = t.numpy()
+                save[f"{tag}/in/{bn}/tokens"] = np.array(escaped)
+                entries.append({"basename": bn, "speaker": spk, "language": lang, "character_tokens": escaped,
+                                "characters": "".join(toks)})
+            ds = FastSpeechDataset(entries, config, {"eng": 0, "fra": 1}, {"spk0": 0, "spk1": 1})
+            batch = FastSpeech2DataModule.collate_method([ds[i] for i in range(len(ds))],
+                                                         learn_alignment=learn_alignment)
+        for k, v in batch.items():
+            if torch.is_tensor(v):
+                save[f"{tag}/out/{k}"] = v.numpy()
+                save[f"{tag}/dtype/{k}"] = np.array(str(v.dtype))
+            elif isinstance(v, list) and v and isinstance(v[0], str):
+                save[f"{tag}/out/{k}"] = np.array(v)
+    np.savez_compressed(out_dir / "data_collate.npz", **save)
+    print(f"data: {len(save)} arrays")
+
+
 def main():
     out_dir = REPO / "tests" / "golden"
     out_dir.mkdir(parents=True, exist_ok=True)
     install_stand_ins()
     if len(sys.argv) <= 1:
         dump_units(out_dir)
+    if len(sys.argv) <= 1 or "data" in sys.argv[1:]:
+        dump_data(out_dir)
     only = set(sys.argv[1:])
     for name in C.CASES:
         if only and name not in only:
