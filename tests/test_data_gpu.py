@@ -25,8 +25,9 @@ def _write_corpus(tmp, cfg, n_utts=6, learn_alignment=False):
         bn = f"utt{u}"
         feats = {("spec", f"spec-{audio.input_sampling_rate}-{audio.spec_type}.pt"):
                  torch.randn(audio.n_mels, n_frames, generator=g),
-                 ("energy", "energy.pt"): torch.randn(n_tok, generator=g),
-                 ("pitch", "pitch.pt"): torch.randn(n_tok, generator=g)}
+                 # learned alignment stores frame-level pitch / energy (averaged per token by the aligner)
+                 ("energy", "energy.pt"): torch.randn(n_frames if learn_alignment else n_tok, generator=g),
+                 ("pitch", "pitch.pt"): torch.randn(n_frames if learn_alignment else n_tok, generator=g)}
         if learn_alignment:
             feats[("attn", "characters-attn-prior.pt")] = torch.rand(n_frames, n_tok, generator=g) + 0.1
         else:
