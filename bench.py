@@ -221,11 +221,13 @@ def main():
     if roofline is None and not args.no_roofline and rank == 0:
         if os.environ.get("FS2_BENCH_GEMM_BREAKDOWN"):
             by = {}
-            for e0, e1, fl, mc, nc, r, _nb in prof:
-                t, f, n = by.get((mc, nc, r), (0.0, 0.0, 0))
-                by[(mc, nc, r)] = (t + e0.elapsed_time(e1), f + fl, n + 1)
-            for (mc, nc, r), (t, f, n) in sorted(by.items(), key=lambda kv: -kv[1][0])[:24]:
-                log(f"gemm Mc={mc:6d} Nc={nc:5d} R={r:6d} x{n:3d}: {t:7.3f} ms  {f / t / 1e9:6.1f} TFLOP/s")
+            for e0, e1, fl, mc, nc, r, _nb, kind in prof:
+                t, f, n = by.get((mc, nc, r, kind), (0.0, 0.0, 0))
+                by[(mc, nc, r, kind)] = (t + e0.elapsed_time(e1), f + fl, n + 1)
+            for (mc, nc, r, kind), (t, f, n) in sorted(by.items(), key=lambda kv: -kv[1][0])[:40]:
+                ak, bk, taps, sh, sk, epi, tile = kind
+                log(f"gemm Mc={mc:6d} Nc={nc:5d} R={r:6d} {'NT'[ak]}{'NT'[bk]} taps={taps} sh={sh} splitk={sk:2d} epi={epi} "
+                    f"tile={tile} x{n:3d}: {t:7.3f} ms  {f / t / 1e9:6.1f} TFLOP/s")
         ms = sum(q[0].elapsed_time(q[1]) for q in prof)
         flops = sum(q[2] for q in prof)
         achieved = flops / (ms * 1e-3) / 1e12

@@ -17,12 +17,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---- stateless dropout: keep iff hash(seed, idx) >= p * 2^32 ------------------------------
+// 32-bit two-round multiply-xorshift mixer (the per-kernel 64-bit seed enters before the first and between the
+// two rounds, so that two dropout sites / steps are not index-permuted copies of one mask).  Integer
+// multiplies are quarter rate on CDNA: a 64-bit splitmix (12 of them per element) made the GEMM epilogues and
+// the attention kernels VALU-bound; this one costs two.
 __device__ __forceinline__ uint32_t fs2_hash32(unsigned long long seed, unsigned long long idx) {
-  unsigned long long z = seed + idx * 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (uint32_t)(z >> 32);
+  const uint32_t hi = (uint32_t)(idx >> 32);
+  uint32_t x = (uint32_t)idx ^ (uint32_t)seed ^ ((hi << 13) | (hi >> 19));
+  x ^= x >> 16;
+  x *= 0x7feb352du;
+  x ^= (uint32_t)(seed >> 32);
+  x ^= x >> 15;
+  x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
 }
 struct Fs2Drop {
   uint32_t thresh;  // drop iff hash < thresh
@@ -44,7 +52,12 @@ inline Fs2Drop fs2_make_drop(float p, unsigned long long seed, const unsigned lo
 }
 // call once at kernel entry
 __device__ __forceinline__ Fs2Drop fs2_resolve_drop(Fs2Drop d) {
-  if (d.on && d.step) d.seed += (*d.step) * 0xD1B54A32D192ED03ull;
+  if (d.on) {
+    unsigned long long z = d.seed + (d.step ? (*d.step) * 0xD1B54A32D192ED03ull : 0ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;  // once per thread: spread site / step over both seed words
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    d.seed = z ^ (z >> 31);
+  }
   return d;
 }
 __device__ __forceinline__ float fs2_drop_factor(const Fs2Drop& d, unsigned long long idx) {
@@ -53,7 +66,8 @@ __device__ __forceinline__ float fs2_drop_factor(const Fs2Drop& d, unsigned long
 }
 
 // ---- activations ------------------------------------------------------------------------
-__device__ __forceinline__ float fs2_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+// v_exp_f32 + v_rcp_f32 (about 1 ulp each): the epilogues that call this run once per output element
+__device__ __forceinline__ float fs2_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float fs2_act(int act, float x) {
   switch (act) {
     case FS2_ACT_RELU: return x > 0.f ? x : 0.f;

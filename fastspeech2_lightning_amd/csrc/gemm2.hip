@@ -135,7 +135,89 @@ __device__ __forceinline__ void wait_vmcnt_barrier() {
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, bool AKC, bool BKC, int NST>
+// MFMA operand fetch from LDS in inline assembly.  A compiler-visible LDS load after an LDS-DMA makes the
+// waitcnt pass insert `s_waitcnt vmcnt(0)` in front of it (it cannot tell which DMA the read depends on),
+// which drains the tile that was just put in flight and serialises DMA and MFMA inside a wave.  With the
+// reads in asm the only vmcnt waits are the counted ones above; the price is that the lgkmcnt bookkeeping
+// is ours as well: `lds_wait<N>()` + `pin()` on every register the following MFMAs consume.
+template <int OFF>
+__device__ __forceinline__ void lds_rd128(f32x4& v, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_rd32(float& v, unsigned addr) {
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lds_wait() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N < 15 ? N : 15) : "memory");
+}
+__device__ __forceinline__ void pin(f32x4& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
+
+// MFMA operands of one 8-deep reduction group (4 MFMA k-steps) for T row blocks of 32.
+//   KC : LDS image [ROWS][32], chunk-swizzled: one ds_read_b128 per row block (lane half h: k = 8g+4h..+3)
+//   !KC: LDS image [32][ROWS]: four conflict-free ds_read_b32 per row block
+template <int T, bool KC>
+struct Frag;
+template <int T>
+struct Frag<T, true> {
+  f32x4 q[T];
+  static constexpr int READS = T;
+  __device__ __forceinline__ float get(int i, int j) const { return q[i][j]; }
+  __device__ __forceinline__ void pin_all() {
+#pragma unroll
+    for (int i = 0; i < T; ++i) pin(q[i]);
+  }
+};
+template <int T>
+struct Frag<T, false> {
+  float q[T][4];
+  static constexpr int READS = 4 * T;
+  __device__ __forceinline__ float get(int i, int j) const { return q[i][j]; }
+  __device__ __forceinline__ void pin_all() {
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pin(q[i][j]);
+  }
+};
+
+// per-lane LDS byte addresses of the operand reads, relative to the operand tile of stage 0
+template <int ROWS, bool KC>
+struct RdAddr {
+  unsigned g[KC ? 4 : 1];
+  __device__ __forceinline__ void setup(int wrow0, int l31, int h) {
+    if (KC) {
+#pragma unroll
+      for (int gg = 0; gg < 4; ++gg) g[gg] = ((wrow0 + l31) * BK2 + (((2 * gg + h) ^ (l31 & 7)) << 2)) * 4;
+    } else {
+      g[0] = (4 * h * ROWS + wrow0 + l31) * 4;
+    }
+  }
+};
+
+template <int G, int ROWS, int T, bool KC>
+__device__ __forceinline__ void frag_read(Frag<T, KC>& f, const RdAddr<ROWS, KC>& ra, unsigned stage_base) {
+  if constexpr (KC) {
+    lds_rd128<0>(f.q[0], ra.g[G] + stage_base);
+    if constexpr (T > 1) lds_rd128<32 * BK2 * 4>(f.q[1], ra.g[G] + stage_base);
+  } else {
+    const unsigned ad = ra.g[0] + stage_base;
+    lds_rd32<(8 * G + 0) * ROWS * 4>(f.q[0][0], ad);
+    lds_rd32<(8 * G + 1) * ROWS * 4>(f.q[0][1], ad);
+    lds_rd32<(8 * G + 2) * ROWS * 4>(f.q[0][2], ad);
+    lds_rd32<(8 * G + 3) * ROWS * 4>(f.q[0][3], ad);
+    if constexpr (T > 1) {
+      lds_rd32<(8 * G + 0) * ROWS * 4 + 128>(f.q[1][0], ad);
+      lds_rd32<(8 * G + 1) * ROWS * 4 + 128>(f.q[1][1], ad);
+      lds_rd32<(8 * G + 2) * ROWS * 4 + 128>(f.q[1][2], ad);
+      lds_rd32<(8 * G + 3) * ROWS * 4 + 128>(f.q[1][3], ad);
+    }
+  }
+}
+
+template <int BM, int BN, bool AKC, bool BKC, int NST, bool TAPS>
 __global__ __launch_bounds__(256) void gemm2_kernel(GemmP p) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int A_TILE = BM * BK2, B_TILE = BN * BK2, STAGE = A_TILE + B_TILE;
@@ -168,10 +250,10 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const bool tapmode = a.taps > 1;  // conv taps: per-tile address decode; otherwise hoisted pointers
+  // conv taps (TAPS): per-tile address decode; otherwise hoisted pointers
   Pieces<BM> pa;
   Pieces<BN> pb;
-  if (!tapmode) {
+  if constexpr (!TAPS) {
     setup_pieces<BM, AKC, true>(pa, p, m0, r_begin, tid);
     setup_pieces<BN, BKC, false>(pb, p, n0, r_begin, tid);
   }
@@ -180,7 +262,7 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmP p) {
     float* At = lds + stage * STAGE;
     float* Bt = At + A_TILE;
     const int r0 = r_begin + kt * BK2;
-    if (tapmode) {
+    if constexpr (TAPS) {
       issue_tile<BM, AKC, true>(At, p, m0, r0, r_end, shift_z, tid, wave);
       issue_tile<BN, BKC, false>(Bt, p, n0, r0, r_end, shift_z, tid, wave);
     } else {
@@ -190,6 +272,12 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmP p) {
   };
 
   const int l31 = lane & 31, h = lane >> 5;
+  const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)lds;
+  RdAddr<BM, AKC> rda;
+  RdAddr<BN, BKC> rdb;
+  rda.setup(wm * (BM / 2), l31, h);
+  rdb.setup(wn * (BN / 2), l31, h);
+
   for (int kt = 0; kt < NST - 1 && kt < nkt; ++kt) issue(kt, kt);
   int stage = 0;
   for (int kt = 0; kt < nkt; ++kt) {
@@ -199,41 +287,34 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmP p) {
     else if (NST >= 3 && newer == 1) wait_vmcnt_barrier<L>();
     else wait_vmcnt_barrier<0>();
     if (kt + NST - 1 < nkt) issue(kt + NST - 1, stage == 0 ? NST - 1 : stage - 1);  // the stage read in iteration kt-1
-    const float* At = lds + stage * STAGE;
-    const float* Bt = At + A_TILE;
-#pragma unroll
-    for (int g = 0; g < BK2 / 8; ++g) {
-      float av[TM][4], bv[TN][4];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int row = wm * (BM / 2) + i * 32 + l31;
-        if (AKC) {
-          const float4 v = *reinterpret_cast<const float4*>(At + row * BK2 + (((2 * g + h) ^ (row & 7)) << 2));
-          av[i][0] = v.x; av[i][1] = v.y; av[i][2] = v.z; av[i][3] = v.w;
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) av[i][j] = At[(8 * g + 4 * h + j) * BM + row];
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < TN; ++i) {
-        const int row = wn * (BN / 2) + i * 32 + l31;
-        if (BKC) {
-          const float4 v = *reinterpret_cast<const float4*>(Bt + row * BK2 + (((2 * g + h) ^ (row & 7)) << 2));
-          bv[i][0] = v.x; bv[i][1] = v.y; bv[i][2] = v.z; bv[i][3] = v.w;
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) bv[i][j] = Bt[(8 * g + 4 * h + j) * BN + row];
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int jn = 0; jn < TN; ++jn)
-            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][j], bv[jn][j], acc[i][jn], 0, 0, 0);
-    }
+    const unsigned sa = lds0 + stage * (STAGE * 4), sb = sa + A_TILE * 4;
+    // LDS reads run one reduction group ahead of the MFMAs that consume them (two register sets)
+    Frag<TM, AKC> fa[2];
+    Frag<TN, BKC> fb[2];
+    constexpr int RD = Frag<TM, AKC>::READS + Frag<TN, BKC>::READS;
+    frag_read<0, BM>(fa[0], rda, sa);
+    frag_read<0, BN>(fb[0], rdb, sb);
+#define FS2_GROUP(G)                                                                                       \
+  {                                                                                                        \
+    if (G < 3) {                                                                                           \
+      frag_read<(G + 1) & 3, BM>(fa[(G + 1) & 1], rda, sa);                                                \
+      frag_read<(G + 1) & 3, BN>(fb[(G + 1) & 1], rdb, sb);                                                \
+      lds_wait<RD>();                                                                                      \
+    } else {                                                                                               \
+      lds_wait<0>();                                                                                       \
+    }                                                                                                      \
+    fa[G & 1].pin_all();                                                                                   \
+    fb[G & 1].pin_all();                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                          \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                         \
+    _Pragma("unroll") for (int jn = 0; jn < TN; ++jn)                                                      \
+        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[G & 1].get(i, j), fb[G & 1].get(jn, j), acc[i][jn], 0, 0, 0); \
+  }
+    FS2_GROUP(0)
+    FS2_GROUP(1)
+    FS2_GROUP(2)
+    FS2_GROUP(3)
+#undef FS2_GROUP
     stage = stage + 1 == NST ? 0 : stage + 1;
   }
   gemm_epilogue<BM, BN>(p, acc, m0, n0, wm, wn, lane, split, tapz);
@@ -245,10 +326,15 @@ int launch_tile(GemmP& p, int nz, hipStream_t s) {
   p.tiles_m = (a.Mc + BM - 1) / BM;
   p.tiles_n = (a.Nc + BN - 1) / BN;
   dim3 grid(p.tiles_m * p.tiles_n, 1, nz), block(256);
-  if (a.a_kcontig && a.b_kcontig) gemm2_kernel<BM, BN, true, true, NST><<<grid, block, 0, s>>>(p);
-  else if (a.a_kcontig && !a.b_kcontig) gemm2_kernel<BM, BN, true, false, NST><<<grid, block, 0, s>>>(p);
-  else if (!a.a_kcontig && !a.b_kcontig) gemm2_kernel<BM, BN, false, false, NST><<<grid, block, 0, s>>>(p);
+  const bool taps = a.taps > 1;
+#define FS2_GO(AK, BK) \
+  (taps ? gemm2_kernel<BM, BN, AK, BK, NST, true><<<grid, block, 0, s>>>(p) \
+        : gemm2_kernel<BM, BN, AK, BK, NST, false><<<grid, block, 0, s>>>(p))
+  if (a.a_kcontig && a.b_kcontig) FS2_GO(true, true);
+  else if (a.a_kcontig && !a.b_kcontig) FS2_GO(true, false);
+  else if (!a.a_kcontig && !a.b_kcontig) FS2_GO(false, false);
   else return FS2HIP_EINVAL;
+#undef FS2_GO
   FS2_LAUNCH_CHECK();
   return 0;
 }

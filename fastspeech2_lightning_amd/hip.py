@@ -256,7 +256,8 @@ def _gemm(_algorithmic=True, **kw):
     ra = a.R // a.taps if (a.taps > 1 and a.shift_operand == 0) else a.R
     nbytes = 4.0 * (a.Mc * ra + a.Nc * a.R + a.Mc * a.Nc * ntap
                     + (a.Mc * a.Nc if a.resid else 0) + (a.Mc * a.Nc if a.aux else 0) + (a.Mc * a.Nc if a.out_pre else 0))
-    GEMM_PROFILE.append((e0, e1, 2.0 * a.Mc * a.Nc * a.R * ntap, a.Mc, a.Nc, a.R * ntap, nbytes))
+    GEMM_PROFILE.append((e0, e1, 2.0 * a.Mc * a.Nc * a.R * ntap, a.Mc, a.Nc, a.R * ntap, nbytes,
+                         (a.a_kcontig, a.b_kcontig, a.taps, a.shift_operand, a.splitk, a.epi, a.tile)))
 
 
 def linear_fwd(x, w, bias=None, *, epi=EPI_STORE, act=None, resid=None, res_scale=1.0, out_pre=None,

@@ -1,0 +1,35 @@
+"""Per-kernel time of ONE training step from a rocprofv3 kernel trace (csv): the step between the last two
+AdamW launches, so the autotuner's timing launches and warm-up are excluded.
+usage: python tools/step_breakdown.py <..._kernel_trace.csv> [n_steps_back]"""
+import csv
+import re
+import sys
+from collections import defaultdict
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+back = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+idx = [i for i, r in enumerate(rows) if "adamw" in r["Kernel_Name"]]
+lo, hi = idx[-1 - back], idx[-1]
+seg = rows[lo + 1:hi + 1]
+t0, t1 = int(seg[0]["Start_Timestamp"]), int(seg[-1]["End_Timestamp"])
+agg = defaultdict(lambda: [0, 0])
+busy = 0
+for r in seg:
+    d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
+    name = re.sub(r"\(.*", "", name).replace("void ", "")
+    agg[name][0] += d
+    agg[name][1] += 1
+    busy += d
+print(f"{back} step(s): wall {(t1 - t0) / 1e6 / back:.2f} ms/step, kernel busy {busy / 1e6 / back:.2f} ms/step, "
+      f"{len(seg) // back} launches/step")
+fam = defaultdict(int)
+for k, (d, n) in agg.items():
+    fam[k.split("<")[0]] += d
+print("-- families")
+for k, d in sorted(fam.items(), key=lambda kv: -kv[1])[:25]:
+    print(f"{d / 1e6 / back:8.3f} ms {100 * d / busy:5.1f}%  {k}")
+print("-- kernels")
+for k, (d, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:40]:
+    print(f"{d / 1e6 / back:8.3f} ms {100 * d / busy:5.1f}%  n={n // back:4d} avg={d / n / 1e3:8.1f} us  {k}")
