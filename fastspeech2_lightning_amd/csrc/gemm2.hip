@@ -89,28 +89,49 @@ template <int ROWS>
 struct Pieces {
   const float* base[ROWS / 32];  // address of the piece in K-tile 0
   int koff[ROWS / 32];           // reduction offset of the piece inside a K-tile (k-contiguous: swizzled chunk)
+  int t[ROWS / 32];              // conv taps: time index of the piece's row (A rows, TAPS == 1) or of its
+                                 // reduction row in the current K-tile (B rows, TAPS == 2)
   bool ok[ROWS / 32];            // row / column inside the matrix
 };
 
-template <int ROWS, bool KC, bool IS_A>
-__device__ __forceinline__ void setup_pieces(Pieces<ROWS>& pc_, const GemmP& p, int row0, int r_begin, int tid) {
+// kernel variants by conv-tap mode
+constexpr int TAPS_NONE = 0;     // plain GEMM
+constexpr int TAPS_RED = 1;      // shift_operand == 0, Rper % 32 == 0: every K-tile lies inside one tap -> the tap
+                                 // (row shift of A, weight slice of B) is a per-tile scalar
+constexpr int TAPS_ROWS = 2;     // shift_operand == 1 (weight gradient): reduction rows of B shifted by the
+                                 // tap of this launch slice; T >= 32
+constexpr int TAPS_GENERIC = 3;  // any Rper / T: per-piece address decode in every K-tile (slow; small convs)
+
+// TAPS_RED keeps the reduction offset out of the base (the per-tile scalar (tap, k-in-tap) supplies it);
+// TAPS_ROWS bakes the launch slice's row shift into B's base and tracks the row's time index.
+template <int ROWS, bool KC, bool IS_A, int TAPS>
+__device__ __forceinline__ void setup_pieces(Pieces<ROWS>& pc_, const GemmP& p, int row0, int r_begin, int shift_z,
+                                             int tid) {
   const Fs2GemmArgs& a = p.a;
   const float* src = IS_A ? a.A : a.B;
   const int ld = IS_A ? a.lda : a.ldb;
   const int nrows = IS_A ? a.Mc : a.Nc;
+  const int rb = TAPS == TAPS_RED ? 0 : r_begin;
 #pragma unroll
   for (int it = 0; it < ROWS / 32; ++it) {
     const int pidx = it * 256 + tid;
+    pc_.t[it] = 0;
     if (KC) {
       const int row = pidx >> 3, pc = pidx & 7, gr = row0 + row;
       pc_.koff[it] = (pc ^ (row & 7)) << 2;
       pc_.ok[it] = gr < nrows;
-      pc_.base[it] = src + (long long)gr * ld + r_begin + pc_.koff[it];
+      pc_.base[it] = src + (long long)gr * ld + rb + pc_.koff[it];
+      if (TAPS == TAPS_RED && IS_A) pc_.t[it] = gr % a.T;
     } else {
       const int k = pidx / (ROWS / 4), col = row0 + (pidx % (ROWS / 4)) * 4;
       pc_.koff[it] = k;
       pc_.ok[it] = col < nrows;
-      pc_.base[it] = src + (long long)(r_begin + k) * ld + col;
+      if (TAPS == TAPS_ROWS && !IS_A) {
+        pc_.t[it] = (r_begin + k) % a.T;
+        pc_.base[it] = src + (long long)(r_begin + k + shift_z) * ld + col;
+      } else {
+        pc_.base[it] = src + (long long)(rb + k) * ld + col;
+      }
     }
   }
 }
@@ -124,6 +145,32 @@ __device__ __forceinline__ void issue_fast(float* __restrict__ tile, const Piece
   for (int it = 0; it < ROWS / 32; ++it) {
     const bool ok = pc_.ok[it] && pc_.koff[it] < rem;
     glds16(ok ? pc_.base[it] + koffset : fs2_zero_page, tile + (it * 256 + wave * 64) * 4);
+  }
+}
+
+// TAPS_RED, A operand: rows shifted by the K-tile's tap; a row whose shifted time index leaves [0, T) is
+// the convolution's zero padding.  offset = shift * lda + k-in-tap (floats).
+template <int ROWS>
+__device__ __forceinline__ void issue_shifted_rows(float* __restrict__ tile, const Pieces<ROWS>& pc_, long long offset,
+                                                   int shift, int T, int wave) {
+#pragma unroll
+  for (int it = 0; it < ROWS / 32; ++it) {
+    const bool ok = pc_.ok[it] && (unsigned)(pc_.t[it] + shift) < (unsigned)T;
+    glds16(ok ? pc_.base[it] + offset : fs2_zero_page, tile + (it * 256 + wave * 64) * 4);
+  }
+}
+
+// TAPS_ROWS, B operand: the reduction index is the (b, t) row itself; advances the pieces' time index by one
+// K-tile (T >= 32, so one conditional subtraction keeps it in [0, T)).
+template <int ROWS>
+__device__ __forceinline__ void issue_shifted_red(float* __restrict__ tile, Pieces<ROWS>& pc_, long long koffset, int rem,
+                                                  int shift, int T, int wave) {
+#pragma unroll
+  for (int it = 0; it < ROWS / 32; ++it) {
+    const bool ok = pc_.ok[it] && pc_.koff[it] < rem && (unsigned)(pc_.t[it] + shift) < (unsigned)T;
+    glds16(ok ? pc_.base[it] + koffset : fs2_zero_page, tile + (it * 256 + wave * 64) * 4);
+    const int t = pc_.t[it] + BK2;
+    pc_.t[it] = t >= T ? t - T : t;
   }
 }
 
@@ -217,7 +264,7 @@ __device__ __forceinline__ void frag_read(Frag<T, KC>& f, const RdAddr<ROWS, KC>
   }
 }
 
-template <int BM, int BN, bool AKC, bool BKC, int NST, bool TAPS>
+template <int BM, int BN, bool AKC, bool BKC, int NST, int TAPS>
 __global__ __launch_bounds__(256) void gemm2_kernel(GemmP p) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int A_TILE = BM * BK2, B_TILE = BN * BK2, STAGE = A_TILE + B_TILE;
@@ -250,21 +297,37 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // conv taps (TAPS): per-tile address decode; otherwise hoisted pointers
+  // loop-invariant per-piece addresses (all modes but TAPS_GENERIC, which decodes every piece in every K-tile)
   Pieces<BM> pa;
   Pieces<BN> pb;
-  if constexpr (!TAPS) {
-    setup_pieces<BM, AKC, true>(pa, p, m0, r_begin, tid);
-    setup_pieces<BN, BKC, false>(pb, p, n0, r_begin, tid);
+  if constexpr (TAPS != TAPS_GENERIC) {
+    setup_pieces<BM, AKC, true, TAPS>(pa, p, m0, r_begin, shift_z, tid);
+    setup_pieces<BN, BKC, false, TAPS>(pb, p, n0, r_begin, shift_z, tid);
   }
   const long long stepA = AKC ? BK2 : (long long)BK2 * a.lda, stepB = BKC ? BK2 : (long long)BK2 * a.ldb;
+  // TAPS_RED: (tap, offset inside the tap) of the next K-tile to issue; K-tiles are issued in order
+  int tap_i = TAPS == TAPS_RED ? r_begin / p.Rper : 0;
+  int kin_i = TAPS == TAPS_RED ? r_begin - tap_i * p.Rper : 0;
   auto issue = [&](int kt, int stage) {
     float* At = lds + stage * STAGE;
     float* Bt = At + A_TILE;
     const int r0 = r_begin + kt * BK2;
-    if constexpr (TAPS) {
+    if constexpr (TAPS == TAPS_GENERIC) {
       issue_tile<BM, AKC, true>(At, p, m0, r0, r_end, shift_z, tid, wave);
       issue_tile<BN, BKC, false>(Bt, p, n0, r0, r_end, shift_z, tid, wave);
+    } else if constexpr (TAPS == TAPS_RED) {
+      const int shift = tap_i * a.tap_mul + a.tap_add;
+      issue_shifted_rows<BM>(At, pa, (long long)shift * a.lda + kin_i, shift, a.T, wave);
+      issue_fast<BN>(Bt, pb, (long long)tap_i * a.b_tap_stride + (BKC ? (long long)kin_i : (long long)kin_i * a.ldb),
+                     BK2, wave);
+      kin_i += BK2;
+      if (kin_i == p.Rper) {
+        kin_i = 0;
+        ++tap_i;
+      }
+    } else if constexpr (TAPS == TAPS_ROWS) {
+      issue_fast<BM>(At, pa, kt * stepA, r_end - r0, wave);
+      issue_shifted_red<BN>(Bt, pb, kt * stepB, r_end - r0, shift_z, a.T, wave);
     } else {
       issue_fast<BM>(At, pa, kt * stepA, r_end - r0, wave);
       issue_fast<BN>(Bt, pb, kt * stepB, r_end - r0, wave);
@@ -320,21 +383,41 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmP p) {
   gemm_epilogue<BM, BN>(p, acc, m0, n0, wm, wn, lane, split, tapz);
 }
 
-template <int BM, int BN, int NST>
+template <int BM, int BN, int NST, bool GENERIC_TOO>
 int launch_tile(GemmP& p, int nz, hipStream_t s) {
   const Fs2GemmArgs& a = p.a;
   p.tiles_m = (a.Mc + BM - 1) / BM;
   p.tiles_n = (a.Nc + BN - 1) / BN;
   dim3 grid(p.tiles_m * p.tiles_n, 1, nz), block(256);
-  const bool taps = a.taps > 1;
-#define FS2_GO(AK, BK) \
-  (taps ? gemm2_kernel<BM, BN, AK, BK, NST, true><<<grid, block, 0, s>>>(p) \
-        : gemm2_kernel<BM, BN, AK, BK, NST, false><<<grid, block, 0, s>>>(p))
-  if (a.a_kcontig && a.b_kcontig) FS2_GO(true, true);
-  else if (a.a_kcontig && !a.b_kcontig) FS2_GO(true, false);
-  else if (!a.a_kcontig && !a.b_kcontig) FS2_GO(false, false);
-  else return FS2HIP_EINVAL;
-#undef FS2_GO
+  int mode = TAPS_NONE;
+  if (a.taps > 1) {
+    if (a.shift_operand == 0) mode = (p.Rper % BK2 == 0) ? TAPS_RED : TAPS_GENERIC;
+    else mode = a.T >= BK2 ? TAPS_ROWS : TAPS_GENERIC;
+  }
+  if (mode == TAPS_GENERIC) {
+    if constexpr (GENERIC_TOO) {
+      if (a.a_kcontig && a.b_kcontig) gemm2_kernel<BM, BN, true, true, NST, TAPS_GENERIC><<<grid, block, 0, s>>>(p);
+      else if (a.a_kcontig) gemm2_kernel<BM, BN, true, false, NST, TAPS_GENERIC><<<grid, block, 0, s>>>(p);
+      else if (!a.b_kcontig) gemm2_kernel<BM, BN, false, false, NST, TAPS_GENERIC><<<grid, block, 0, s>>>(p);
+      else return FS2HIP_EINVAL;
+    } else {
+      return FS2HIP_EINVAL;  // odd tap widths: only the 64x64 2-stage tile carries the generic decode
+    }
+  } else if (a.a_kcontig && a.b_kcontig) {  // forward: taps only as TAPS_RED
+    if (mode == TAPS_RED) gemm2_kernel<BM, BN, true, true, NST, TAPS_RED><<<grid, block, 0, s>>>(p);
+    else if (mode == TAPS_NONE) gemm2_kernel<BM, BN, true, true, NST, TAPS_NONE><<<grid, block, 0, s>>>(p);
+    else return FS2HIP_EINVAL;
+  } else if (a.a_kcontig && !a.b_kcontig) {  // backward data
+    if (mode == TAPS_RED) gemm2_kernel<BM, BN, true, false, NST, TAPS_RED><<<grid, block, 0, s>>>(p);
+    else if (mode == TAPS_NONE) gemm2_kernel<BM, BN, true, false, NST, TAPS_NONE><<<grid, block, 0, s>>>(p);
+    else return FS2HIP_EINVAL;
+  } else if (!a.a_kcontig && !a.b_kcontig) {  // weight gradient
+    if (mode == TAPS_ROWS) gemm2_kernel<BM, BN, false, false, NST, TAPS_ROWS><<<grid, block, 0, s>>>(p);
+    else if (mode == TAPS_NONE) gemm2_kernel<BM, BN, false, false, NST, TAPS_NONE><<<grid, block, 0, s>>>(p);
+    else return FS2HIP_EINVAL;
+  } else {
+    return FS2HIP_EINVAL;
+  }
   FS2_LAUNCH_CHECK();
   return 0;
 }
@@ -348,12 +431,12 @@ int fs2_gemm2_launch(GemmP& p, int tile, int nz, hipStream_t s) {
   const int chunk = (a.R + a.splitk - 1) / a.splitk;
   p.r_chunk = ((chunk + BK2 - 1) / BK2) * BK2;
   switch (tile) {
-    case 4: return launch_tile<128, 128, 3>(p, nz, s);  // 96 KiB ring, 1 workgroup / CU
-    case 5: return launch_tile<128, 64, 3>(p, nz, s);   // 72 KiB ring, 2 workgroups / CU
-    case 6: return launch_tile<64, 64, 4>(p, nz, s);    // 64 KiB ring, 2 workgroups / CU
-    case 7: return launch_tile<64, 64, 2>(p, nz, s);    // 32 KiB, 5 workgroups / CU (occupancy instead of depth)
-    case 8: return launch_tile<128, 64, 2>(p, nz, s);   // 48 KiB, 3 workgroups / CU
-    case 9: return launch_tile<128, 128, 2>(p, nz, s);  // 64 KiB, 2 workgroups / CU
+    case 4: return launch_tile<128, 128, 3, false>(p, nz, s);  // 96 KiB ring, 1 workgroup / CU
+    case 5: return launch_tile<128, 64, 3, false>(p, nz, s);   // 72 KiB ring, 2 workgroups / CU
+    case 6: return launch_tile<64, 64, 4, false>(p, nz, s);    // 64 KiB ring, 2 workgroups / CU
+    case 7: return launch_tile<64, 64, 2, true>(p, nz, s);     // 32 KiB, 5 workgroups / CU (occupancy instead of depth)
+    case 8: return launch_tile<128, 64, 2, false>(p, nz, s);   // 48 KiB, 3 workgroups / CU
+    case 9: return launch_tile<128, 128, 2, false>(p, nz, s);  // 64 KiB, 2 workgroups / CU
     default: return FS2HIP_EINVAL;
   }
 }

@@ -142,7 +142,7 @@ def test_against_oracle_on_fresh_inputs_with_default_widths():
         if p.grad is None:
             continue
         r = rel(got[k].cpu().numpy(), p.grad.numpy(), floor)
-        if float(np.abs(body(key)).max()) < floor:
+        if float(p.grad.abs().max()) < floor:
             # pure-noise tensor (true gradient exactly zero): both sides are rounding residue of a 20k-term
             # cancellation; bound it at 2e-6 of the largest gradient instead of comparing noise with noise
             assert r < 2e-2, (k, r)
