@@ -215,6 +215,12 @@ extern "C" int fs2hip_gemm(const Fs2GemmArgs* args, void* stream) {
   if (a.splitk > 1 && (a.a_kcontig || a.b_kcontig || !a.workspace)) return FS2HIP_EINVAL;
   if (a.epi == FS2_EPI_RESID && !a.resid) return FS2HIP_EINVAL;
   if (a.epi == FS2_EPI_DACT && !a.aux) return FS2HIP_EINVAL;
+  {  // the epilogue addresses its tensors with 32-bit byte offsets (gemm_common.h): each must stay below 2 GiB
+    auto fits = [&](long long ld) { return 4LL * a.Mc * ld < 0x7fffffffLL; };
+    if (!fits(a.splitk > 1 ? a.Nc : a.ldc) || (a.out_pre && !fits(a.ldpre)) ||
+        (a.epi == FS2_EPI_RESID && !fits(a.ldr)) || (a.epi == FS2_EPI_DACT && !fits(a.ldaux)))
+      return FS2HIP_EINVAL;
+  }
   p.drop = fs2_make_drop(a.drop_p, a.drop_seed, a.drop_step);
   int chunk = (a.R + a.splitk - 1) / a.splitk;
   p.r_chunk = ((chunk + BK - 1) / BK) * BK;
@@ -236,7 +242,7 @@ extern "C" int fs2hip_gemm(const Fs2GemmArgs* args, void* stream) {
   }
   if (tile >= 4) {
     if (!v2_ok) return FS2HIP_EINVAL;
-    return fs2_gemm2_launch(p, tile, nz, s);
+    return tile >= 10 ? fs2_gemm2p_launch(p, tile, nz, s) : fs2_gemm2_launch(p, tile, nz, s);
   }
   if (!v1_ok) return FS2HIP_EINVAL;
   if (tile == 3) {

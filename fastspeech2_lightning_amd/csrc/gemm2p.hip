@@ -1,0 +1,179 @@
+// Persistent variant of the direct-to-LDS GEMM core (gemm2.hip) for gfx950.
+//
+// One launch fills every workgroup slot of the chip once (grid = CUs x workgroups per CU, or the number of
+// work units if smaller); a workgroup walks the units u = blockIdx, blockIdx + grid, ... (a unit = one output
+// tile of one split-K / conv-tap slice).  The K-tiles of all its units form ONE stream through the two LDS
+// stages, so
+//   * the DMA of the next unit's first K-tile is in flight while the last K-tile of the current unit is in
+//     the MFMAs: no per-tile prologue latency;
+//   * the epilogue of a unit is executed after the barrier and DMA issue of the next unit's first K-tile: its
+//     global stores are not waited for until the following K-tile (every wait of
+//     this two-stage ring is vmcnt(0), which also covers them), i.e. they drain under one K-tile of MFMAs
+//     instead of at the end of a workgroup, where every co-resident workgroup would write at once.
+// Work-unit ids go through the XCD remap, so the units that the workgroups of one XCD process in the same
+// round are consecutive tiles (shared A rows stay in that XCD's L2).
+#include "gemm2_core.h"
+
+namespace {
+
+struct Unit {
+  int m0, n0, tapz, split, r_begin, r_end, nkt, shift_z;
+};
+
+__device__ __forceinline__ Unit decode_unit(const GemmP& p, int u, int nunits, int tiles, int BM, int BN) {
+  const Fs2GemmArgs& a = p.a;
+  const int uu = fs2_xcd_remap(u, nunits);
+  const int z = uu / tiles, t = uu - z * tiles;
+  const int tile_m = t / p.tiles_n, tile_n = t - tile_m * p.tiles_n;
+  Unit q;
+  q.m0 = tile_m * BM;
+  q.n0 = tile_n * BN;
+  q.tapz = z / a.splitk;
+  q.split = z - q.tapz * a.splitk;
+  q.r_begin = q.split * p.r_chunk;
+  q.r_end = min(a.R, q.r_begin + p.r_chunk);
+  q.nkt = q.r_end > q.r_begin ? (q.r_end - q.r_begin + BK2 - 1) / BK2 : 0;
+  q.shift_z = q.tapz * a.tap_mul + a.tap_add;
+  return q;
+}
+
+template <int BM, int BN, bool AKC, bool BKC, int TAPS>
+__global__ __launch_bounds__(256) void gemm2p_kernel(GemmP p, int nunits, int tiles) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int A_TILE = BM * BK2, B_TILE = BN * BK2, STAGE = A_TILE + B_TILE;
+  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+  const Fs2GemmArgs& a = p.a;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int G = gridDim.x;
+
+  f32x16 acc[TM][TN];
+
+  // ---- producer: the next K-tile of this workgroup's stream -------------------------------------------------
+  int u_p = blockIdx.x, nkt_p = 0;
+  Pieces<BM> pa;
+  Pieces<BN> pb;
+  Stream<AKC, BKC, TAPS> st;
+  auto enter_unit = [&]() {
+    if (u_p >= nunits) return;
+    const Unit up = decode_unit(p, u_p, nunits, tiles, BM, BN);
+    setup_pieces<BM, AKC, true, TAPS>(pa, p, up.m0, up.r_begin, tid);
+    setup_pieces<BN, BKC, false, TAPS>(pb, p, up.n0, up.r_begin, tid);
+    st.begin(p, up.r_begin, up.r_end, up.shift_z);
+    nkt_p = up.nkt;
+  };
+  auto produce = [&](int stage) {
+    if (u_p >= nunits) return;
+    float* At = lds + stage * STAGE;
+    st.template issue<BM, BN>(p, At, At + A_TILE, pa, pb, wave, tid);
+    if (st.kt == nkt_p) {
+      u_p += G;
+      enter_unit();
+    }
+  };
+
+  const int l31 = lane & 31, h = lane >> 5;
+  const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)lds;
+  RdAddr<BM, AKC> rda;
+  RdAddr<BN, BKC> rdb;
+  rda.setup(wm * (BM / 2), l31, h);
+  rdb.setup(wn * (BN / 2), l31, h);
+
+  auto clear = [&]() {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+
+  // The accumulators are touched by non-MFMA code in exactly one place, after the inner K loop (as in the
+  // one-tile-per-workgroup kernel).  [A flat loop over the stream with the epilogue under `if (kt == 0)` made
+  // the compiler carry VGPR copies of all accumulators around every iteration, and its copy of the last
+  // registers raced with the MFMA that writes them.]  Every unit has nkt >= 1 (the launcher rejects
+  // split-K chunkings with empty slices).
+  enter_unit();
+  produce(0);
+  int stage = 0;
+  wait_vmcnt_barrier<0>();  // K-tile 0 of the first unit has landed for everybody
+  produce(1);
+  for (int u_c = blockIdx.x; u_c < nunits; u_c += G) {
+    const Unit uc = decode_unit(p, u_c, nunits, tiles, BM, BN);
+    clear();
+    compute_ktile<BM, BN, AKC, BKC>(acc, rda, rdb, lds0 + stage * (STAGE * 4), lds0 + stage * (STAGE * 4) + A_TILE * 4);
+    stage ^= 1;
+    for (int kt = 1; kt < uc.nkt; ++kt) {
+      wait_vmcnt_barrier<0>();  // this K-tile has landed for everybody; the other stage is no longer read
+      produce(stage ^ 1);
+      compute_ktile<BM, BN, AKC, BKC>(acc, rda, rdb, lds0 + stage * (STAGE * 4), lds0 + stage * (STAGE * 4) + A_TILE * 4);
+      stage ^= 1;
+    }
+    if (u_c + G < nunits) {  // first K-tile of the next unit: its sync and the following DMA go ahead of the
+      wait_vmcnt_barrier<0>();  // epilogue, whose stores then drain under that K-tile's MFMAs
+      produce(stage ^ 1);
+    }
+    gemm_epilogue<BM, BN>(p, acc, uc.m0, uc.n0, wm, wn, lane, uc.split, uc.tapz);
+  }
+}
+
+template <int BM, int BN, int WG_PER_CU>
+int launch_persistent(GemmP& p, int nz, hipStream_t s) {
+  const Fs2GemmArgs& a = p.a;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return FS2HIP_EINVAL;
+    n_cu = prop.multiProcessorCount;
+  }
+  p.tiles_m = (a.Mc + BM - 1) / BM;
+  p.tiles_n = (a.Nc + BN - 1) / BN;
+  const int tiles = p.tiles_m * p.tiles_n;
+  const long long nunits_ll = (long long)tiles * nz;
+  if (nunits_ll > 0x7fffffffLL) return FS2HIP_EINVAL;
+  const int nunits = (int)nunits_ll;
+  const int slots = n_cu * WG_PER_CU;
+  dim3 grid(nunits < slots ? nunits : slots), block(256);
+  int mode = TAPS_NONE;
+  if (a.taps > 1) {
+    if (a.shift_operand == 0) mode = (p.Rper % BK2 == 0) ? TAPS_RED : TAPS_GENERIC;
+    else mode = a.T >= BK2 ? TAPS_ROWS : TAPS_GENERIC;
+  }
+  if (mode == TAPS_GENERIC) return FS2HIP_EINVAL;  // odd tap widths: gemm2.hip tile 7
+  if (a.a_kcontig && a.b_kcontig) {
+    if (mode == TAPS_RED) gemm2p_kernel<BM, BN, true, true, TAPS_RED><<<grid, block, 0, s>>>(p, nunits, tiles);
+    else if (mode == TAPS_NONE) gemm2p_kernel<BM, BN, true, true, TAPS_NONE><<<grid, block, 0, s>>>(p, nunits, tiles);
+    else return FS2HIP_EINVAL;
+  } else if (a.a_kcontig && !a.b_kcontig) {
+    if (mode == TAPS_RED) gemm2p_kernel<BM, BN, true, false, TAPS_RED><<<grid, block, 0, s>>>(p, nunits, tiles);
+    else if (mode == TAPS_NONE) gemm2p_kernel<BM, BN, true, false, TAPS_NONE><<<grid, block, 0, s>>>(p, nunits, tiles);
+    else return FS2HIP_EINVAL;
+  } else if (!a.a_kcontig && !a.b_kcontig) {
+    if (mode == TAPS_ROWS) gemm2p_kernel<BM, BN, false, false, TAPS_ROWS><<<grid, block, 0, s>>>(p, nunits, tiles);
+    else if (mode == TAPS_NONE) gemm2p_kernel<BM, BN, false, false, TAPS_NONE><<<grid, block, 0, s>>>(p, nunits, tiles);
+    else return FS2HIP_EINVAL;
+  } else {
+    return FS2HIP_EINVAL;
+  }
+  FS2_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+// tile ids 10-12: persistent 64x64 (5 workgroups / CU), 128x64 (3), 128x128 (2)
+int fs2_gemm2p_launch(GemmP& p, int tile, int nz, hipStream_t s) {
+  const Fs2GemmArgs& a = p.a;
+  const int chunk = (a.R + a.splitk - 1) / a.splitk;
+  p.r_chunk = ((chunk + BK2 - 1) / BK2) * BK2;
+  if ((long long)(a.splitk - 1) * p.r_chunk >= a.R) return FS2HIP_EINVAL;  // an empty split-K slice
+  if (!fs2_gemm2_offsets_fit(a)) return FS2HIP_EINVAL;
+  switch (tile) {
+    case 10: return launch_persistent<64, 64, 4>(p, nz, s);  // 128 VGPRs: 4 waves per SIMD
+    case 11: return launch_persistent<128, 64, 3>(p, nz, s);
+    case 12: return launch_persistent<128, 128, 2>(p, nz, s);
+    default: return FS2HIP_EINVAL;
+  }
+}

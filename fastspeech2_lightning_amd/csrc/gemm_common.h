@@ -14,43 +14,60 @@ struct GemmP {
 // accumulator tile -> global memory with the fused epilogue (bias, activation, residual, dropout, act')
 // C/D layout of v_mfma_f32_32x32x2_f32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5):
 // one store instruction writes two full 128-byte row segments.
+//
 // EPI is a compile-time copy of a.epi (-1 = split-K slab: raw partial sums into the workspace), so that each
 // variant is one straight run of stores -- the epilogue is executed once per tile, from a cold
 // instruction cache, and must not be a chain of per-element branches.
+//
+// Addressing: every tensor the epilogue touches goes through a raw buffer resource with ONE per-lane byte
+// offset (the lane's column in the tile's first row) and a scalar byte offset per accumulator row, so the
+// 16 addresses of an accumulator cost one VGPR instead of 32, and rows past Mc / columns past Nc are dropped by
+// the buffer range check (num_records = Mc * ld * 4; a lane outside Nc carries the out-of-range offset)
+// instead of 16 predicates.  Extents are < 2 GiB (checked by fs2hip_gemm).
+constexpr int FS2_EPI_OOB = (int)0x80000000;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t fs2_epi_rsrc(const float* base, int rows, int ld) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, rows * ld * 4, 0x00020000);
+}
+__device__ __forceinline__ float fs2_buf_load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void fs2_buf_store(__amdgpu_buffer_rsrc_t r, int voff, int soff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+
 template <int BM, int BN, int EPI>
 __device__ __forceinline__ void gemm_epilogue_impl(const GemmP& p, const f32x16 (&acc)[BM / 64][BN / 64], float* C,
                                                    int ldc, int m0, int n0, int wm, int wn, int lane) {
   constexpr int TM = BM / 64, TN = BN / 64;
   const Fs2GemmArgs& a = p.a;
   const Fs2Drop drop = fs2_resolve_drop(p.drop);
-  const int mrow = m0 + wm * (BM / 2) + 4 * (lane >> 5);
+  const int mrow = m0 + wm * (BM / 2) + 4 * (lane >> 5);  // the lane's row of accumulator register 0, block i = 0
+  const __amdgpu_buffer_rsrc_t rc = fs2_epi_rsrc(C, a.Mc, ldc);
+#define FS2_ROWOFF(i, r) ((i) * 32 + ((r) & 3) + 8 * ((r) >> 2))  // compile-time row inside the wave tile
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
-    if (n >= a.Nc) continue;
-    const float bias = (EPI >= 0 && a.bias) ? a.bias[n] : 0.f;
+    const bool col = n < a.Nc;
+    const float bias = (EPI >= 0 && a.bias && col) ? a.bias[n] : 0.f;
+    const int vc = col ? (mrow * ldc + n) * 4 : FS2_EPI_OOB;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       // one 32x32 accumulator (16 values per lane) at a time; every run-time choice (activation kind,
       // dropout on/off, optional pre-activation output) is tested once per accumulator, not per element
-      const int mb = mrow + i * 32;
       float v[16];
-      bool in[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        v[r] = acc[i][j][r];
-        in[r] = mb + (r & 3) + 8 * (r >> 2) < a.Mc;
-      }
-#define FS2_ROW(r) ((long long)(mb + ((r) & 3) + 8 * ((r) >> 2)))
+      for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r];
       if (EPI >= 0) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = a.alpha * v[r] + bias;
       }
       if (EPI == FS2_EPI_ACT) {
         if (a.out_pre) {
+          const __amdgpu_buffer_rsrc_t rp = fs2_epi_rsrc(a.out_pre, a.Mc, a.ldpre);
+          const int vp = col ? (mrow * a.ldpre + n) * 4 : FS2_EPI_OOB;
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            if (in[r]) a.out_pre[FS2_ROW(r) * a.ldpre + n] = v[r];
+          for (int r = 0; r < 16; ++r) fs2_buf_store(rp, vp, FS2_ROWOFF(i, r) * a.ldpre * 4, v[r]);
         }
         if (a.act == FS2_ACT_RELU) {
 #pragma unroll
@@ -63,9 +80,11 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmP& p, const f32x16 
           for (int r = 0; r < 16; ++r) v[r] = fs2_act(FS2_ACT_TANH, v[r]);
         }
       } else if (EPI == FS2_EPI_DACT) {
+        const __amdgpu_buffer_rsrc_t rx = fs2_epi_rsrc(a.aux, a.Mc, a.ldaux);
+        const int vx = col ? (mrow * a.ldaux + n) * 4 : FS2_EPI_OOB;
         float x[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = in[r] ? a.aux[FS2_ROW(r) * a.ldaux + n] : 0.f;
+        for (int r = 0; r < 16; ++r) x[r] = fs2_buf_load(rx, vx, FS2_ROWOFF(i, r) * a.ldaux * 4);  // 0 outside
         if (a.act == FS2_ACT_RELU) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) v[r] *= fs2_dact(FS2_ACT_RELU, x[r]);
@@ -77,23 +96,25 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmP& p, const f32x16 
           for (int r = 0; r < 16; ++r) v[r] *= fs2_dact(FS2_ACT_TANH, x[r]);
         }
       }
-      if (EPI > 0 && drop.on) {
+      if (EPI > 0 && drop.on) {  // element index m * ldc + n, as everywhere else this mask is used
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] *= fs2_drop_factor(drop, (unsigned long long)(FS2_ROW(r) * ldc + n));
+        for (int r = 0; r < 16; ++r)
+          v[r] *= fs2_drop_factor(drop, (unsigned long long)((unsigned)(vc + FS2_ROWOFF(i, r) * ldc * 4) >> 2));
       }
       if (EPI == FS2_EPI_RESID) {
+        const __amdgpu_buffer_rsrc_t rx = fs2_epi_rsrc(a.resid, a.Mc, a.ldr);
+        const int vx = col ? (mrow * a.ldr + n) * 4 : FS2_EPI_OOB;
         float x[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = in[r] ? a.resid[FS2_ROW(r) * a.ldr + n] : 0.f;
+        for (int r = 0; r < 16; ++r) x[r] = fs2_buf_load(rx, vx, FS2_ROWOFF(i, r) * a.ldr * 4);
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = x[r] + a.res_scale * v[r];
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (in[r]) C[FS2_ROW(r) * ldc + n] = v[r];
-#undef FS2_ROW
+      for (int r = 0; r < 16; ++r) fs2_buf_store(rc, vc, FS2_ROWOFF(i, r) * ldc * 4, v[r]);
     }
   }
+#undef FS2_ROWOFF
 }
 
 template <int BM, int BN>
@@ -125,3 +146,5 @@ __device__ __forceinline__ int fs2_xcd_remap(int orig, int nwg) {
 // v2 core launcher (gemm2.hip); tile: 4 = 128x128 (3-stage ring), 5 = 128x64 (3), 6 = 64x64 (4),
 // 7 = 64x64 (2), 8 = 128x64 (2), 9 = 128x128 (2)
 int fs2_gemm2_launch(GemmP& p, int tile, int nz, hipStream_t s);
+// persistent v2 core (gemm2p.hip); tile: 10 = 64x64, 11 = 128x64, 12 = 128x128 (all 2-stage)
+int fs2_gemm2p_launch(GemmP& p, int tile, int nz, hipStream_t s);

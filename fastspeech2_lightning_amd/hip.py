@@ -206,7 +206,8 @@ GEMM_PROFILE = None
 #: a few launches with HIP events) the first time it is launched outside a graph capture; the launch
 #: is idempotent (outputs are only overwritten), so re-running it for timing is safe.
 GEMM_TUNE = True
-GEMM_TILES = (1, 2, 3, 4, 5, 6, 7, 8, 9)  # 1-3: register-staged BK=16 core; 4-9: direct-to-LDS BK=32 core
+GEMM_TILES = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12)  # 1-3: register-staged BK=16 core; 4-9: direct-to-LDS BK=32 core;
+#                                                      10-12: persistent direct-to-LDS core
 _TILE_CACHE = {}
 
 
