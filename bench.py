@@ -239,7 +239,7 @@ def main():
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": round(sum(q[6] for q in prof) / len(prof)),
-                    "kernel": "gemm_kernel / gemm2_kernel family (fp32 v_mfma_f32_32x32x2_f32), tile autotuned per shape",
+                    "kernel": "gemm2_kernel / gemm2p_kernel / gemm_kernel family (fp32 v_mfma_f32_32x32x2_f32), tile autotuned per shape",
                     "launches_per_step": len(prof),
                     "avg_launch_us": round(ms * 1e3 / len(prof), 2), "flops_per_launch": round(flops / len(prof)),
                     "gemm_ms_per_step": round(ms, 3)}

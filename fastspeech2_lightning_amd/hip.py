@@ -226,13 +226,15 @@ def _tune_tile(a) -> int:
         if rc == -22:
             continue
         _ok(rc, "gemm")
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(3):
-            _ok(L.fs2hip_gemm(C.byref(a), s), "gemm")
-        e1.record()
-        e1.synchronize()
-        ms = e0.elapsed_time(e1)
+        ms = float("inf")
+        for _ in range(2):  # best of two rounds of four launches: single rounds are noisy at 10-100 us per launch
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(4):
+                _ok(L.fs2hip_gemm(C.byref(a), s), "gemm")
+            e1.record()
+            e1.synchronize()
+            ms = min(ms, e0.elapsed_time(e1))
         if ms < best_ms:
             best, best_ms = tile, ms
     _TILE_CACHE[key] = best
