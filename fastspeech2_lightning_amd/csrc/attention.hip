@@ -32,20 +32,36 @@ struct AttnP {
   Fs2Drop drop;
 };
 
-// stage 64 rows x HD columns (starting at column `col`) of the [*, ld] matrix into LDS [64][HD+4]
+// One 64-row x HD tile (columns from `col`) of the [*, ld] matrix: global -> registers (`fetch_rows`, issued one
+// tile ahead so that the loads are in flight under the MFMAs of the current tile) and registers -> LDS
+// [64][HD+4] (`commit_rows`, between the two barriers of an iteration).
 template <int HD>
-__device__ __forceinline__ void stage_rows(float* __restrict__ dst, const float* __restrict__ src, int ld, int col,
-                                           int row0, int nrows, int tid) {
+struct RowRegs {
+  float4 v[(64 * (HD / 4) + 255) / 256];
+};
+template <int HD>
+__device__ __forceinline__ void fetch_rows(RowRegs<HD>& regs, const float* __restrict__ src, int ld, int col, int row0,
+                                           int nrows, int tid) {
+  constexpr int F4 = HD / 4;
+#pragma unroll
+  for (int it = 0; it < (64 * F4 + 255) / 256; ++it) {
+    int idx = tid + it * 256;
+    int r = idx / F4, c4 = idx % F4;
+    int row = row0 + r;
+    regs.v[it] = (idx < 64 * F4 && row < nrows)
+                     ? *reinterpret_cast<const float4*>(src + (long long)row * ld + col + c4 * 4)
+                     : make_float4(0, 0, 0, 0);
+  }
+}
+template <int HD>
+__device__ __forceinline__ void commit_rows(float* __restrict__ dst, const RowRegs<HD>& regs, int tid) {
   constexpr int LDT = HD + 4, F4 = HD / 4;
 #pragma unroll
   for (int it = 0; it < (64 * F4 + 255) / 256; ++it) {
     int idx = tid + it * 256;
     if (idx < 64 * F4) {
       int r = idx / F4, c4 = idx % F4;
-      int row = row0 + r;
-      float4 v = row < nrows ? *reinterpret_cast<const float4*>(src + (long long)row * ld + col + c4 * 4)
-                             : make_float4(0, 0, 0, 0);
-      *reinterpret_cast<float4*>(dst + r * LDT + c4 * 4) = v;
+      *reinterpret_cast<float4*>(dst + r * LDT + c4 * 4) = regs.v[it];
     }
   }
 }
@@ -90,11 +106,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p, float* __restric
   float m = -INFINITY, l = 0.f;
   const int kend = min(T, len);
   const unsigned long long rowidx = ((unsigned long long)(b * p.H + h) * T + q) * T;
+  RowRegs<HD> kreg, vreg;
+  fetch_rows<HD>(kreg, base, ld, D + h * HD, 0, T, tid);
+  fetch_rows<HD>(vreg, base, ld, 2 * D + h * HD, 0, T, tid);
   for (int key0 = 0; key0 < kend; key0 += 64) {
     __syncthreads();
-    stage_rows<HD>(Ks, base, ld, D + h * HD, key0, T, tid);
-    stage_rows<HD>(Vs, base, ld, 2 * D + h * HD, key0, T, tid);
+    commit_rows<HD>(Ks, kreg, tid);
+    commit_rows<HD>(Vs, vreg, tid);
     __syncthreads();
+    if (key0 + 64 < kend) {  // next tile's loads fly under this tile's MFMAs
+      fetch_rows<HD>(kreg, base, ld, D + h * HD, key0 + 64, T, tid);
+      fetch_rows<HD>(vreg, base, ld, 2 * D + h * HD, key0 + 64, T, tid);
+    }
     f32x4 s[4];
     float mx = -INFINITY;
 #pragma unroll
@@ -194,11 +217,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p, const float* 
   for (int j = 0; j < NJ; ++j) dq[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int kend = min(T, len);
   const unsigned long long rowidx = ((unsigned long long)(b * p.H + h) * T + q) * T;
+  RowRegs<HD> kreg, vreg;
+  fetch_rows<HD>(kreg, base, ld, D + h * HD, 0, T, tid);
+  fetch_rows<HD>(vreg, base, ld, 2 * D + h * HD, 0, T, tid);
   for (int key0 = 0; key0 < kend; key0 += 64) {
     __syncthreads();
-    stage_rows<HD>(Ks, base, ld, D + h * HD, key0, T, tid);
-    stage_rows<HD>(Vs, base, ld, 2 * D + h * HD, key0, T, tid);
+    commit_rows<HD>(Ks, kreg, tid);
+    commit_rows<HD>(Vs, vreg, tid);
     __syncthreads();
+    if (key0 + 64 < kend) {
+      fetch_rows<HD>(kreg, base, ld, D + h * HD, key0 + 64, T, tid);
+      fetch_rows<HD>(vreg, base, ld, 2 * D + h * HD, key0 + 64, T, tid);
+    }
     f32x4 ds[4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
@@ -273,16 +303,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p, const float*
   }
   const bool key_ok = key < len;
   const unsigned long long headidx = (unsigned long long)(b * p.H + h) * T;
+  RowRegs<HD> qreg, oreg;
+  fetch_rows<HD>(qreg, base, ld, h * HD, 0, T, tid);
+  fetch_rows<HD>(oreg, dout + (long long)b * T * D, D, h * HD, 0, T, tid);
   for (int q0 = 0; q0 < T; q0 += 64) {
     __syncthreads();
-    stage_rows<HD>(Qs, base, ld, h * HD, q0, T, tid);
-    stage_rows<HD>(Os, dout + (long long)b * T * D, D, h * HD, q0, T, tid);
+    commit_rows<HD>(Qs, qreg, tid);
+    commit_rows<HD>(Os, oreg, tid);
     if (tid < 64) {
       int qq = q0 + tid;
       lse_s[tid] = qq < T ? lse[((long long)b * p.H + h) * T + qq] : INFINITY;
       delta_s[tid] = qq < T ? delta[((long long)b * p.H + h) * T + qq] : 0.f;
     }
     __syncthreads();
+    if (q0 + 64 < T) {
+      fetch_rows<HD>(qreg, base, ld, h * HD, q0 + 64, T, tid);
+      fetch_rows<HD>(oreg, dout + (long long)b * T * D, D, h * HD, q0 + 64, T, tid);
+    }
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
       f32x4 s = dot_tile<HD>(Qs, kr, qt, c, g);
