@@ -167,5 +167,6 @@ extern "C" int fs2hip_layernorm_bwd(const float* dy, const float* x, const float
   }
   FS2_LAUNCH_CHECK();
   // partial is [nblk][2][C]: columns [0, C) -> dgamma, [C, 2C) -> dbeta
+  if (!dgamma && !dbeta) return 0;  // the caller finishes the partial sums with fs2hip_reduce_rows_multi
   return fs2_reduce_rows(partial, nblk, 2 * C, 2LL * C, dgamma, C, dbeta, s);
 }

@@ -49,6 +49,7 @@ SIGNATURES = {
     "fs2hip_version": "",
     "fs2hip_gemm": None,  # (const Fs2GemmArgs*, stream)
     "fs2hip_reduce_slabs": "ppqiqp",
+    "fs2hip_reduce_rows_multi": None,  # (const Fs2ReduceJob*, int, void*): set below
     "fs2hip_colsum_rows": "i",
     "fs2hip_colsum": "piiippp",
     "fs2hip_layernorm_fwd": "ppppppiifp",
@@ -121,6 +122,7 @@ def lib():
             if sig is not None:
                 fn.argtypes = [_T[c] for c in sig]
         L.fs2hip_gemm.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
+        L.fs2hip_reduce_rows_multi.argtypes = [C.POINTER(ReduceJob), C.c_int, C.c_void_p]
         _lib = L
     return _lib
 
@@ -372,6 +374,50 @@ def colsum(x, out):
     return out
 
 
+# ---- deferred second stage of parameter-gradient reductions ----------------------------------------------------
+#: bias and LayerNorm parameter gradients are only read by the optimizer / the data-parallel bucket exchange, so
+#: their partial sums are kept (each in its own buffer) and finished FS2_REDUCE_MAX_JOBS at a time by one launch:
+#: ``flush_grad_reductions()`` -- called by ``FastSpeech2.backward`` before every bucket hand-off and at its end.
+REDUCE_MAX_JOBS = 48
+_PENDING_REDUCTIONS = []  # (partial tensor, rows, n, stride, out0, n0, out1)
+
+
+class ReduceJob(C.Structure):  # mirrors Fs2ReduceJob (include/fs2hip.h)
+    _fields_ = [("src", C.c_void_p), ("out0", C.c_void_p), ("out1", C.c_void_p), ("stride", C.c_longlong),
+                ("rows", C.c_int), ("n", C.c_int), ("n0", C.c_int), ("pad_", C.c_int)]
+
+
+def _defer_reduction(partial, rows, n, stride, out0, n0, out1):
+    _PENDING_REDUCTIONS.append((partial, rows, n, stride, out0, n0, out1))
+    if len(_PENDING_REDUCTIONS) >= REDUCE_MAX_JOBS:
+        flush_grad_reductions()
+
+
+def flush_grad_reductions():
+    if not _PENDING_REDUCTIONS:
+        return
+    jobs = (ReduceJob * len(_PENDING_REDUCTIONS))()
+    for j, (partial, rows, n, stride, out0, n0, out1) in zip(jobs, _PENDING_REDUCTIONS):
+        j.src, j.out0, j.out1 = _p(partial), _p(out0), (_p(out1) if out1 is not None else None)
+        j.stride, j.rows, j.n, j.n0 = stride, rows, n, n0
+    _ok(lib().fs2hip_reduce_rows_multi(jobs, len(_PENDING_REDUCTIONS), _stream()), "reduce_rows_multi")
+    _PENDING_REDUCTIONS.clear()  # the partial buffers may be reused from here on (stream order)
+
+
+def colsum_grad(x, out):
+    """``colsum`` for a parameter gradient: first stage now, second stage at the next ``flush_grad_reductions()``."""
+    _chk(x, name="x"); _chk(out, name="out")
+    M, N = _rows(x), x.shape[-1]
+    _req(out.numel() == N, "colsum: bad output size")
+    gy = lib().fs2hip_colsum_rows(M)
+    if gy == 1:  # nothing to batch: one partial row
+        return colsum(x, out)
+    part = torch.empty(gy * N, device=x.device, dtype=torch.float32)
+    _ok(lib().fs2hip_colsum(_p(x), N, M, N, _p(part), None, _stream()), "colsum")
+    _defer_reduction(part, gy, N, N, out, N, None)
+    return out
+
+
 # ------------------------------------------------------------------------------------------
 # LayerNorm
 # ------------------------------------------------------------------------------------------
@@ -387,8 +433,8 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dx_add=None):
-    """Returns dx (+ dx_add); writes dgamma/dbeta."""
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dx_add=None, defer=False):
+    """Returns dx (+ dx_add); writes dgamma/dbeta (``defer``: at the next ``flush_grad_reductions()``)."""
     for n, t in (("dy", dy), ("x", x), ("gamma", gamma), ("mean", mean), ("rstd", rstd), ("dgamma", dgamma),
                  ("dbeta", dbeta)):
         _chk(t, name=n)
@@ -400,6 +446,12 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dx_add=None):
         _req(dx_add.shape == x.shape, "layernorm_bwd: dx_add shape")
     dx = torch.empty_like(x)
     nblk = lib().fs2hip_layernorm_bwd_blocks(M)
+    if defer and nblk > 1:
+        part = torch.empty(nblk * 2 * Cc, device=x.device, dtype=torch.float32)
+        _ok(lib().fs2hip_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx_add), _p(dx), _p(part),
+                                       None, None, M, Cc, _stream()), "layernorm_bwd")
+        _defer_reduction(part, nblk, 2 * Cc, 2 * Cc, dgamma, Cc, dbeta)
+        return dx
     ws = _workspace(nblk * 2 * Cc, x.device)
     _ok(lib().fs2hip_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx_add), _p(dx), _p(ws),
                                    _p(dgamma), _p(dbeta), M, Cc, _stream()), "layernorm_bwd")

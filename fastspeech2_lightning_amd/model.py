@@ -420,12 +420,14 @@ class FastSpeech2(_Base):
             d_out = H.axpby(d_out, d_post)
             d_out = H.axpby(d_out, self.postnet.bwd(d_post, c["post"]))
         H.linear_bwd_weight(d_out, c["dec_out"], S.g("mel_linear.weight"))
-        H.colsum(d_out, S.g("mel_linear.bias"))
+        H.colsum_grad(d_out, S.g("mel_linear.bias"))
         d = H.linear_bwd_data(d_out, S.p("mel_linear.weight"))
         if sync:
+            H.flush_grad_reductions()  # deferred bias / LayerNorm gradient sums of this bucket
             sync.bucket_ready(3)
         d = self.decoder.bwd(d, c["dec"])
         if sync:
+            H.flush_grad_reductions()
             sync.bucket_ready(2)
         d, d_text = self.variance_adaptor.bwd(d, g, c["va"])
         if c.get("gst") is not None:
@@ -435,11 +437,13 @@ class FastSpeech2(_Base):
         if m.multilingual:
             self._rowvec_embedding_bwd("language_embedding.weight", c["batch"]["language_id"], d)
         if sync:
+            H.flush_grad_reductions()
             sync.bucket_ready(1)
         d = self.encoder.bwd(d, c["enc"])
         if d_text is not None:  # the aligner's keys are the raw text embedding (fs2/variance_adaptor.py:254)
             d = H.axpby(d, d_text)
         H.embedding_bwd(c["text"].reshape(-1), d, S.g("text_input_layer.weight"), self.padding_idx)
+        H.flush_grad_reductions()
         if sync:
             sync.bucket_ready(0)
         self._ctx = self._loss_grads = None

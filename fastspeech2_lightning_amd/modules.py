@@ -73,7 +73,7 @@ class LayerNorm:
 
     def bwd(self, dy, saved, dx_add=None):
         x, mean, rstd = saved
-        return H.layernorm_bwd(dy, x, self.S.p(self.w), mean, rstd, self.S.g(self.w), self.S.g(self.b), dx_add)
+        return H.layernorm_bwd(dy, x, self.S.p(self.w), mean, rstd, self.S.g(self.w), self.S.g(self.b), dx_add, defer=True)
 
 
 class BatchNorm:
@@ -129,10 +129,10 @@ class FeedForward:
         S, env = self.S, self.env
         dz = H.axpby(dy, None, 0.5, 0.0, env.drop(self.p, self.s2))
         H.linear_bwd_weight(dz, c.a, S.g(self.w2))
-        H.colsum(dz, S.g(self.b2))
+        H.colsum_grad(dz, S.g(self.b2))
         du = H.linear_bwd_data(dz, S.p(self.w2), epi=H.EPI_DACT, act="silu", aux=c.u, drop=env.drop(self.p, self.s1))
         H.linear_bwd_weight(du, c.h, S.g(self.w1))
-        H.colsum(du, S.g(self.b1))
+        H.colsum_grad(du, S.g(self.b1))
         dh = H.linear_bwd_data(du, S.p(self.w1))
         return self.ln.bwd(dh, c.ln, dx_add=dy)
 
@@ -166,11 +166,11 @@ class SelfAttention:
         d_o = env.drop(self.p, self.so)
         dz = H.axpby(dy, None, 1.0, 0.0, d_o) if d_o.p > 0 else dy
         H.linear_bwd_weight(dz, c.o, S.g(self.wo))
-        H.colsum(dz, S.g(self.bo))
+        H.colsum_grad(dz, S.g(self.bo))
         do = H.linear_bwd_data(dz, S.p(self.wo))
         dqkv = H.attention_bwd(c.qkv, c.lens, c.o, do, c.lse, B, T, self.heads, env.drop(self.p, self.sa))
         H.linear_bwd_weight(dqkv, c.h, S.g(self.wi))
-        H.colsum(dqkv, S.g(self.bi))
+        H.colsum_grad(dqkv, S.g(self.bi))
         dh = H.linear_bwd_data(dqkv, S.p(self.wi))
         return self.ln.bwd(dh, c.ln, dx_add=dy)
 
@@ -212,13 +212,13 @@ class ConvModule:
         d_o = env.drop(self.p, self.site)
         dz = H.axpby(dy, None, 1.0, 0.0, d_o) if d_o.p > 0 else dy
         H.linear_bwd_weight(dz, c.s, S.g(self.w2))
-        H.colsum(dz, S.g(self.b2))
+        H.colsum_grad(dz, S.g(self.b2))
         ds = H.linear_bwd_data(dz, S.p(self.w2))
         gg, gb = self.bn.grads()
         dc = H.bn_act_bwd(ds, c.c, c.stats, gg, gb, "silu", training=env.training)
         dg2 = H.dwconv_bwd(dc, c.g2, S.p(self.wd), S.g(self.wd), S.g(self.bd), B, T, glu=True)
         H.linear_bwd_weight(dg2, c.h, S.g(self.w1))
-        H.colsum(dg2, S.g(self.b1))
+        H.colsum_grad(dg2, S.g(self.b1))
         dh = H.linear_bwd_data(dg2, S.p(self.w1))
         return self.ln.bwd(dh, c.ln, dx_add=dy)
 
@@ -327,12 +327,12 @@ class VariancePredictor:
             d = H.dact_mul(d, r, "relu")
             if self.depthwise:
                 H.linear_bwd_weight(d, c, S.g(L["wp"]))
-                H.colsum(d, S.g(L["bp"]))
+                H.colsum_grad(d, S.g(L["bp"]))
                 dc = H.linear_bwd_data(d, S.p(L["wp"]))
                 d = H.dwconv_bwd(dc, x, S.p(L["wd"]), S.g(L["wd"]), S.g(L["bd"]), B, T)
             else:
                 H.linear_bwd_weight(d, x, S.g(L["wc"]), taps=self.k, T=T)
-                H.colsum(d, S.g(L["bc"]))
+                H.colsum_grad(d, S.g(L["bc"]))
                 d = H.linear_bwd_data(d, S.p(L["wc"]), taps=self.k, T=T)
         return d
 
@@ -393,19 +393,19 @@ class Aligner:
         g = lambda key: (S.g(self.names[key][0]), S.g(self.names[key][1]))  # noqa: E731
         # query branch (the mel input needs no gradient)
         gw, gb = g("q4")
-        H.linear_bwd_weight(dq, c.q2, gw); H.colsum(dq, gb)
+        H.linear_bwd_weight(dq, c.q2, gw); H.colsum_grad(dq, gb)
         d = H.linear_bwd_data(dq, self._w("q4")[0], epi=H.EPI_DACT, act="relu", aux=c.q2)
         gw, gb = g("q2")
-        H.linear_bwd_weight(d, c.q1, gw); H.colsum(d, gb)
+        H.linear_bwd_weight(d, c.q1, gw); H.colsum_grad(d, gb)
         d = H.linear_bwd_data(d, self._w("q2")[0], epi=H.EPI_DACT, act="relu", aux=c.q1)
         gw, gb = g("q0")
-        H.linear_bwd_weight(d, c.mel, gw, taps=3, T=Tm); H.colsum(d, gb)
+        H.linear_bwd_weight(d, c.mel, gw, taps=3, T=Tm); H.colsum_grad(d, gb)
         # key branch
         gw, gb = g("k2")
-        H.linear_bwd_weight(dk, c.k1, gw); H.colsum(dk, gb)
+        H.linear_bwd_weight(dk, c.k1, gw); H.colsum_grad(dk, gb)
         d = H.linear_bwd_data(dk, self._w("k2")[0], epi=H.EPI_DACT, act="relu", aux=c.k1)
         gw, gb = g("k0")
-        H.linear_bwd_weight(d, c.text_emb, gw, taps=3, T=Ts); H.colsum(d, gb)
+        H.linear_bwd_weight(d, c.text_emb, gw, taps=3, T=Ts); H.colsum_grad(d, gb)
         return H.linear_bwd_data(d, self._w("k0")[0], taps=3, T=Ts)
 
 
@@ -485,7 +485,7 @@ class StyleEncoder:
         B, Hh, Ww, C = c.shape
         g = lambda name: (S.g(self.lin[name][0]), S.g(self.lin[name][1]))  # noqa: E731
         gw, gb = g("out")
-        H.linear_bwd_weight(d_style, c.ctx, gw); H.colsum(d_style, gb)
+        H.linear_bwd_weight(d_style, c.ctx, gw); H.colsum_grad(d_style, gb)
         dctx = H.linear_bwd_data(d_style, self._lw("out")[0])
         dq, dkp, dvp = H.gst_attn_bwd(dctx, c.q, c.k, c.v, c.p, self.HEADS)
         NT, Fd = c.k.shape
@@ -494,14 +494,14 @@ class StyleEncoder:
         H.colsum(dkp.view(B, NT * Fd), dk.view(-1))
         H.colsum(dvp.view(B, NT * Fd), dv.view(-1))
         gw, gb = g("k")
-        H.linear_bwd_weight(dk, c.tk, gw); H.colsum(dk, gb)
+        H.linear_bwd_weight(dk, c.tk, gw); H.colsum_grad(dk, gb)
         dtk = H.linear_bwd_data(dk, self._lw("k")[0])
         gw, gb = g("v")
-        H.linear_bwd_weight(dv, c.tk, gw); H.colsum(dv, gb)
+        H.linear_bwd_weight(dv, c.tk, gw); H.colsum_grad(dv, gb)
         dtk = H.axpby(dtk, H.linear_bwd_data(dv, self._lw("v")[0]))
         H.axpby(H.dact_mul(dtk, S.p(self.embs), "tanh"), None, 1.0, 0.0, out=S.g(self.embs))
         gw, gb = g("q")
-        H.linear_bwd_weight(dq, c.hs[Hh], gw); H.colsum(dq, gb)
+        H.linear_bwd_weight(dq, c.hs[Hh], gw); H.colsum_grad(dq, gb)
         dh = H.linear_bwd_data(dq, self._lw("q")[0])
         # GRU backward through time
         dgi = torch.empty(B * Hh, 3 * U, device=dh.device, dtype=torch.float32)
@@ -510,9 +510,9 @@ class StyleEncoder:
             _, dhprev = H.gru_gate_bwd(dh, c.gates[t], c.hs[t], dgi.view(-1)[t * 3 * U:], Hh * 3 * U, U, dgh=dgh_all[t])
             dh = H.axpby(dhprev, H.linear_bwd_data(dgh_all[t], S.p(self.whh)))
         H.linear_bwd_weight(dgh_all.view(Hh * B, 3 * U), c.hs[:Hh].reshape(Hh * B, U), S.g(self.whh))
-        H.colsum(dgh_all.view(Hh * B, 3 * U), S.g(self.bhh))
+        H.colsum_grad(dgh_all.view(Hh * B, 3 * U), S.g(self.bhh))
         H.linear_bwd_weight(dgi, c.feat, S.g(self.wih))
-        H.colsum(dgi, S.g(self.bih))
+        H.colsum_grad(dgi, S.g(self.bih))
         d = H.linear_bwd_data(dgi, S.p(self.wih)).view(B, Hh, Ww, C)
         for i in range(len(self.convs) - 1, -1, -1):
             w, bn, ch = self.convs[i]
@@ -565,7 +565,7 @@ class PostNet:
             act = "tanh" if i < self.n - 1 else None
             draw = H.bn_act_bwd(dy, raw, stats, gg, gb, act, env.drop(self.dropout_p, site), training=env.training)
             H.linear_bwd_weight(draw, x, S.g(w), taps=self.k, T=T)
-            H.colsum(draw, S.g(b))
+            H.colsum_grad(draw, S.g(b))
             if i > 0 or need_dx:
                 dy = H.linear_bwd_data(draw, S.p(w), taps=self.k, T=T)
         return dy

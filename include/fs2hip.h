@@ -96,6 +96,20 @@ typedef struct {
 
 int fs2hip_gemm(const Fs2GemmArgs* args, void* stream);
 
+/* Several row reductions in one launch: out0[c] (c < n0) / out1[c - n0] = sum over `rows` rows of src[r * stride + c],
+ * c < n.  Finishes the partial sums of fs2hip_colsum (out == NULL) and fs2hip_layernorm_bwd (dgamma == dbeta == NULL),
+ * i.e. the bias and LayerNorm parameter gradients (torch autograd's sum-to-size in the reference), whose only
+ * consumer is the optimizer: the host batches them.  njobs <= FS2_REDUCE_MAX_JOBS. */
+#define FS2_REDUCE_MAX_JOBS 48
+typedef struct {
+  const float* src;
+  float* out0;
+  float* out1;
+  long long stride;
+  int rows, n, n0, pad_;
+} Fs2ReduceJob;
+int fs2hip_reduce_rows_multi(const Fs2ReduceJob* jobs, int njobs, void* stream);
+
 /* out[i] = sum_s slabs[s*slab_stride + i], i < n  (split-K / partial-sum finish) */
 int fs2hip_reduce_slabs(const float* slabs, float* out, long long n, int nslabs,
                         long long slab_stride, void* stream);
