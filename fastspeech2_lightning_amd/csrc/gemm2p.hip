@@ -18,27 +18,57 @@ namespace {
 
 struct Unit {
   int m0, n0, tapz, split, r_begin, r_end, nkt, shift_z;
+  int slice;  // >= 0: a reduction slice of a tail tile (raw partial sums into the workspace slab `slice`)
 };
 
-__device__ __forceinline__ Unit decode_unit(const GemmP& p, int u, int nunits, int tiles, int BM, int BN) {
+// Split tail (tiles 13/14): with T tiles on G workgroup slots the last T mod G tiles would occupy a fraction of
+// the chip for a whole tile time.  The tiles of the last M-tile rows are therefore cut into S reduction slices
+// each (S * tail tiles <= G): units [0, u_full) are whole tiles, the rest are slices, which write raw partial sums
+// that fs2_tail_fixup adds up (+ bias).  S == 0: no split.
+struct Hybrid {
+  int u_full, S, chunk, m_tail0;
+  float* ws;
+  long long slab;
+};
+
+__device__ __forceinline__ Unit decode_unit(const GemmP& p, const Hybrid& hy, int u, int nunits, int tiles, int BM,
+                                            int BN) {
   const Fs2GemmArgs& a = p.a;
-  const int uu = fs2_xcd_remap(u, nunits);
-  const int z = uu / tiles, t = uu - z * tiles;
-  const int tile_m = t / p.tiles_n, tile_n = t - tile_m * p.tiles_n;
   Unit q;
+  int t;
+  if (hy.S == 0) {
+    const int uu = fs2_xcd_remap(u, nunits);
+    const int z = uu / tiles;
+    t = uu - z * tiles;
+    q.tapz = z / a.splitk;
+    q.split = z - q.tapz * a.splitk;
+    q.r_begin = q.split * p.r_chunk;
+    q.r_end = min(a.R, q.r_begin + p.r_chunk);
+    q.slice = -1;
+  } else if (u < hy.u_full) {  // whole tiles and slices are remapped separately: every XCD gets the same mix
+    t = fs2_xcd_remap(u, hy.u_full);
+    q.tapz = q.split = 0;
+    q.r_begin = 0;
+    q.r_end = a.R;
+    q.slice = -1;
+  } else {
+    const int v = fs2_xcd_remap(u - hy.u_full, nunits - hy.u_full);
+    t = hy.u_full + v / hy.S;
+    q.slice = v - (v / hy.S) * hy.S;
+    q.tapz = q.split = 0;
+    q.r_begin = q.slice * hy.chunk;
+    q.r_end = min(a.R, q.r_begin + hy.chunk);
+  }
+  const int tile_m = t / p.tiles_n, tile_n = t - tile_m * p.tiles_n;
   q.m0 = tile_m * BM;
   q.n0 = tile_n * BN;
-  q.tapz = z / a.splitk;
-  q.split = z - q.tapz * a.splitk;
-  q.r_begin = q.split * p.r_chunk;
-  q.r_end = min(a.R, q.r_begin + p.r_chunk);
   q.nkt = q.r_end > q.r_begin ? (q.r_end - q.r_begin + BK2 - 1) / BK2 : 0;
   q.shift_z = q.tapz * a.tap_mul + a.tap_add;
   return q;
 }
 
 template <int BM, int BN, bool AKC, bool BKC, int TAPS>
-__global__ __launch_bounds__(256) void gemm2p_kernel(GemmP p, int nunits, int tiles) {
+__global__ __launch_bounds__(256) void gemm2p_kernel(GemmP p, Hybrid hy, int nunits, int tiles) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int A_TILE = BM * BK2, B_TILE = BN * BK2, STAGE = A_TILE + B_TILE;
   __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
@@ -57,7 +87,7 @@ __global__ __launch_bounds__(256) void gemm2p_kernel(GemmP p, int nunits, int ti
   Stream<AKC, BKC, TAPS> st;
   auto enter_unit = [&]() {
     if (u_p >= nunits) return;
-    const Unit up = decode_unit(p, u_p, nunits, tiles, BM, BN);
+    const Unit up = decode_unit(p, hy, u_p, nunits, tiles, BM, BN);
     setup_pieces<BM, AKC, true, TAPS>(pa, p, up.m0, up.r_begin, tid);
     setup_pieces<BN, BKC, false, TAPS>(pb, p, up.n0, up.r_begin, tid);
     st.begin(p, up.r_begin, up.r_end, up.shift_z);
@@ -100,7 +130,7 @@ __global__ __launch_bounds__(256) void gemm2p_kernel(GemmP p, int nunits, int ti
   wait_vmcnt_barrier<0>();  // K-tile 0 of the first unit has landed for everybody
   produce(1);
   for (int u_c = blockIdx.x; u_c < nunits; u_c += G) {
-    const Unit uc = decode_unit(p, u_c, nunits, tiles, BM, BN);
+    const Unit uc = decode_unit(p, hy, u_c, nunits, tiles, BM, BN);
     clear();
     compute_ktile<BM, BN, AKC, BKC>(acc, rda, rdb, lds0 + stage * (STAGE * 4), lds0 + stage * (STAGE * 4) + A_TILE * 4);
     stage ^= 1;
@@ -114,11 +144,15 @@ __global__ __launch_bounds__(256) void gemm2p_kernel(GemmP p, int nunits, int ti
       wait_vmcnt_barrier<0>();  // epilogue, whose stores then drain under that K-tile's MFMAs
       produce(stage ^ 1);
     }
-    gemm_epilogue<BM, BN>(p, acc, uc.m0, uc.n0, wm, wn, lane, uc.split, uc.tapz);
+    if (uc.slice >= 0)  // raw partial sums; the slab is addressed with the tile's absolute row numbers
+      gemm_epilogue_impl<BM, BN, -1>(p, acc, hy.ws + uc.slice * hy.slab - (long long)hy.m_tail0 * a.Nc, a.Nc, uc.m0, uc.n0,
+                                     wm, wn, lane);
+    else
+      gemm_epilogue<BM, BN>(p, acc, uc.m0, uc.n0, wm, wn, lane, uc.split, uc.tapz);
   }
 }
 
-template <int BM, int BN, int WG_PER_CU>
+template <int BM, int BN, int WG_PER_CU, bool SPLIT_TAIL>
 int launch_persistent(GemmP& p, int nz, hipStream_t s) {
   const Fs2GemmArgs& a = p.a;
   static int n_cu = 0;
@@ -133,8 +167,33 @@ int launch_persistent(GemmP& p, int nz, hipStream_t s) {
   const int tiles = p.tiles_m * p.tiles_n;
   const long long nunits_ll = (long long)tiles * nz;
   if (nunits_ll > 0x7fffffffLL) return FS2HIP_EINVAL;
-  const int nunits = (int)nunits_ll;
+  int nunits = (int)nunits_ll;
   const int slots = n_cu * WG_PER_CU;
+  Hybrid hy{0, 0, 0, 0, nullptr, 0};
+  if (SPLIT_TAIL) {
+    // only where a separate pass can finish the tiles: plain store (+ bias), one reduction range, 16-byte rows
+    if (nz != 1 || a.splitk != 1 || a.epi != FS2_EPI_STORE || a.out_pre || (a.Nc % 4) || (a.ldc % 4) || !a.workspace ||
+        ((uintptr_t)a.C % 16) || (a.bias && ((uintptr_t)a.bias % 16)))
+      return FS2HIP_EINVAL;
+    const int rem = tiles % slots;
+    if (rem == 0 || rem * 5 >= slots * 4) return FS2HIP_EINVAL;  // no tail worth cutting: tiles 11/12 do this shape
+    const int tail_mt = (rem + p.tiles_n - 1) / p.tiles_n;         // whole M-tile rows
+    const int tail_tiles = tail_mt * p.tiles_n;
+    if (tail_tiles > tiles) return FS2HIP_EINVAL;
+    const int nkt = (a.R + BK2 - 1) / BK2;
+    int S = slots / tail_tiles;
+    if (S > nkt / 4) S = nkt / 4;  // at least 4 K-tiles per slice
+    if (S < 2) return FS2HIP_EINVAL;
+    hy.S = S;
+    hy.chunk = ((nkt + S - 1) / S) * BK2;
+    if ((long long)(S - 1) * hy.chunk >= a.R) return FS2HIP_EINVAL;
+    hy.u_full = tiles - tail_tiles;
+    hy.m_tail0 = (p.tiles_m - tail_mt) * BM;
+    hy.slab = (long long)(a.Mc - hy.m_tail0) * a.Nc;
+    hy.ws = a.workspace;
+    if (hy.slab * S > a.workspace_floats || (hy.slab % 4) || ((uintptr_t)a.workspace % 16)) return FS2HIP_EINVAL;
+    nunits = hy.u_full + tail_tiles * S;
+  }
   dim3 grid(nunits < slots ? nunits : slots), block(256);
   int mode = TAPS_NONE;
   if (a.taps > 1) {
@@ -143,27 +202,28 @@ int launch_persistent(GemmP& p, int nz, hipStream_t s) {
   }
   if (mode == TAPS_GENERIC) return FS2HIP_EINVAL;  // odd tap widths: gemm2.hip tile 7
   if (a.a_kcontig && a.b_kcontig) {
-    if (mode == TAPS_RED) gemm2p_kernel<BM, BN, true, true, TAPS_RED><<<grid, block, 0, s>>>(p, nunits, tiles);
-    else if (mode == TAPS_NONE) gemm2p_kernel<BM, BN, true, true, TAPS_NONE><<<grid, block, 0, s>>>(p, nunits, tiles);
+    if (mode == TAPS_RED) gemm2p_kernel<BM, BN, true, true, TAPS_RED><<<grid, block, 0, s>>>(p, hy, nunits, tiles);
+    else if (mode == TAPS_NONE) gemm2p_kernel<BM, BN, true, true, TAPS_NONE><<<grid, block, 0, s>>>(p, hy, nunits, tiles);
     else return FS2HIP_EINVAL;
   } else if (a.a_kcontig && !a.b_kcontig) {
-    if (mode == TAPS_RED) gemm2p_kernel<BM, BN, true, false, TAPS_RED><<<grid, block, 0, s>>>(p, nunits, tiles);
-    else if (mode == TAPS_NONE) gemm2p_kernel<BM, BN, true, false, TAPS_NONE><<<grid, block, 0, s>>>(p, nunits, tiles);
+    if (mode == TAPS_RED) gemm2p_kernel<BM, BN, true, false, TAPS_RED><<<grid, block, 0, s>>>(p, hy, nunits, tiles);
+    else if (mode == TAPS_NONE) gemm2p_kernel<BM, BN, true, false, TAPS_NONE><<<grid, block, 0, s>>>(p, hy, nunits, tiles);
     else return FS2HIP_EINVAL;
   } else if (!a.a_kcontig && !a.b_kcontig) {
-    if (mode == TAPS_ROWS) gemm2p_kernel<BM, BN, false, false, TAPS_ROWS><<<grid, block, 0, s>>>(p, nunits, tiles);
-    else if (mode == TAPS_NONE) gemm2p_kernel<BM, BN, false, false, TAPS_NONE><<<grid, block, 0, s>>>(p, nunits, tiles);
+    if (mode == TAPS_ROWS) gemm2p_kernel<BM, BN, false, false, TAPS_ROWS><<<grid, block, 0, s>>>(p, hy, nunits, tiles);
+    else if (mode == TAPS_NONE) gemm2p_kernel<BM, BN, false, false, TAPS_NONE><<<grid, block, 0, s>>>(p, hy, nunits, tiles);
     else return FS2HIP_EINVAL;
   } else {
     return FS2HIP_EINVAL;
   }
   FS2_LAUNCH_CHECK();
+  if (hy.S) return fs2_tail_fixup(hy.ws, hy.S, hy.slab, a.C, a.ldc, a.bias, a.alpha, hy.m_tail0, a.Mc, a.Nc, s);
   return 0;
 }
 
 }  // namespace
 
-// tile ids 10-12: persistent 64x64 (5 workgroups / CU), 128x64 (3), 128x128 (2)
+// tile ids 10-12: persistent 64x64 (4 workgroups / CU), 128x64 (3), 128x128 (2); 13/14: 128x128 / 128x64 + split tail
 int fs2_gemm2p_launch(GemmP& p, int tile, int nz, hipStream_t s) {
   const Fs2GemmArgs& a = p.a;
   const int chunk = (a.R + a.splitk - 1) / a.splitk;
@@ -171,9 +231,11 @@ int fs2_gemm2p_launch(GemmP& p, int tile, int nz, hipStream_t s) {
   if ((long long)(a.splitk - 1) * p.r_chunk >= a.R) return FS2HIP_EINVAL;  // an empty split-K slice
   if (!fs2_gemm2_offsets_fit(a)) return FS2HIP_EINVAL;
   switch (tile) {
-    case 10: return launch_persistent<64, 64, 4>(p, nz, s);  // 128 VGPRs: 4 waves per SIMD
-    case 11: return launch_persistent<128, 64, 3>(p, nz, s);
-    case 12: return launch_persistent<128, 128, 2>(p, nz, s);
+    case 10: return launch_persistent<64, 64, 4, false>(p, nz, s);  // 128 VGPRs: 4 waves per SIMD
+    case 11: return launch_persistent<128, 64, 3, false>(p, nz, s);
+    case 12: return launch_persistent<128, 128, 2, false>(p, nz, s);
+    case 13: return launch_persistent<128, 128, 2, true>(p, nz, s);
+    case 14: return launch_persistent<128, 64, 3, true>(p, nz, s);
     default: return FS2HIP_EINVAL;
   }
 }

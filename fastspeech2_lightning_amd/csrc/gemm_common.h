@@ -146,5 +146,9 @@ __device__ __forceinline__ int fs2_xcd_remap(int orig, int nwg) {
 // v2 core launcher (gemm2.hip); tile: 4 = 128x128 (3-stage ring), 5 = 128x64 (3), 6 = 64x64 (4),
 // 7 = 64x64 (2), 8 = 128x64 (2), 9 = 128x128 (2)
 int fs2_gemm2_launch(GemmP& p, int tile, int nz, hipStream_t s);
-// persistent v2 core (gemm2p.hip); tile: 10 = 64x64, 11 = 128x64, 12 = 128x128 (all 2-stage)
+// persistent v2 core (gemm2p.hip); tile: 10 = 64x64, 11 = 128x64, 12 = 128x128 (all 2-stage); 13 / 14 = 128x128 /
+// 128x64 with the last partial round of tiles cut along the reduction
 int fs2_gemm2p_launch(GemmP& p, int tile, int nz, hipStream_t s);
+// finishes the reduction-split tail tiles of a persistent launch (reduce.hip)
+int fs2_tail_fixup(const float* ws, int S, long long slab, float* C, int ldc, const float* bias, float alpha, int m0,
+                   int Mc, int Nc, hipStream_t s);

@@ -158,7 +158,42 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __re
   }
 }
 
+// C[m][n] = alpha * sum_s slab_s[m - m0][n] + bias[n] for the rows [m0, Mc) whose tiles a persistent GEMM cut
+// along the reduction (gemm2p.hip, tiles 13/14)
+__global__ __launch_bounds__(256) void tail_fixup_kernel(const float* __restrict__ ws, int S, long long slab,
+                                                         float* __restrict__ C, int ldc, const float* __restrict__ bias,
+                                                         float alpha, int m0, int Mc, int Nc) {
+  const int n4 = Nc >> 2;
+  const long long total = (long long)(Mc - m0) * n4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int r = (int)(i / n4), c4 = (int)(i - (long long)r * n4);
+    const float* src = ws + (long long)r * Nc + c4 * 4;
+    float4 acc = *reinterpret_cast<const float4*>(src);
+    for (int k = 1; k < S; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(src + k * slab);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    float4 b = make_float4(0, 0, 0, 0);
+    if (bias) b = *reinterpret_cast<const float4*>(bias + c4 * 4);
+    float* dst = C + (long long)(m0 + r) * ldc + c4 * 4;
+    *reinterpret_cast<float4*>(dst) =
+        make_float4(alpha * acc.x + b.x, alpha * acc.y + b.y, alpha * acc.z + b.z, alpha * acc.w + b.w);
+  }
+}
+
 }  // namespace
+
+// internal (declared in gemm_common.h)
+int fs2_tail_fixup(const float* ws, int S, long long slab, float* C, int ldc, const float* bias, float alpha, int m0,
+                   int Mc, int Nc, hipStream_t s) {
+  const long long total = (long long)(Mc - m0) * (Nc >> 2);
+  if (total <= 0) return 0;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  tail_fixup_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(ws, S, slab, C, ldc, bias, alpha, m0, Mc, Nc);
+  FS2_LAUNCH_CHECK();
+  return 0;
+}
 
 // internal (declared in common.h): out0[c] for c < n0, out1[c - n0] otherwise
 int fs2_reduce_rows(const float* src, int rows, int n, long long stride, float* out0, int n0, float* out1,

@@ -38,7 +38,7 @@ class GemmArgs(C.Structure):
         ("aux", C.c_void_p), ("ldaux", C.c_int),
         ("out_pre", C.c_void_p), ("ldpre", C.c_int),
         ("drop_p", C.c_float), ("drop_seed", C.c_ulonglong), ("drop_step", C.c_void_p),
-        ("splitk", C.c_int), ("workspace", C.c_void_p), ("tile", C.c_int),
+        ("splitk", C.c_int), ("workspace", C.c_void_p), ("tile", C.c_int), ("workspace_floats", C.c_longlong),
     ]
 
 
@@ -182,6 +182,10 @@ NO_DROP = Drop()
 _WS = {}
 
 
+#: 512 workgroup slots x 128 x 128 partial sums
+HYBRID_WS_FLOATS = 512 * 128 * 128
+
+
 def reserve_workspace(n: int, device) -> torch.Tensor:
     """Pre-size the scratch buffer (do this before capturing a hipGraph)."""
     key = str(device)
@@ -208,8 +212,8 @@ GEMM_PROFILE = None
 #: a few launches with HIP events) the first time it is launched outside a graph capture; the launch
 #: is idempotent (outputs are only overwritten), so re-running it for timing is safe.
 GEMM_TUNE = True
-GEMM_TILES = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12)  # 1-3: register-staged BK=16 core; 4-9: direct-to-LDS BK=32 core;
-#                                                      10-12: persistent direct-to-LDS core
+GEMM_TILES = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14)  # 1-3: register-staged BK=16 core; 4-9: direct-to-LDS BK=32 core;
+#                                                      10-12: persistent direct-to-LDS core; 13-14: + split tail
 _TILE_CACHE = {}
 
 
@@ -248,6 +252,9 @@ def _gemm(_algorithmic=True, **kw):
     a.taps, a.alpha, a.res_scale, a.splitk = 1, 1.0, 1.0, 1
     for k, v in kw.items():
         setattr(a, k, v)
+    if not a.workspace:  # scratch for the split-tail tiles (13/14): at most one slab of partial sums per workgroup slot
+        ws = _workspace(HYBRID_WS_FLOATS, torch.device("cuda", torch.cuda.current_device()))
+        a.workspace, a.workspace_floats = _p(ws), ws.numel()
     a.tile = _tune_tile(a)
     if GEMM_PROFILE is None or not _algorithmic:  # (the one-hot embedding GEMM's flops are not algorithmic)
         _ok(lib().fs2hip_gemm(C.byref(a), _stream()), "gemm")
@@ -356,6 +363,7 @@ def linear_bwd_weight(dy, x, out, *, taps=1, T=0, n_valid=None):
         n = taps * N * K
         ws = _workspace(S * n, dy.device)
         kw["workspace"] = _p(ws)
+        kw["workspace_floats"] = ws.numel()
         _gemm(_algorithmic=n_valid is None, **kw)
         _ok(lib().fs2hip_reduce_slabs(_p(ws), _p(out), n, S, n, _stream()), "reduce_slabs")
     else:

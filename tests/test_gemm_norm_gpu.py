@@ -77,6 +77,39 @@ def test_conv_taps_fwd_bwd(H, taps, Cin, Cout):
     close(dw, w.grad.permute(2, 0, 1), B * T, "conv bwd weight")
 
 
+@pytest.mark.parametrize("tile", [13, 14, 12, 11, 10])
+def test_persistent_and_split_tail_tiles_at_full_size(H, tile):
+    """Benchmark-size shapes (more tiles than workgroup slots, with a partial last round): the persistent cores and
+    the variants that cut the tail tiles along the reduction (finished by the fix-up pass), forced one at a time.
+    Forward GEMM with bias, backward-data GEMM, and a 5-tap convolution whose tail slices start inside a tap."""
+    saved = H.GEMM_TILES, dict(H._TILE_CACHE)
+    try:
+        H.GEMM_TILES = (tile,)
+        H._TILE_CACHE.clear()
+        M, N, K = 20736 + 40, 512, 256  # ragged last M-tile as well
+        x, w, b = rnd(M, K, seed=1).cuda(), rnd(N, K, seed=2, scale=K ** -0.5).cuda(), rnd(N, seed=3).cuda()
+        y = H.linear_fwd(x, w, b)
+        close(y, (x.double() @ w.double().t() + b.double()).float(), K, f"tile {tile} fwd")
+        w4, b4 = rnd(1024, K, seed=8, scale=K ** -0.5).cuda(), rnd(1024, seed=9).cuda()  # 128x64 tiles: 304-tile tail
+        y4 = H.linear_fwd(x, w4, b4)
+        close(y4, (x.double() @ w4.double().t() + b4.double()).float(), K, f"tile {tile} fwd N=1024")
+        dy, w2 = rnd(M, N, seed=4).cuda(), rnd(N, 512, seed=7, scale=N ** -0.5).cuda()
+        dx = H.linear_bwd_data(dy, w2)
+        close(dx, (dy.double() @ w2.double()).float(), N, f"tile {tile} bwd data")
+        B, T, Cin, Cout, taps = 32, 648, 64, 512, 5
+        xc = rnd(B, T, Cin, seed=5).cuda()
+        wc = rnd(Cout, Cin, taps, seed=6, scale=(Cin * taps) ** -0.5).cuda()
+        ref = F.conv1d(xc.transpose(1, 2).double(), wc.double(), b.double(), padding=2).transpose(1, 2).float()
+        yc = H.linear_fwd(xc, wc.permute(2, 0, 1).contiguous(), b, taps=taps, T=T)
+        close(yc, ref, Cin * taps, f"tile {tile} conv fwd")
+        # the forced tile really ran (0 = the tile does not take that shape and the built-in heuristic chose)
+        assert set(H._TILE_CACHE.values()) <= {tile, 0} and tile in H._TILE_CACHE.values(), H._TILE_CACHE
+    finally:
+        H.GEMM_TILES = saved[0]
+        H._TILE_CACHE.clear()
+        H._TILE_CACHE.update(saved[1])
+
+
 @pytest.mark.parametrize("M,N,K", [(4100, 256, 1024), (333, 1024, 256), (20000, 80, 256)])
 def test_linear_bwd(H, M, N, K):
     x, w, dy = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(M, N, seed=3)
