@@ -107,7 +107,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
-    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step from a hipGraph (single stream: the side stream for weight-gradient work is "
+                         "switched off, graph branches run slower than two eager streams)")
+    ap.add_argument("--no-graph", action="store_true", help="(default, kept for old command lines) launch eagerly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--learn-alignment", action="store_true",
@@ -173,7 +176,8 @@ def main():
         torch.cuda.synchronize()
         log(f"warm-up step {i}: {(time.perf_counter() - t_w) * 1e3:.1f} ms")
 
-    use_graph = not args.no_graph and world == 1
+    use_graph = args.graph and not args.no_graph and world == 1
+    model.env.side_enabled = not use_graph
     graph = None
     if use_graph:
         graph = torch.cuda.CUDAGraph()
@@ -208,7 +212,10 @@ def main():
     if not args.no_roofline:
         # live measurement of the dominant kernel: HIP events around every GEMM launch of an eager step.
         # Every rank runs the steps (they contain the collectives); rank 0 records.  A GPU-side spin first,
-        # so that the host runs ahead and the events bracket device time only, as in the replayed graph.
+        # so that the host runs ahead and the events bracket device time only.  The side stream is switched off
+        # for these two steps: with two streams a GEMM shares the chip with another kernel and its own launch
+        # duration says nothing about the kernel.
+        side_was, model.env.side_enabled = model.env.side_enabled, False
         rec = rank == 0
         H.GEMM_PROFILE = [] if rec else None
         step()
@@ -218,6 +225,7 @@ def main():
         step()
         torch.cuda.synchronize()
         prof, H.GEMM_PROFILE = H.GEMM_PROFILE, None
+        model.env.side_enabled = side_was
     if roofline is None and not args.no_roofline and rank == 0:
         if os.environ.get("FS2_BENCH_GEMM_BREAKDOWN"):
             by = {}
@@ -261,7 +269,7 @@ def main():
                                    "(96-128 phonemes, 80 x ~600 mel), learn_alignment=" + str(args.learn_alignment) + ", dropout on",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "real_frames_per_step": frames_all, "padded_frames_per_step": padded_all,
-                       "parallelism": f"dp{world}", "hipgraph": bool(graph is not None),
+                       "parallelism": f"dp{world}", "hipgraph": bool(graph is not None), "streams": 2 if model.env.side_enabled else 1,
                        "parameters": model.store.num_trainable},
             "per_gpu_value": round(frames_all * args.steps / elapsed / world, 1),
             "padded_frames_per_s": round(padded_all * args.steps / elapsed, 1),

@@ -188,7 +188,7 @@ HYBRID_WS_FLOATS = 512 * 128 * 128
 
 def reserve_workspace(n: int, device) -> torch.Tensor:
     """Pre-size the scratch buffer (do this before capturing a hipGraph)."""
-    key = str(device)
+    key = (str(device), torch.cuda.current_stream().cuda_stream)  # one scratch buffer per stream
     ws = _WS.get(key)
     if ws is None or ws.numel() < n:
         ws = torch.empty(max(n, 1 << 22), device=device, dtype=torch.float32)
@@ -396,20 +396,20 @@ class ReduceJob(C.Structure):  # mirrors Fs2ReduceJob (include/fs2hip.h)
 
 
 def _defer_reduction(partial, rows, n, stride, out0, n0, out1):
+    # never flushed from here: the caller may be on the side stream (modules.Env.side) while other partial sums
+    # were produced on the main one; flush_grad_reductions() is called on the main stream after the join
     _PENDING_REDUCTIONS.append((partial, rows, n, stride, out0, n0, out1))
-    if len(_PENDING_REDUCTIONS) >= REDUCE_MAX_JOBS:
-        flush_grad_reductions()
 
 
 def flush_grad_reductions():
-    if not _PENDING_REDUCTIONS:
-        return
-    jobs = (ReduceJob * len(_PENDING_REDUCTIONS))()
-    for j, (partial, rows, n, stride, out0, n0, out1) in zip(jobs, _PENDING_REDUCTIONS):
-        j.src, j.out0, j.out1 = _p(partial), _p(out0), (_p(out1) if out1 is not None else None)
-        j.stride, j.rows, j.n, j.n0 = stride, rows, n, n0
-    _ok(lib().fs2hip_reduce_rows_multi(jobs, len(_PENDING_REDUCTIONS), _stream()), "reduce_rows_multi")
-    _PENDING_REDUCTIONS.clear()  # the partial buffers may be reused from here on (stream order)
+    while _PENDING_REDUCTIONS:
+        batch = _PENDING_REDUCTIONS[:REDUCE_MAX_JOBS]
+        jobs = (ReduceJob * len(batch))()
+        for j, (partial, rows, n, stride, out0, n0, out1) in zip(jobs, batch):
+            j.src, j.out0, j.out1 = _p(partial), _p(out0), (_p(out1) if out1 is not None else None)
+            j.stride, j.rows, j.n, j.n0 = stride, rows, n, n0
+        _ok(lib().fs2hip_reduce_rows_multi(jobs, len(batch), _stream()), "reduce_rows_multi")
+        del _PENDING_REDUCTIONS[:len(batch)]  # the partial buffers may be reused from here on (stream order)
 
 
 def colsum_grad(x, out):

@@ -423,10 +423,12 @@ class FastSpeech2(_Base):
         H.colsum_grad(d_out, S.g("mel_linear.bias"))
         d = H.linear_bwd_data(d_out, S.p("mel_linear.weight"))
         if sync:
+            self.env.join()            # weight-gradient work on the side stream
             H.flush_grad_reductions()  # deferred bias / LayerNorm gradient sums of this bucket
             sync.bucket_ready(3)
         d = self.decoder.bwd(d, c["dec"])
         if sync:
+            self.env.join()
             H.flush_grad_reductions()
             sync.bucket_ready(2)
         d, d_text = self.variance_adaptor.bwd(d, g, c["va"])
@@ -437,12 +439,14 @@ class FastSpeech2(_Base):
         if m.multilingual:
             self._rowvec_embedding_bwd("language_embedding.weight", c["batch"]["language_id"], d)
         if sync:
+            self.env.join()
             H.flush_grad_reductions()
             sync.bucket_ready(1)
         d = self.encoder.bwd(d, c["enc"])
         if d_text is not None:  # the aligner's keys are the raw text embedding (fs2/variance_adaptor.py:254)
             d = H.axpby(d, d_text)
         H.embedding_bwd(c["text"].reshape(-1), d, S.g("text_input_layer.weight"), self.padding_idx)
+        self.env.join()
         H.flush_grad_reductions()
         if sync:
             sync.bucket_ready(0)

@@ -48,6 +48,56 @@ class Env:
             return H.NO_DROP
         return H.Drop(p, (self.seed * 0x9E3779B1 + site * 0x632BE59BD9B4E019) & 0xFFFFFFFFFFFFFFFF, self.step_state)
 
+    # ---- second HIP stream for parameter-gradient work ---------------------------------------------------------
+    # In the backward pass a layer's weight-gradient GEMM (+ split-K finish + bias column sums) depends only on
+    # tensors that already exist, and nothing reads its result before the optimizer / the bucket exchange.  It is
+    # therefore enqueued on a side stream: its workgroups fill the CUs that the main chain (dX GEMM -> LayerNorm
+    # backward -> ...) leaves idle in the partial last round of a GEMM and under its small kernels.  ``join()``
+    # (bucket boundaries, end of backward) makes the main stream wait for it.  Tensors the side stream reads are
+    # kept alive until the join, so the caching allocator cannot hand their memory to the main stream early.
+    side_enabled = True
+
+    def side(self, *tensors):
+        """Context manager: run the enclosed launches on the side stream, after everything enqueued so far."""
+        return _SideSection(self, tensors)
+
+    def join(self):
+        st = getattr(self, "_side_stream", None)
+        if st is None or not getattr(self, "_side_dirty", False):
+            return
+        ev = torch.cuda.Event()
+        ev.record(st)
+        torch.cuda.current_stream().wait_event(ev)
+        self._side_dirty = False
+        self._side_held = []
+
+
+class _SideSection:
+    def __init__(self, env: Env, tensors):
+        self.env, self.tensors = env, tensors
+        self.ctx = None
+
+    def __enter__(self):
+        env = self.env
+        if not env.side_enabled:
+            return self
+        if getattr(env, "_side_stream", None) is None:
+            env._side_stream = torch.cuda.Stream()
+            env._side_held = []
+        ev = torch.cuda.Event()
+        ev.record()
+        env._side_stream.wait_event(ev)
+        env._side_held.extend(self.tensors)
+        env._side_dirty = True
+        self.ctx = torch.cuda.stream(env._side_stream)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
 
 # ------------------------------------------------------------------------------------------------
 # declaration helpers (reference key names)
@@ -128,11 +178,13 @@ class FeedForward:
     def bwd(self, dy, c):
         S, env = self.S, self.env
         dz = H.axpby(dy, None, 0.5, 0.0, env.drop(self.p, self.s2))
-        H.linear_bwd_weight(dz, c.a, S.g(self.w2))
-        H.colsum_grad(dz, S.g(self.b2))
+        with env.side(dz, c.a):
+            H.linear_bwd_weight(dz, c.a, S.g(self.w2))
+            H.colsum_grad(dz, S.g(self.b2))
         du = H.linear_bwd_data(dz, S.p(self.w2), epi=H.EPI_DACT, act="silu", aux=c.u, drop=env.drop(self.p, self.s1))
-        H.linear_bwd_weight(du, c.h, S.g(self.w1))
-        H.colsum_grad(du, S.g(self.b1))
+        with env.side(du, c.h):
+            H.linear_bwd_weight(du, c.h, S.g(self.w1))
+            H.colsum_grad(du, S.g(self.b1))
         dh = H.linear_bwd_data(du, S.p(self.w1))
         return self.ln.bwd(dh, c.ln, dx_add=dy)
 
@@ -165,12 +217,14 @@ class SelfAttention:
         B, T, _ = dy.shape
         d_o = env.drop(self.p, self.so)
         dz = H.axpby(dy, None, 1.0, 0.0, d_o) if d_o.p > 0 else dy
-        H.linear_bwd_weight(dz, c.o, S.g(self.wo))
-        H.colsum_grad(dz, S.g(self.bo))
+        with env.side(dz, c.o):
+            H.linear_bwd_weight(dz, c.o, S.g(self.wo))
+            H.colsum_grad(dz, S.g(self.bo))
         do = H.linear_bwd_data(dz, S.p(self.wo))
         dqkv = H.attention_bwd(c.qkv, c.lens, c.o, do, c.lse, B, T, self.heads, env.drop(self.p, self.sa))
-        H.linear_bwd_weight(dqkv, c.h, S.g(self.wi))
-        H.colsum_grad(dqkv, S.g(self.bi))
+        with env.side(dqkv, c.h):
+            H.linear_bwd_weight(dqkv, c.h, S.g(self.wi))
+            H.colsum_grad(dqkv, S.g(self.bi))
         dh = H.linear_bwd_data(dqkv, S.p(self.wi))
         return self.ln.bwd(dh, c.ln, dx_add=dy)
 
@@ -211,14 +265,16 @@ class ConvModule:
         B, T, _ = dy.shape
         d_o = env.drop(self.p, self.site)
         dz = H.axpby(dy, None, 1.0, 0.0, d_o) if d_o.p > 0 else dy
-        H.linear_bwd_weight(dz, c.s, S.g(self.w2))
-        H.colsum_grad(dz, S.g(self.b2))
+        with env.side(dz, c.s):
+            H.linear_bwd_weight(dz, c.s, S.g(self.w2))
+            H.colsum_grad(dz, S.g(self.b2))
         ds = H.linear_bwd_data(dz, S.p(self.w2))
         gg, gb = self.bn.grads()
         dc = H.bn_act_bwd(ds, c.c, c.stats, gg, gb, "silu", training=env.training)
         dg2 = H.dwconv_bwd(dc, c.g2, S.p(self.wd), S.g(self.wd), S.g(self.bd), B, T, glu=True)
-        H.linear_bwd_weight(dg2, c.h, S.g(self.w1))
-        H.colsum_grad(dg2, S.g(self.b1))
+        with env.side(dg2, c.h):
+            H.linear_bwd_weight(dg2, c.h, S.g(self.w1))
+            H.colsum_grad(dg2, S.g(self.b1))
         dh = H.linear_bwd_data(dg2, S.p(self.w1))
         return self.ln.bwd(dh, c.ln, dx_add=dy)
 
@@ -564,8 +620,9 @@ class PostNet:
             gg, gb = bn.grads()
             act = "tanh" if i < self.n - 1 else None
             draw = H.bn_act_bwd(dy, raw, stats, gg, gb, act, env.drop(self.dropout_p, site), training=env.training)
-            H.linear_bwd_weight(draw, x, S.g(w), taps=self.k, T=T)
-            H.colsum_grad(draw, S.g(b))
+            with env.side(draw, x):
+                H.linear_bwd_weight(draw, x, S.g(w), taps=self.k, T=T)
+                H.colsum_grad(draw, S.g(b))
             if i > 0 or need_dx:
                 dy = H.linear_bwd_data(draw, S.p(w), taps=self.k, T=T)
         return dy
