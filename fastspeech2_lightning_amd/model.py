@@ -59,7 +59,11 @@ class VarianceAdaptor:
     def _variance(self, name, x, target, lens, control, inference):
         S, pre = self.S, self.pre
         predictor = getattr(self, f"{name}_predictor")
-        pred, pctx = predictor.fwd(x, lens)
+        if inference:
+            pred, pctx = predictor.fwd(x, lens)
+        else:  # training: the prediction feeds only the loss (the embedding uses the target) -> side stream
+            with self.env.side(x, lens):
+                pred, pctx = predictor.fwd(x, lens)
         if inference:
             out, idx = H.bucket_embed_add(pred, S.b(pre + f"{name}_bins"), S.p(pre + f"{name}_embedding.weight"), x, control)
             if control != 1.0:
@@ -99,7 +103,11 @@ class VarianceAdaptor:
             energy_p, x, c["energy"] = self._variance("energy", x, energy_t, src_lens, control.energy, inference)
         if cfg.pitch.level.value == "phone":
             pitch_p, x, c["pitch"] = self._variance("pitch", x, pitch_t, src_lens, control.pitch, inference)
-        logd, c["duration"] = self.duration_predictor.fwd(x, src_lens)
+        if dur_aligned is not None or teacher_forcing or not inference:
+            with self.env.side(x, src_lens):  # durations come from the batch / the aligner: prediction feeds the loss only
+                logd, c["duration"] = self.duration_predictor.fwd(x, src_lens)
+        else:
+            logd, c["duration"] = self.duration_predictor.fwd(x, src_lens)
         if dur_aligned is not None:
             dur = dur_aligned
         elif teacher_forcing or not inference:
@@ -123,15 +131,41 @@ class VarianceAdaptor:
                     duration_rounded=dur, pitch_prediction=pitch_p, pitch_target=pitch_t, energy_prediction=energy_p,
                     energy_target=energy_t, tgt_lens=tgt_lens, Tm=Tm, **attn), c
 
+    def bwd_predictors_early(self, dpred, c):
+        """The three predictors' backward chains depend only on the loss gradients and saved activations: they are
+        enqueued on the side stream at the very start of the backward pass (small, latency-bound kernels that then
+        run under the PostNet / decoder GEMMs); ``bwd`` joins and adds their input gradients where they belong."""
+        env = self.env
+        if not env.side_enabled:
+            return
+        out = {}
+        for name in ("duration", "pitch", "energy"):
+            if name not in c or dpred.get(name) is None:
+                continue
+            ctx = c[name][0] if name != "duration" else c[name]
+            with env.side(dpred[name]):
+                out[name] = getattr(self, f"{name}_predictor").bwd(dpred[name], ctx)
+        c["early_bwd"] = out
+
     def bwd(self, d_dec_in, dpred, c):
         """d_dec_in: gradient of the decoder input; dpred: {'pitch','energy','duration'} loss gradients."""
         S, pre = self.S, self.pre
         cfg = self.config.model.variance_predictors
 
+        early = c.get("early_bwd", {})  # predictor backward chains already computed on the side stream
+        if early:
+            self.env.join()
+
+        def predictor_bwd(name):
+            if name in early:
+                return early[name]
+            ctx = c[name][0] if name != "duration" else c[name]
+            return getattr(self, f"{name}_predictor").bwd(dpred[name], ctx)
+
         def variance_bwd(name, d):
             pctx, idx = c[name]
             H.embedding_bwd(idx.reshape(-1), d, S.g(pre + f"{name}_embedding.weight"))
-            return H.axpby(d, getattr(self, f"{name}_predictor").bwd(dpred[name], pctx))
+            return H.axpby(d, predictor_bwd(name))
 
         d = d_dec_in
         if cfg.pitch.level.value == "frame":
@@ -139,7 +173,7 @@ class VarianceAdaptor:
         if cfg.energy.level.value == "frame":
             d = variance_bwd("energy", d)
         d = H.length_regulate_bwd(d, c["cum"])
-        d = H.axpby(d, self.duration_predictor.bwd(dpred["duration"], c["duration"]))
+        d = H.axpby(d, predictor_bwd("duration"))
         if cfg.pitch.level.value == "phone":
             d = variance_bwd("pitch", d)
         if cfg.energy.level.value == "phone":
@@ -158,6 +192,7 @@ class FastSpeech2Loss:
 
     def __call__(self, output, batch, current_epoch=0, frozen_components=None):
         m = self.model
+        m.env.join()  # variance predictors run on the side stream during a training forward
         cfg, t = m.config.model, m.config.training
         dev = m.device_
         slots = torch.zeros(len(LOSS_KEYS) + 1, device=dev, dtype=torch.float32)
@@ -394,6 +429,7 @@ class FastSpeech2(_Base):
         if save:
             self._ctx = dict(text=text, enc=enc_ctx, va=va_ctx, dec=dec_ctx, dec_out=y, post=post_ctx, B=B, Ts=Ts, Tm=Tm,
                              batch=batch, gst=gst_ctx)
+        self.env.join()  # variance predictors of a teacher-forced forward ran on the side stream under the decoder
         return {
             "output": output, "postnet_output": postnet_output,
             "src_mask": H.mask_from_lens(src_lens, Ts), "src_lens": src_lens,
@@ -414,6 +450,7 @@ class FastSpeech2(_Base):
             raise RuntimeError("backward() needs a training-mode forward() and loss() first")
         S, c, g, m = self.store, self._ctx, self._loss_grads, self.config.model
         sync = self.grad_sync
+        self.variance_adaptor.bwd_predictors_early(g, c["va"])
         d_out = g["spec"]
         if m.use_postnet:
             d_post = g["postnet"]

@@ -33,3 +33,16 @@ for k, d in sorted(fam.items(), key=lambda kv: -kv[1])[:25]:
 print("-- kernels")
 for k, (d, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:40]:
     print(f"{d / 1e6 / back:8.3f} ms {100 * d / busy:5.1f}%  n={n // back:4d} avg={d / n / 1e3:8.1f} us  {k}")
+
+# ---- concurrency: union of kernel intervals vs sum (two streams) and idle time inside the step
+iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in seg)
+union, cur_s, cur_e = 0, iv[0][0], iv[0][1]
+for s_, e_ in iv[1:]:
+    if s_ > cur_e:
+        union += cur_e - cur_s
+        cur_s, cur_e = s_, e_
+    else:
+        cur_e = max(cur_e, e_)
+union += cur_e - cur_s
+print(f"-- timeline: union of kernel intervals {union / 1e6 / back:.2f} ms/step, idle {(t1 - t0 - union) / 1e6 / back:.2f} ms/step, "
+      f"overlapped {(busy - union) / 1e6 / back:.2f} ms/step")
