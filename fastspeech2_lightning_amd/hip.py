@@ -402,14 +402,19 @@ def _defer_reduction(partial, rows, n, stride, out0, n0, out1):
 
 
 def flush_grad_reductions():
+    """Finishes every pending sum on the current stream.  Returns the partial-sum buffers it read: a caller that
+    flushes on a stream other than the one they were allocated on must keep them alive until the streams join."""
+    used = []
     while _PENDING_REDUCTIONS:
         batch = _PENDING_REDUCTIONS[:REDUCE_MAX_JOBS]
         jobs = (ReduceJob * len(batch))()
         for j, (partial, rows, n, stride, out0, n0, out1) in zip(jobs, batch):
             j.src, j.out0, j.out1 = _p(partial), _p(out0), (_p(out1) if out1 is not None else None)
             j.stride, j.rows, j.n, j.n0 = stride, rows, n, n0
+            used.append(partial)
         _ok(lib().fs2hip_reduce_rows_multi(jobs, len(batch), _stream()), "reduce_rows_multi")
-        del _PENDING_REDUCTIONS[:len(batch)]  # the partial buffers may be reused from here on (stream order)
+        del _PENDING_REDUCTIONS[:len(batch)]
+    return used
 
 
 def colsum_grad(x, out):

@@ -459,15 +459,9 @@ class FastSpeech2(_Base):
         H.linear_bwd_weight(d_out, c["dec_out"], S.g("mel_linear.weight"))
         H.colsum_grad(d_out, S.g("mel_linear.bias"))
         d = H.linear_bwd_data(d_out, S.p("mel_linear.weight"))
-        if sync:
-            self.env.join()            # weight-gradient work on the side stream
-            H.flush_grad_reductions()  # deferred bias / LayerNorm gradient sums of this bucket
-            sync.bucket_ready(3)
+        self._bucket_done(3)
         d = self.decoder.bwd(d, c["dec"])
-        if sync:
-            self.env.join()
-            H.flush_grad_reductions()
-            sync.bucket_ready(2)
+        self._bucket_done(2)
         d, d_text = self.variance_adaptor.bwd(d, g, c["va"])
         if c.get("gst") is not None:
             self.gst.bwd(self._rowsum(d), c["gst"])
@@ -475,19 +469,30 @@ class FastSpeech2(_Base):
             self._rowvec_embedding_bwd("speaker_embedding.weight", c["batch"]["speaker_id"], d)
         if m.multilingual:
             self._rowvec_embedding_bwd("language_embedding.weight", c["batch"]["language_id"], d)
-        if sync:
-            self.env.join()
-            H.flush_grad_reductions()
-            sync.bucket_ready(1)
+        self._bucket_done(1)
         d = self.encoder.bwd(d, c["enc"])
         if d_text is not None:  # the aligner's keys are the raw text embedding (fs2/variance_adaptor.py:254)
             d = H.axpby(d, d_text)
         H.embedding_bwd(c["text"].reshape(-1), d, S.g("text_input_layer.weight"), self.padding_idx)
+        self._bucket_done(0)
         self.env.join()
-        H.flush_grad_reductions()
-        if sync:
-            sync.bucket_ready(0)
+        H.flush_grad_reductions()  # single GPU: everything at once, after the join
         self._ctx = self._loss_grads = None
+
+    def _bucket_done(self, bucket: int):
+        """Data parallel: every gradient of ``bucket`` has been enqueued (main chain, side stream and deferred
+        second-stage sums).  The hand-off runs ON the side stream, after an event of the main one: the bucket's
+        all-reduce then waits for the weight-gradient GEMMs without the main chain ever waiting for them."""
+        sync, env = self.grad_sync, self.env
+        if not sync:
+            return
+        if env.side_enabled:
+            with env.side():
+                env._side_held.extend(H.flush_grad_reductions())
+                sync.bucket_ready(bucket)
+        else:
+            H.flush_grad_reductions()
+            sync.bucket_ready(bucket)
 
     def _rowsum(self, d):
         """[B, T, D] -> [B, D]: gradient of a per-utterance vector that was broadcast over time."""

@@ -1,0 +1,66 @@
+"""GPU, two ranks sharing the one device (gloo: RCCL refuses duplicate devices): the bucketed gradient exchange of
+the real model -- buckets handed over from the side stream while the backward pass continues -- must leave on every
+rank the SUM of the per-rank gradients (the 1/world factor lives in the optimizer's clip coefficient)."""
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rank(rank, world, port, q):
+    import torch.distributed as dist
+    from fastspeech2_lightning_amd.config import Stats
+    from fastspeech2_lightning_amd.model import FastSpeech2
+    from fastspeech2_lightning_amd.parallel import GradSync
+    from oracle import cases as C
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    config = C.small_config(learn_alignment=False)
+    model = FastSpeech2(config, Stats(**C.STATS), seed=1)  # same seed: same initial weights on both ranks
+    model.postnet.dropout_p = 0.0
+    model.train()
+    from oracle import fs2_oracle as O
+    batches = [O.synthetic_batch(B=3, ts_lo=6, ts_hi=12, n_symbols=C.N_SYMBOLS, n_mels=config.preprocessing.audio.n_mels,
+                                 seed=100 + r, dur_hi=4) for r in range(world)]
+    # reference: both batches locally, no exchange
+    local = []
+    for b in batches:
+        model.training_step(b)
+        torch.cuda.synchronize()
+        local.append(model.store.grad.clone())
+    want = local[0] + local[1]
+    # data parallel: this rank's batch only, buckets exchanged during the backward pass
+    sync = GradSync(model.store)
+    sync.broadcast_parameters(0)
+    model.grad_sync = sync
+    for _ in range(2):  # twice: the second pass reuses cached scratch / stream state
+        model.training_step(batches[rank])
+        sync.wait()
+        torch.cuda.synchronize()
+    got = model.store.grad
+    err = float((got - want).abs().max() / want.abs().max())
+    q.put((rank, err, len(sync.ranges)))
+    dist.destroy_process_group()
+
+
+def test_bucketed_exchange_world2_on_one_gpu():
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, err, nbuckets in res:
+        assert nbuckets >= 3
+        assert err < 1e-5, (rank, err)
