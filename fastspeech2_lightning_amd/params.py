@@ -106,6 +106,7 @@ class ParamStore:
         self.flat = self.grad = self.adam_m = self.adam_v = None
         self.total = 0
         self._bucket = 0
+        self._pviews, self._gviews = {}, {}
 
     # ---- declaration phase -----------------------------------------------------------------
     def add(self, name, ref_shape, kind="id", init=init_zeros):
@@ -149,6 +150,7 @@ class ParamStore:
         for name, t in self._buffer_specs:
             self.buffers[name] = t.to(device)
         self.device = torch.device(device)
+        self._pviews, self._gviews = {}, {}
         return self
 
     def _view(self, base, name):
@@ -156,10 +158,16 @@ class ParamStore:
         return base[e.offset:e.offset + e.numel].view(native_shape(e.ref_shape, e.kind))
 
     def p(self, name):
-        return self._view(self.flat, name)
+        v = self._pviews.get(name)  # the views never change (finalize() allocates once): built on first use
+        if v is None:
+            v = self._pviews[name] = self._view(self.flat, name)
+        return v
 
     def g(self, name):
-        return self._view(self.grad, name)
+        v = self._gviews.get(name)
+        if v is None:
+            v = self._gviews[name] = self._view(self.grad, name)
+        return v
 
     def b(self, name):
         return self.buffers[name]
