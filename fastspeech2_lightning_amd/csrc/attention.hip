@@ -83,7 +83,7 @@ __device__ __forceinline__ f32x4 dot_tile(const float* __restrict__ tile, const 
 }
 
 template <int HD>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p, float* __restrict__ o, float* __restrict__ lse) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p, float* __restrict__ o, float* __restrict__ lse) {
   constexpr int LDT = HD + 4, NJ = HD / 16;
   __shared__ __attribute__((aligned(16))) float Ks[64 * LDT];
   __shared__ __attribute__((aligned(16))) float Vs[64 * LDT];
@@ -132,13 +132,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p, float* __restric
     }
     mx = xor_max16_32(mx);
     const float mnew = fmaxf(m, mx);
-    const float alpha = expf(m - mnew);
+    const float alpha = __expf(m - mnew);
     float rs = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float pv = expf(s[kt][r] - mnew);
+        float pv = __expf(s[kt][r] - mnew);  // v_exp_f32: ~1 ulp; precise expf costs 5x the instructions
         rs += pv;
         s[kt][r] = pv * fs2_drop_factor(drop, rowidx + (unsigned long long)(key0 + 16 * kt + 4 * g + r));
       }
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p, const float* 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int key = key0 + 16 * kt + 4 * g + r;
-        float pv = key < len ? expf(s[r] - lse_q) : 0.f;
+        float pv = key < len ? __expf(s[r] - lse_q) : 0.f;
         float f = fs2_drop_factor(drop, rowidx + (unsigned long long)key);
         ds[kt][r] = pv * (dp[r] * f - delta_q);
       }
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p, const float*
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int ql = 16 * qt + 4 * g + r;
-        float pv = key_ok ? expf(s[r] - lse_s[ql]) : 0.f;
+        float pv = key_ok ? __expf(s[r] - lse_s[ql]) : 0.f;
         float f = fs2_drop_factor(drop, (headidx + (unsigned long long)(q0 + ql)) * T + (unsigned long long)key);
         pd[r] = pv * f;
         ds[r] = pv * (dp[r] * f - delta_s[ql]);
