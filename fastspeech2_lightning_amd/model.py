@@ -266,14 +266,16 @@ class FastSpeech2(_Base):
         self.lang2id, self.speaker2id = lang2id or {}, speaker2id or {}
         self.current_epoch_ = 0
         m = config.model
-        if m.target_text_representation_level == TargetTrainingTextRepresentationLevel.phonological_features:
-            raise NotImplementedError("phonological-feature input layer is not built yet")
         d = m.encoder.input_dim
         self.step_state = H.new_step_state(self.device_)
         self.env = M.Env(self.step_state, seed)
         S = self.store = P.ParamStore()
         self.padding_idx = self.text_processor.encode_text(self.text_processor._pad_symbol)[0]
-        S.add("text_input_layer.weight", (len(self.text_processor.symbols), d), "id", self._init_text_embedding)
+        self.use_pfs = m.target_text_representation_level == TargetTrainingTextRepresentationLevel.phonological_features
+        if self.use_pfs:  # fs2/model.py:72-81: nn.Linear(N_PHONOLOGICAL_FEATURES, d, bias=False) on batch["pfs"]
+            S.add("text_input_layer.weight", (d, N_PHONOLOGICAL_FEATURES), "padk4", P.init_linear_weight)
+        else:
+            S.add("text_input_layer.weight", (len(self.text_processor.symbols), d), "id", self._init_text_embedding)
         S.add_buffer("position_embedding.inv_freq", 1 / (10000 ** (torch.arange(0.0, d, 2.0) / d)))
         self.encoder = M.Conformer(S, self.env, "encoder.", m.encoder)
         S.next_bucket()
@@ -380,6 +382,12 @@ class FastSpeech2(_Base):
         for k in ("mel", "pitch", "energy"):
             if b.get(k) is not None:
                 b[k] = self._dev(b[k], torch.float32)
+        if self.use_pfs and b.get("pfs") is not None and b["pfs"].shape[-1] == N_PHONOLOGICAL_FEATURES:
+            # feature rows padded with zero columns to a multiple of 4 floats (the GEMM reads 16-byte pieces)
+            pfs = self._dev(b["pfs"], torch.float32)
+            padded = torch.zeros(*pfs.shape[:-1], (N_PHONOLOGICAL_FEATURES + 3) // 4 * 4, device=pfs.device)
+            padded[..., :N_PHONOLOGICAL_FEATURES] = pfs
+            b["pfs"] = padded
         if b.get("duration") is not None and torch.is_tensor(b["duration"]):
             # learned alignment: "duration" carries the (B, Tm, Ts) attention prior (fs2/dataset.py:274-281)
             prior = self.config.model.learn_alignment and b["duration"].dim() == 3
@@ -394,12 +402,15 @@ class FastSpeech2(_Base):
         batch = self.prepare_batch(batch)
         teacher_forcing = bool(inference and batch.get("mel_lens") is not None)
         S, m = self.store, self.config.model
-        text, src_lens = batch["text"], batch["src_lens"]
-        B, Ts = text.shape
+        text, src_lens = (batch["pfs"] if self.use_pfs else batch["text"]), batch["src_lens"]
+        B, Ts = text.shape[:2]
         if int(batch["max_src_len"]) != Ts:
             raise ValueError("max_src_len must equal the padded text length")
         save = self.training and not inference
-        inputs = H.embedding_fwd(text, S.p("text_input_layer.weight"))
+        if self.use_pfs:
+            inputs = H.linear_fwd(text, S.p("text_input_layer.weight"))
+        else:
+            inputs = H.embedding_fwd(text, S.p("text_input_layer.weight"))
         x = H.add_posenc(inputs, self._table(Ts), src_lens, B, Ts)
         x, enc_ctx = self.encoder.fwd(x, src_lens)
         gst_ctx = None
@@ -473,7 +484,10 @@ class FastSpeech2(_Base):
         d = self.encoder.bwd(d, c["enc"])
         if d_text is not None:  # the aligner's keys are the raw text embedding (fs2/variance_adaptor.py:254)
             d = H.axpby(d, d_text)
-        H.embedding_bwd(c["text"].reshape(-1), d, S.g("text_input_layer.weight"), self.padding_idx)
+        if self.use_pfs:
+            H.linear_bwd_weight(d, c["text"], S.g("text_input_layer.weight"))
+        else:
+            H.embedding_bwd(c["text"].reshape(-1), d, S.g("text_input_layer.weight"), self.padding_idx)
         self._bucket_done(0)
         self.env.join()
         H.flush_grad_reductions()  # single GPU: everything at once, after the join

@@ -30,6 +30,8 @@ _TO_NATIVE = {
     "conv2d": lambda t: t.permute(2, 3, 1, 0),  # (Cout, Cin, kh, kw) -> [kh][kw][Cin][Cout]
     # GRU input weights (3U, C*W) with columns c*W+w  ->  columns w*C+c (channels-last feature order); W = 2
     "gru_ih_w2": lambda t: t.reshape(t.shape[0], -1, 2).transpose(1, 2).reshape(t.shape[0], -1),
+    # (N, K) with K not a multiple of 4 -> zero columns up to the next multiple (16-byte operand pieces)
+    "padk4": lambda t: torch.nn.functional.pad(t, (0, (-t.shape[1]) % 4)),
 }
 _TO_REF = {
     "id": lambda t, shape: t,
@@ -38,6 +40,7 @@ _TO_REF = {
     "pw": lambda t, shape: t.unsqueeze(-1),
     "conv2d": lambda t, shape: t.permute(3, 2, 0, 1),
     "gru_ih_w2": lambda t, shape: t.reshape(t.shape[0], 2, -1).transpose(1, 2).reshape(t.shape[0], -1),
+    "padk4": lambda t, shape: t[:, :shape[1]],
 }
 
 
@@ -51,6 +54,8 @@ def native_shape(ref_shape, kind):
         return (s[0], s[1])
     if kind == "conv2d":
         return (s[2], s[3], s[1], s[0])
+    if kind == "padk4":
+        return (s[0], (s[1] + 3) // 4 * 4)
     return s
 
 
@@ -113,7 +118,7 @@ class ParamStore:
         if name in self.entries:
             raise KeyError(name)
         e = Entry(name, tuple(ref_shape), kind, init)
-        e.numel = int(torch.Size(ref_shape).numel())
+        e.numel = int(torch.Size(native_shape(ref_shape, kind)).numel())  # storage (the padded kind is larger)
         e.offset = self.total
         e.bucket = self._bucket
         self.total += (e.numel + self.ALIGN - 1) // self.ALIGN * self.ALIGN

@@ -110,18 +110,24 @@ def test_forward_loss_backward_vs_reference_golden(golden_dir, name):
             assert int(sd[k[9:]]) == int(g[k]), k
 
 
-def test_against_oracle_on_fresh_inputs_with_default_widths():
+@pytest.mark.parametrize("level", ["characters", "phonological_features"])
+def test_against_oracle_on_fresh_inputs_with_default_widths(level):
     """Default-width model (D=256, F=1024, hd=128, PostNet 512) on a fresh small batch: HIP path vs
-    the CPU oracle sharing one state dict."""
-    from fastspeech2_lightning_amd.config import FastSpeech2Config
+    the CPU oracle sharing one state dict.  ``phonological_features``: the text input layer is the bias-free
+    Linear over 38-wide feature vectors (fs2/model.py:72-81) instead of the embedding."""
+    from fastspeech2_lightning_amd.config import FastSpeech2Config, N_PHONOLOGICAL_FEATURES
     from fastspeech2_lightning_amd.model import FastSpeech2
     conf = dict(layers=1, dropout=0.0)
     vp = dict(dropout=0.0)
     config = FastSpeech2Config(
-        model=dict(encoder=conf, decoder=conf, learn_alignment=False,
+        model=dict(encoder=conf, decoder=conf, learn_alignment=False, target_text_representation_level=level,
                    variance_predictors=dict(energy=vp, pitch=vp, duration=vp)),
         text=dict(symbols=dict(letters=[f"s{i}" for i in range(40)])))
     batch = O.synthetic_batch(B=2, ts_lo=20, ts_hi=33, n_symbols=41, n_mels=80, seed=3, dur_hi=5)
+    if level == "phonological_features":
+        g = torch.Generator().manual_seed(11)
+        pfs = (torch.rand(*batch["text"].shape, N_PHONOLOGICAL_FEATURES, generator=g) < 0.4).float()
+        batch["pfs"] = pfs * (batch["text"] != 0)[..., None]  # zero rows on padding
     model = FastSpeech2(config, Stats(**C.STATS))
     oracle = O.FastSpeech2Oracle(config, Stats(**C.STATS), n_symbols=41)
     sd = O.seeded_state_dict(oracle.state_dict())
