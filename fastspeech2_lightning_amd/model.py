@@ -415,10 +415,14 @@ class FastSpeech2(_Base):
         x, enc_ctx = self.encoder.fwd(x, src_lens)
         gst_ctx = None
         if self.gst is not None:
-            # fs2/model.py:196-203: training / teacher forcing condition on the target mel
-            if batch.get("mel") is None:
-                raise NotImplementedError("GST inference without a reference mel (condition_on_gst_tokens) is not built yet")
-            style, gst_ctx = self.gst.fwd(batch["mel"])
+            # fs2/model.py:196-203: a style-reference mel in inference, token 0 in free inference, else the target mel
+            ref_mel = batch.get("mel_style_reference")
+            if inference and torch.is_tensor(ref_mel):
+                style, _ = self.gst.fwd(self._dev(ref_mel, torch.float32))
+            elif inference and not teacher_forcing:
+                style = self.gst.condition_on_gst_tokens(B)
+            else:
+                style, gst_ctx = self.gst.fwd(batch["mel"])
             x = H.add_rowvec(x, style, B, Ts)
         if m.multispeaker:
             x = H.add_rowvec(x, H.embedding_fwd(batch["speaker_id"], S.p("speaker_embedding.weight")), B, Ts)

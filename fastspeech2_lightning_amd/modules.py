@@ -536,6 +536,17 @@ class StyleEncoder:
         return style, Ctx(conv=conv_saved, feat=feat, hs=hs, gates=gates, q=q, tk=tk, k=k, v=v, p=p, ctx=ctx,
                           shape=(B, Hh, Ww, C))
 
+    def condition_on_gst_tokens(self, batch_size: int, index: int = 0):
+        """reference ``fs2/gst/model.py:77-85`` (free inference without a reference mel): attention over the single
+        token ``index`` -- its softmax weight is 1, so the style is ``linear_out(linear_v(tanh(gst_embs[index])))``
+        for every utterance, whatever the (zero) query."""
+        if index >= self.TOKENS:
+            raise ValueError(f"We can only synthesize by conditioning on one of {self.TOKENS} GST tokens")
+        S = self.S
+        tk = H.act_apply(S.p(self.embs)[index:index + 1].contiguous(), "tanh")
+        style = H.linear_fwd(H.linear_fwd(tk, *self._lw("v")), *self._lw("out"))
+        return style.expand(batch_size, -1).contiguous()
+
     def bwd(self, d_style, c):
         S, env, U = self.S, self.env, self.U
         B, Hh, Ww, C = c.shape

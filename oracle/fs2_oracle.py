@@ -339,6 +339,12 @@ class StyleEncoder(nn.Module):
     def forward(self, speech):
         return self.stl(self.ref_enc(speech))
 
+    def condition_on_gst_tokens(self, batch_size, index=0):  # fs2/gst/model.py:77-85
+        gst = torch.tanh(self.stl.gst_embs)
+        query = torch.zeros(batch_size, 1, gst.size(1) * 2)  # gst_token_dim // 2 = ref_dim
+        keys = gst[index].unsqueeze(0).expand(batch_size, -1, -1)
+        return self.stl.mha(query, keys, keys).squeeze(1)
+
 
 # --------------------------------------------------------------------------- #
 # fs2/layers.py:143-212
@@ -533,7 +539,14 @@ class FastSpeech2Oracle(nn.Module):
         pos = self.position_embedding(torch.arange(max_src_len).to(inputs.dtype)) * src_mask.unsqueeze(2)
         x, _ = self.encoder(inputs + pos, src_lens)
         if m.use_global_style_token_module:  # fs2/model.py:196-203 (training / teacher forcing: the target mel)
-            x = x + self.gst(batch["mel"]).unsqueeze(1)
+            ref_mel = batch.get("mel_style_reference")  # fs2/model.py:196-203
+            if inference and torch.is_tensor(ref_mel):
+                style = self.gst(ref_mel)
+            elif inference and not teacher_forcing:
+                style = self.gst.condition_on_gst_tokens(batch["src_lens"].size(0))
+            else:
+                style = self.gst(batch["mel"])
+            x = x + style.unsqueeze(1)
         if self.speaker_embedding is not None:
             x = x + self.speaker_embedding(batch["speaker_id"]).unsqueeze(1)
         if self.language_embedding is not None:

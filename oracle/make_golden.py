@@ -227,6 +227,13 @@ def dump_units(out_dir: Path):
     logd = torch.log(torch.tensor([0.5, 1.5, 2.5, 3.5, 1.0, 7.49, 0.2]) + 1)
     save["round/logd"] = _np(logd)
     save["round/out"] = _np(torch.clamp(torch.round(torch.exp(logd) - 1) * 1.0, min=0).int())
+    # GST free-inference conditioning on one style token -- fs2/gst/model.py:77-85
+    from fs2.gst.model import StyleEncoder as RefStyleEncoder
+    ref_gst = RefStyleEncoder(idim=80)
+    ref_gst.load_state_dict(O.seeded_state_dict(O.StyleEncoder(idim=80).state_dict()))
+    ref_gst.eval()
+    with torch.no_grad():
+        save["gst_cond/out"] = _np(ref_gst.condition_on_gst_tokens(3, index=2))
     np.savez_compressed(out_dir / "units.npz", **save)
     print(f"units: {len(save)} arrays")
 
@@ -288,7 +295,7 @@ def main():
     out_dir = REPO / "tests" / "golden"
     out_dir.mkdir(parents=True, exist_ok=True)
     install_stand_ins()
-    if len(sys.argv) <= 1:
+    if len(sys.argv) <= 1 or "units" in sys.argv[1:]:
         dump_units(out_dir)
     if len(sys.argv) <= 1 or "data" in sys.argv[1:]:
         dump_data(out_dir)

@@ -15,8 +15,9 @@ pytestmark = pytest.mark.gpu
 def build_pair(name="e2e_noalign_eval"):
     from fastspeech2_lightning_amd.model import FastSpeech2
     config, batch, _ = C.build(name)
-    model = FastSpeech2(config, Stats(**C.STATS))
-    oracle = O.FastSpeech2Oracle(config, Stats(**C.STATS), n_symbols=C.N_SYMBOLS)
+    model = FastSpeech2(config, Stats(**C.STATS), lang2id=C.LANG2ID, speaker2id=C.SPEAKER2ID)
+    oracle = O.FastSpeech2Oracle(config, Stats(**C.STATS), n_symbols=C.N_SYMBOLS, n_speakers=len(C.SPEAKER2ID),
+                                 n_langs=len(C.LANG2ID))
     sd = O.seeded_state_dict(oracle.state_dict())
     # make the duration predictor produce a useful spread of durations
     sd["variance_adaptor.duration_predictor.linear.bias"] = torch.tensor([1.2])
@@ -73,3 +74,21 @@ def test_checkpoint_round_trip(tmp_path):
         model.on_load_checkpoint(bad)
     with pytest.raises(TypeError):
         model.on_load_checkpoint(dict(ckpt, model_info={"name": "HiFiGAN", "version": "1.0"}))
+
+
+@pytest.mark.parametrize("mode", ["token", "style_reference"])
+def test_gst_inference_branches_match_oracle(mode):
+    """fs2/model.py:196-203: free inference conditions on style token 0 (``condition_on_gst_tokens``), inference with a
+    ``mel_style_reference`` runs the reference encoder on that mel."""
+    model, oracle, batch, _ = build_pair("e2e_gst_multispeaker_train")
+    infer = {k: v for k, v in batch.items() if k not in ("mel", "pitch", "energy", "duration")}
+    infer.update(mel=None, mel_lens=None, max_mel_len=1_000_000, duration=None)
+    infer["mel_style_reference"] = batch["mel"][:, :40].contiguous() if mode == "style_reference" else None
+    with torch.no_grad():
+        ref = oracle(dict(infer), InferenceControl(), inference=True)
+    out = model(dict(infer), InferenceControl(), inference=True)
+    assert torch.equal(out["tgt_lens"].cpu(), ref["tgt_lens"].cpu().int())
+    for k in ("output", "postnet_output", "duration_prediction", "pitch_prediction", "energy_prediction"):
+        a, b = out[k].cpu().numpy(), ref[k].numpy()
+        assert a.shape == b.shape, k
+        assert np.abs(a - b).max() < 1e-4 * max(1.0, np.abs(b).max()), k
