@@ -276,6 +276,16 @@ def main():
             "loss_total": round(losses.get("total", float("nan")), 5),
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        # whole-step view (SURVEY.md 8d closed form, padded shapes, backward = 2 x forward): algorithmic FLOPs of the
+        # step / step time against the fp32 MFMA peak -- beside the dominant kernel's own roofline above
+        Bq, Ts_p, Tm_p = int(batch["text"].shape[0]), int(batch["text"].shape[1]), int(batch["mel"].shape[1])
+        f_step = 3.0 * (Bq * Ts_p * (4 * (3019264 + 1024 * Ts_p) + 1990656)
+                        + Bq * Tm_p * (4 * (3019264 + 1024 * Tm_p) + 40960 + 8683520))
+        if args.learn_alignment:
+            f_step += 3.0 * Bq * (Ts_p * 868352 + Tm_p * (115200 + 240 * Ts_p))
+        tf = f_step / (ms_per_step * 1e-3) / 1e12
+        line["whole_step"] = {"algorithmic_tflop_per_step_per_gpu": round(f_step / 1e12, 4), "achieved_tflops_per_gpu": round(tf, 2),
+                              "frac_of_fp32_mfma_peak": round(tf / PEAK_FP32_MFMA_TFLOPS, 4)}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
