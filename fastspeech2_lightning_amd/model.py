@@ -227,8 +227,14 @@ class FastSpeech2Loss:
             lp, soft = output["attn_logprob"], output["attn_soft"]
             Bm, _, Tmm, Tss = lp.shape
             i = LOSS_KEYS.index("attn_ctc")
-            grads["attn_ctc"] = H.attn_ctc_loss(lp.view(Bm, Tmm, Tss), batch["src_lens"], batch["mel_lens"],
-                                                t.attn_ctc_loss_weight, slots[i:i + 1], want_grad=want)
+            early = getattr(m, "_early_ctc", None)
+            if early is not None and want:  # computed on the side stream during the forward pass (model.forward)
+                H.axpby(early[0], None, 1.0, 0.0, out=slots[i:i + 1])
+                grads["attn_ctc"] = early[1]
+                m._early_ctc = None
+            else:
+                grads["attn_ctc"] = H.attn_ctc_loss(lp.view(Bm, Tmm, Tss), batch["src_lens"], batch["mel_lens"],
+                                                    t.attn_ctc_loss_weight, slots[i:i + 1], want_grad=want)
             losses["attn_ctc"] = slots[i]
             w = min(current_epoch / t.attn_bin_loss_warmup_epochs, 1.0) * t.attn_bin_loss_weight
             i = LOSS_KEYS.index("attn_bin")
@@ -432,6 +438,17 @@ class FastSpeech2(_Base):
         va, va_ctx = self.variance_adaptor.fwd(x, batch, src_lens, self._table, int(Tm), control, inference,
                                                teacher_forcing, text_emb=inputs)
         self._hard_idx = va_ctx.get("hard_idx")
+        self._early_ctc = None
+        if save and va.get("attn_logprob") is not None and self.env.side_enabled:
+            # The forward-sum (CTC) loss of the aligner and its gradient are a 2 x Tm-step serial recursion per
+            # utterance (1.4 ms on 32 wavefronts): started now on the side stream, it runs under the decoder and
+            # PostNet instead of between forward and backward.  fs2/loss.py:109-116 gives weight and inputs.
+            lp = va["attn_logprob"]
+            slot = torch.zeros(1, device=lp.device, dtype=torch.float32)
+            with self.env.side(lp, slot, batch["src_lens"], batch["mel_lens"]):
+                g_ctc = H.attn_ctc_loss(lp.view(lp.shape[0], lp.shape[2], lp.shape[3]), batch["src_lens"],
+                                        batch["mel_lens"], self.config.training.attn_ctc_loss_weight, slot, want_grad=True)
+            self._early_ctc = (slot, g_ctc)
         Tm, tgt_lens = va["Tm"], va["tgt_lens"]
         if (teacher_forcing or not inference) and batch.get("mel") is not None and batch["mel"].shape[1] != Tm:
             raise ValueError("max_mel_len must equal the padded mel length")
