@@ -145,6 +145,9 @@ class VarianceAdaptor:
             ctx = c[name][0] if name != "duration" else c[name]
             with env.side(dpred[name]):
                 out[name] = getattr(self, f"{name}_predictor").bwd(dpred[name], ctx)
+        if "align" in c:  # the aligner's backward only meets the main chain at the text embedding's gradient
+            with env.side(dpred.get("attn_ctc"), dpred.get("attn_bin")):
+                out["align"] = self.aligner.bwd(dpred.get("attn_ctc"), dpred.get("attn_bin"), c["align"])
         c["early_bwd"] = out
 
     def bwd(self, d_dec_in, dpred, c):
@@ -180,7 +183,8 @@ class VarianceAdaptor:
             d = variance_bwd("energy", d)
         d_text = None
         if "align" in c:
-            d_text = self.aligner.bwd(dpred.get("attn_ctc"), dpred.get("attn_bin"), c["align"])
+            d_text = early["align"] if "align" in early else self.aligner.bwd(dpred.get("attn_ctc"), dpred.get("attn_bin"),
+                                                                              c["align"])
         return d, d_text
 
 
