@@ -111,28 +111,73 @@ __global__ __launch_bounds__(256) void mas_kernel(const float* __restrict__ in, 
   }
   __syncthreads();
   int cur = 0;
-  for (int i = 1; i < T1; ++i) {
-    const float* pr = prev + cur * Ts;
-    float* nx = prev + (cur ^ 1) * Ts;
-    for (int j0 = 0; j0 < T2; j0 += 256) {
-      const int j = j0 + tid;
-      bool left = false;
-      if (j < T2) {
-        const float p1 = j > 0 ? pr[j - 1] : NEG_INF, p2 = pr[j];
-        float v = src[(long long)i * Ts + j];
-        if (!is_log) v = logf(v);
-        nx[j] = v + fmaxf(p1, p2);
-        left = j > 0 && p1 >= p2;  // fs2/attn/alignment.py:68 (ties move left)
+  // The recursion over rows is serial, but its inputs are not: the log-probabilities of the next MAS_CHUNK rows are
+  // fetched (and logged) into registers while the current chunk runs, so a row costs an LDS exchange + barrier and
+  // no longer a dependent global load.  (Ts <= 256 tokens per pass of the column loop.)
+  constexpr int MAS_CHUNK = 8;
+  if (T2 <= 256) {
+    const int j = tid;
+    const bool act = j < T2;
+    float nxt[MAS_CHUNK], curv[MAS_CHUNK];
+    auto fetch = [&](int i0, float (&dst)[MAS_CHUNK]) {
+#pragma unroll
+      for (int r = 0; r < MAS_CHUNK; ++r) {
+        const int i = i0 + r;
+        float v = (act && i < T1) ? src[(long long)i * Ts + j] : 1.f;
+        dst[r] = is_log ? v : logf(v);
       }
-      const unsigned long long bal = __ballot(left);
-      if ((tid & 31) == 0 && j < T2 + 31) {
-        const unsigned word = (tid & 32) ? (unsigned)(bal >> 32) : (unsigned)bal;
-        const int w = j >> 5;
-        if (w < W) dirs[(long long)i * W + w] = word;
+    };
+    fetch(1, nxt);
+    for (int i0 = 1; i0 < T1; i0 += MAS_CHUNK) {
+#pragma unroll
+      for (int r = 0; r < MAS_CHUNK; ++r) curv[r] = nxt[r];
+      if (i0 + MAS_CHUNK < T1) fetch(i0 + MAS_CHUNK, nxt);
+#pragma unroll
+      for (int r = 0; r < MAS_CHUNK; ++r) {
+        const int i = i0 + r;
+        if (i >= T1) break;  // uniform
+        const float* pr = prev + cur * Ts;
+        float* nx = prev + (cur ^ 1) * Ts;
+        bool left = false;
+        if (act) {
+          const float p1 = j > 0 ? pr[j - 1] : NEG_INF, p2 = pr[j];
+          nx[j] = curv[r] + fmaxf(p1, p2);
+          left = j > 0 && p1 >= p2;  // fs2/attn/alignment.py:68 (ties move left)
+        }
+        const unsigned long long bal = __ballot(left);
+        if ((tid & 31) == 0 && j < T2 + 31) {
+          const unsigned word = (tid & 32) ? (unsigned)(bal >> 32) : (unsigned)bal;
+          const int w = j >> 5;
+          if (w < W) dirs[(long long)i * W + w] = word;
+        }
+        __syncthreads();
+        cur ^= 1;
       }
     }
-    __syncthreads();
-    cur ^= 1;
+  } else {
+    for (int i = 1; i < T1; ++i) {
+      const float* pr = prev + cur * Ts;
+      float* nx = prev + (cur ^ 1) * Ts;
+      for (int j0 = 0; j0 < T2; j0 += 256) {
+        const int j = j0 + tid;
+        bool left = false;
+        if (j < T2) {
+          const float p1 = j > 0 ? pr[j - 1] : NEG_INF, p2 = pr[j];
+          float v = src[(long long)i * Ts + j];
+          if (!is_log) v = logf(v);
+          nx[j] = v + fmaxf(p1, p2);
+          left = j > 0 && p1 >= p2;  // fs2/attn/alignment.py:68 (ties move left)
+        }
+        const unsigned long long bal = __ballot(left);
+        if ((tid & 31) == 0 && j < T2 + 31) {
+          const unsigned word = (tid & 32) ? (unsigned)(bal >> 32) : (unsigned)bal;
+          const int w = j >> 5;
+          if (w < W) dirs[(long long)i * W + w] = word;
+        }
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
   }
   if (tid == 0) {
     int j = T2 - 1;
@@ -157,6 +202,102 @@ __global__ __launch_bounds__(256) void mas_kernel(const float* __restrict__ in, 
   __syncthreads();
   // durations = column sums of the hard map (fs2/variance_adaptor.py:267-268)
   for (int i = tid; i < T1; i += 256) {
+    const int j = hard_idx[b * Tm + i];
+    if (j >= 0) atomicAdd(&dur[b * Ts + j], 1);
+  }
+}
+
+// Same search for texts of at most 128 tokens (the usual case), ONE wavefront per utterance: lane l owns columns l
+// and l + 64 in registers, the left neighbour comes by lane shift, so a row costs two shuffles and a ballot instead
+// of an LDS exchange and a workgroup barrier (648 rows: 0.44 ms -> tens of microseconds).  Row inputs are fetched a
+// chunk ahead.  Bit-identical to mas_kernel.
+__global__ __launch_bounds__(64) void mas_wave_kernel(const float* __restrict__ in, int is_log,
+                                                      const int* __restrict__ in_lens, const int* __restrict__ out_lens,
+                                                      float* __restrict__ hard, int* __restrict__ hard_idx,
+                                                      int* __restrict__ dur, int B, int Tm, int Ts) {
+  extern __shared__ unsigned long long dirs64[];  // [Tm][2]: bit j of word j >> 6 = "move left when leaving (i, j)"
+  const int b = blockIdx.x, lane = threadIdx.x;
+  int T1 = out_lens[b], T2 = in_lens[b];
+  T1 = T1 < 0 ? 0 : (T1 > Tm ? Tm : T1);
+  T2 = T2 < 1 ? 1 : (T2 > Ts ? Ts : T2);
+  const float* src = in + (long long)b * Tm * Ts;
+  float* hb = hard + (long long)b * Tm * Ts;
+  for (long long i = lane; i < (long long)Tm * Ts; i += 64) hb[i] = 0.f;
+  for (int j = lane; j < Ts; j += 64) dur[b * Ts + j] = 0;
+  for (int i = lane; i < Tm; i += 64) hard_idx[b * Tm + i] = -1;
+  if (T1 == 0) return;
+  const int ja = lane, jb = lane + 64;
+  const bool acta = ja < T2, actb = jb < T2;
+  float pa = NEG_INF, pb = NEG_INF;
+  if (lane == 0) {
+    const float v = src[0];
+    pa = is_log ? v : logf(v);
+  }
+  constexpr int CH = 8;
+  float na[CH], nb[CH], va[CH], vb[CH];
+  auto fetch = [&](int i0) {
+#pragma unroll
+    for (int r = 0; r < CH; ++r) {
+      const int i = i0 + r;
+      const float xa = (acta && i < T1) ? src[(long long)i * Ts + ja] : 1.f;
+      const float xb = (actb && i < T1) ? src[(long long)i * Ts + jb] : 1.f;
+      na[r] = is_log ? xa : logf(xa);
+      nb[r] = is_log ? xb : logf(xb);
+    }
+  };
+  fetch(1);
+  for (int i0 = 1; i0 < T1; i0 += CH) {
+#pragma unroll
+    for (int r = 0; r < CH; ++r) {
+      va[r] = na[r];
+      vb[r] = nb[r];
+    }
+    if (i0 + CH < T1) fetch(i0 + CH);
+#pragma unroll
+    for (int r = 0; r < CH; ++r) {
+      const int i = i0 + r;
+      if (i >= T1) break;  // uniform
+      float la = __shfl_up(pa, 1, 64), lb = __shfl_up(pb, 1, 64);
+      const float a63 = __shfl(pa, 63, 64);
+      if (lane == 0) {
+        la = NEG_INF;  // column 0 has no left neighbour
+        lb = a63;      // column 64's left neighbour is column 63
+      }
+      const bool left_a = acta && ja > 0 && la >= pa;  // fs2/attn/alignment.py:68 (ties move left)
+      const bool left_b = actb && lb >= pb;
+      const float xa = va[r] + fmaxf(la, pa), xb = vb[r] + fmaxf(lb, pb);
+      const unsigned long long ba = __ballot(left_a), bb = __ballot(left_b);
+      if (lane == 0) {
+        dirs64[2 * i] = ba;
+        dirs64[2 * i + 1] = bb;
+      }
+      pa = acta ? xa : NEG_INF;
+      pb = actb ? xb : NEG_INF;
+    }
+  }
+  __syncthreads();
+  if (lane == 0) {
+    int j = T2 - 1;
+    int i = T1 - 1;
+    for (; i >= 1; --i) {
+      hb[(long long)i * Ts + j] = 1.f;
+      hard_idx[b * Tm + i] = j;
+      if (j > 0 && ((dirs64[2 * i + (j >> 6)] >> (j & 63)) & 1ull)) {
+        --j;
+        if (j == 0) {
+          for (int r = 1; r < i; ++r) {
+            hb[(long long)r * Ts] = 1.f;
+            hard_idx[b * Tm + r] = 0;
+          }
+          break;
+        }
+      }
+    }
+    hb[j] = 1.f;
+    hard_idx[b * Tm] = j;
+  }
+  __syncthreads();
+  for (int i = lane; i < T1; i += 64) {
     const int j = hard_idx[b * Tm + i];
     if (j >= 0) atomicAdd(&dur[b * Ts + j], 1);
   }
@@ -416,6 +557,11 @@ extern "C" int fs2hip_attn_softmax(const float* logits, const float* prior, cons
 extern "C" int fs2hip_mas(const float* in, int is_log, const int* in_lens, const int* out_lens, float* hard,
                           int* hard_idx, int* dur, unsigned* dirs_ws, int B, int Tm, int Ts, void* stream) {
   if (B <= 0 || Tm <= 0 || Ts <= 0) return FS2HIP_EINVAL;
+  if (Ts <= 128 && (size_t)Tm * 16 <= 60 * 1024) {  // one wavefront per utterance, everything on chip
+    mas_wave_kernel<<<dim3(B), dim3(64), (size_t)Tm * 16, S_>>>(in, is_log, in_lens, out_lens, hard, hard_idx, dur, B, Tm, Ts);
+    FS2_LAUNCH_CHECK();
+    return 0;
+  }
   const int W = (Ts + 31) / 32;
   size_t smem = (size_t)2 * Ts * sizeof(float);
   const size_t dirs_bytes = (size_t)Tm * W * sizeof(unsigned);

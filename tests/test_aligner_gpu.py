@@ -64,22 +64,28 @@ def test_mas_bit_exact(H, golden_dir):
         x = x - np.log(np.exp(x).sum(1, keepdims=True))
         cases.append(x.astype(np.float32))
         cases.append(np.round(x).astype(np.float32))  # tie-heavy
-    B = len(cases)
-    Tm, Ts = max(c.shape[0] for c in cases), max(c.shape[1] for c in cases)
-    x = torch.zeros(B, Tm, Ts)
-    for i, c in enumerate(cases):
-        x[i, : c.shape[0], : c.shape[1]] = torch.tensor(c)
-    in_lens = torch.tensor([c.shape[1] for c in cases], dtype=torch.int32)
-    out_lens = torch.tensor([c.shape[0] for c in cases], dtype=torch.int32)
-    hard, idx, dur = H.mas(x.cuda(), in_lens.cuda(), out_lens.cuda(), is_log=True)
-    for i, c in enumerate(cases):
-        ref = O.mas_width1(c.copy()) if i >= 4 else [g[f"mas/{t}/out"] for t in ("rand", "ties", "t2_2", "square")][i]
-        got = hard[i].cpu().numpy()
-        np.testing.assert_array_equal(got[: c.shape[0], : c.shape[1]], ref, err_msg=f"case {i}")
-        assert got.sum() == c.shape[0]
-        np.testing.assert_array_equal(dur[i].cpu().numpy()[: c.shape[1]], ref.sum(0).astype(np.int32))
-        np.testing.assert_array_equal(idx[i].cpu().numpy()[: c.shape[0]], ref.argmax(1))
-        assert (idx[i].cpu().numpy()[c.shape[0]:] == -1).all()
+    refs = [O.mas_width1(c.copy()) if i >= 4 else [g[f"mas/{t}/out"] for t in ("rand", "ties", "t2_2", "square")][i]
+            for i, c in enumerate(cases)]
+    # two launches: every case (padded to 200 tokens -> the workgroup kernel) and the cases of at most 128 tokens
+    # (-> the one-wavefront-per-utterance kernel); both must reproduce the reference's search bit for bit
+    for group in (list(range(len(cases))), [i for i, c in enumerate(cases) if c.shape[1] <= 128]):
+        sel = [cases[i] for i in group]
+        Tm, Ts = max(c.shape[0] for c in sel), max(c.shape[1] for c in sel)
+        assert (Ts <= 128) == (len(group) < len(cases))
+        x = torch.zeros(len(sel), Tm, Ts)
+        for n, c in enumerate(sel):
+            x[n, : c.shape[0], : c.shape[1]] = torch.tensor(c)
+        in_lens = torch.tensor([c.shape[1] for c in sel], dtype=torch.int32)
+        out_lens = torch.tensor([c.shape[0] for c in sel], dtype=torch.int32)
+        hard, idx, dur = H.mas(x.cuda(), in_lens.cuda(), out_lens.cuda(), is_log=True)
+        for n, i in enumerate(group):
+            c, ref = cases[i], refs[i]
+            got = hard[n].cpu().numpy()
+            np.testing.assert_array_equal(got[: c.shape[0], : c.shape[1]], ref, err_msg=f"case {i} (Ts={Ts})")
+            assert got.sum() == c.shape[0]
+            np.testing.assert_array_equal(dur[n].cpu().numpy()[: c.shape[1]], ref.sum(0).astype(np.int32))
+            np.testing.assert_array_equal(idx[n].cpu().numpy()[: c.shape[0]], ref.argmax(1))
+            assert (idx[n].cpu().numpy()[c.shape[0]:] == -1).all()
 
 
 def test_avg_variance(H, golden_dir):
