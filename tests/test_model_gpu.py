@@ -156,3 +156,35 @@ def test_against_oracle_on_fresh_inputs_with_default_widths(level):
         if r > worst[1]:
             worst = (k, r)
     assert worst[1] < 2e-3, worst
+
+
+@pytest.mark.parametrize("B,ts_lo,ts_hi,dur_hi,tol", [
+    (1, 2, 2, 2, 5e-3),       # two tokens, three frames: BatchNorm over 2-3 rows is ill-conditioned on both sides
+    (2, 1, 9, 3, 1e-5),       # a one-token utterance beside a longer one
+    (5, 3, 40, 6, 1e-5),      # ragged batch, lengths not multiples of anything
+    (1, 130, 140, 9, 1e-5),   # more than 128 tokens / one long utterance (generic alignment / tile edges)
+])
+def test_ragged_and_extreme_batches_vs_oracle(B, ts_lo, ts_hi, dur_hi, tol):
+    """Train step (forward + losses + backward) on awkward batch shapes: loss and every parameter gradient against
+    the CPU oracle (a single token in train mode is left out: torch's BatchNorm itself refuses one value per channel)."""
+    from fastspeech2_lightning_amd.model import FastSpeech2
+    config = C.small_config(learn_alignment=False)
+    batch = O.synthetic_batch(B=B, ts_lo=ts_lo, ts_hi=ts_hi, n_symbols=C.N_SYMBOLS,
+                              n_mels=config.preprocessing.audio.n_mels, seed=B + ts_hi, dur_hi=dur_hi)
+    model = FastSpeech2(config, Stats(**C.STATS))
+    oracle = O.FastSpeech2Oracle(config, Stats(**C.STATS), n_symbols=C.N_SYMBOLS)
+    sd = O.seeded_state_dict(oracle.state_dict())
+    oracle.load_state_dict(sd)
+    model.load_state_dict(sd)
+    model.train(); oracle.train()
+    model.postnet.dropout_p = 0.0
+    oracle.postnet.dropout_p = 0.0
+    ref_losses = oracle.loss(oracle(batch), batch, 0)
+    ref_losses["total"].backward()
+    total = model.training_step(batch)
+    assert abs(float(total) - float(ref_losses["total"])) < max(tol, 1e-5) * abs(float(ref_losses["total"]))
+    got = model.store.grad_state_dict()
+    gmax = max(float(p.grad.abs().max()) for p in oracle.parameters() if p.grad is not None)
+    for k, p in oracle.named_parameters():
+        if p.grad is not None:
+            assert float((got[k].cpu() - p.grad).abs().max()) < tol * gmax, k
