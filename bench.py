@@ -111,6 +111,8 @@ def main():
                     help="replay the step from a hipGraph (single stream: the side stream for weight-gradient work is "
                          "switched off, graph branches run slower than two eager streams)")
     ap.add_argument("--no-graph", action="store_true", help="(default, kept for old command lines) launch eagerly")
+    ap.add_argument("--refine", action="store_true",
+                    help="second tuner stage: try the next-best GEMM tiles inside the step (+6 s of warm-up; measured gain 0.4 %%)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--learn-alignment", action="store_true",
@@ -178,6 +180,9 @@ def main():
 
     use_graph = args.graph and not args.no_graph and world == 1
     model.env.side_enabled = not use_graph
+    if args.refine and not use_graph:
+        t_ref, n_ref = H.refine_tiles_in_step(step, log=log)
+        log(f"in-step tile refinement: {n_ref} signatures changed, {t_ref:.2f} ms/step")
     graph = None
     if use_graph:
         graph = torch.cuda.CUDAGraph()

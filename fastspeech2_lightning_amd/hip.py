@@ -221,17 +221,61 @@ GEMM_TUNE = True
 GEMM_TILES = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14)  # 1-3: register-staged BK=16 core; 4-9: direct-to-LDS BK=32 core;
 #                                                      10-12: persistent direct-to-LDS core; 13-14: + split tail
 _TILE_CACHE = {}
+#: per signature: [(isolated ms for 4 launches, tile), ...] sorted, and how often the signature was launched --
+#: what ``refine_tiles_in_step`` works from
+_TILE_TIMINGS = {}
+_TILE_CALLS = {}
+
+
+def refine_tiles_in_step(step, rounds: int = 5, candidates: int = 2, top: int = 16, min_gain: float = 0.004,
+                         log=None):
+    """Second tuning stage, run once after warm-up: the per-shape tuner times a GEMM alone, back to back, with its
+    operands warm in the Infinity Cache; inside the step the same launch sees cold outputs and a second stream.  For
+    the ``top`` signatures by time the next-best isolated tiles are therefore tried IN the step (``step()`` = one whole
+    training step, timed over ``rounds`` steps) and kept when the step gets faster by more than ``min_gain``."""
+    def timed():
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(rounds):
+            step()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / rounds
+
+    for v in _TILE_CALLS.values():
+        v[0] = 0
+    step()  # counts launches per signature
+    base = min(timed(), timed())
+    order = sorted((k for k in _TILE_TIMINGS if _TILE_CALLS.get(k, [0])[0] > 0),
+                   key=lambda k: -_TILE_TIMINGS[k][0][0] * _TILE_CALLS[k][0])[:top]
+    changed = 0
+    for key in order:
+        keep = _TILE_CACHE[key]
+        for ms_iso, tile in _TILE_TIMINGS[key][1:1 + candidates]:
+            _TILE_CACHE[key] = tile
+            t = min(timed(), timed())
+            if t < base * (1.0 - min_gain):
+                if log:
+                    log(f"in-step tile refinement {key[:3]}: tile {keep} -> {tile}, step {base:.3f} -> {t:.3f} ms")
+                base, keep, changed = t, tile, changed + 1
+        _TILE_CACHE[key] = keep
+    return base, changed
 
 
 def _tune_tile(a) -> int:
     key = (a.Mc, a.Nc, a.R, a.taps, a.a_kcontig, a.b_kcontig, a.shift_operand, a.splitk, a.epi)
     t = _TILE_CACHE.get(key)
     if t is not None:
+        c = _TILE_CALLS.get(key)
+        if c is not None:
+            c[0] += 1
         return t
     if not GEMM_TUNE or torch.cuda.is_current_stream_capturing():
         return 0
     L, s = lib(), _stream()
     best, best_ms = 0, float("inf")
+    timings = []
     for tile in GEMM_TILES:
         a.tile = tile
         rc = L.fs2hip_gemm(C.byref(a), s)  # warm; -22 = this core/tile does not take the shape
@@ -247,9 +291,13 @@ def _tune_tile(a) -> int:
             e1.record()
             e1.synchronize()
             ms = min(ms, e0.elapsed_time(e1))
+        timings.append((ms, tile))
         if ms < best_ms:
             best, best_ms = tile, ms
     _TILE_CACHE[key] = best
+    if timings:
+        _TILE_TIMINGS[key] = sorted(timings)
+        _TILE_CALLS[key] = [1]
     return best
 
 
