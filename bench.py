@@ -48,10 +48,13 @@ def log(msg):
 T_START = time.perf_counter()
 
 
-def make_config(learn_alignment=False):
+def make_config(learn_alignment=False, gst=False):
     from fastspeech2_lightning_amd.config import FastSpeech2Config
     from fastspeech2_lightning_amd.synthetic import default_symbols
-    return FastSpeech2Config(model=dict(learn_alignment=learn_alignment), text=default_symbols(64))
+    model = dict(learn_alignment=learn_alignment)
+    if gst:  # BASELINE.json configs[4] in fp32: multi-speaker + GST reference encoder, mel up to ~1200 frames
+        model.update(use_global_style_token_module=True, multispeaker=True)
+    return FastSpeech2Config(model=model, text=default_symbols(64))
 
 
 def cpu_baseline(config, batch, sample_B=32, iters=2):
@@ -113,6 +116,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="(default, kept for old command lines) launch eagerly")
     ap.add_argument("--refine", action="store_true",
                     help="second tuner stage: try the next-best GEMM tiles inside the step (+6 s of warm-up; measured gain 0.4 %%)")
+    ap.add_argument("--gst", action="store_true",
+                    help="BASELINE.json configs[4] shape in fp32: multi-speaker (16) + GST style encoder, mel up to ~1200 frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--learn-alignment", action="store_true",
@@ -145,12 +150,15 @@ def main():
     from fastspeech2_lightning_amd.parallel import GradSync
     from fastspeech2_lightning_amd.synthetic import DEFAULT_STATS, synthetic_batch
 
-    config = make_config(args.learn_alignment)
-    model = FastSpeech2(config, Stats(**DEFAULT_STATS), device=f"cuda:{local}", seed=1234)
+    config = make_config(args.learn_alignment, args.gst)
+    spk = {f"spk{i}": i for i in range(16)} if args.gst else None
+    model = FastSpeech2(config, Stats(**DEFAULT_STATS), speaker2id=spk, device=f"cuda:{local}", seed=1234)
     model.train()
     opt = model.configure_optimizers()[0][0]
-    batch = synthetic_batch(B=args.batch, ts_lo=96, ts_hi=128, n_symbols=64, n_mels=80, seed=1234 + rank, dur_hi=9,
-                            learn_alignment=args.learn_alignment)
+    batch = synthetic_batch(B=args.batch, ts_lo=96, ts_hi=128, n_symbols=64, n_mels=80, seed=1234 + rank,
+                            dur_hi=18 if args.gst else 9, learn_alignment=args.learn_alignment)
+    if args.gst:
+        batch["speaker_id"] = torch.arange(args.batch, dtype=torch.int32) % 16
     sync = None
     if world > 1:
         sync = GradSync(model.store)
@@ -287,7 +295,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: fp32 train step, batch=32/GPU, LJSpeech-shaped synthetic "
-                                   "(96-128 phonemes, 80 x ~600 mel), learn_alignment=" + str(args.learn_alignment) + ", dropout on",
+                                   "(96-128 phonemes, 80 x ~600 mel), learn_alignment=" + str(args.learn_alignment) + ", dropout on"
+                                   + (" [--gst: multi-speaker + GST, mel up to ~1200 frames (configs[4] shape, fp32)]" if args.gst else ""),
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "real_frames_per_step": frames_all, "padded_frames_per_step": padded_all,
                        "parallelism": f"dp{world}", "hipgraph": bool(graph is not None), "streams": 2 if model.env.side_enabled else 1,

@@ -91,6 +91,59 @@ __global__ __launch_bounds__(256) void conv2d_s2_bwd_weight_kernel(const float* 
 
 // ---- GRU (nn.GRU gate order r, z, n) ----------------------------------------------------------------
 // gi: rows of stride gi_stride (input projections incl. b_ih of step t), gh [B][3U] (recurrent incl. b_hh)
+// ---- 3x3 stride-2 convolution as GEMM (Cin % 4 == 0): gather the 9 taps of every output pixel into a row of
+// col[B*Ho*Wo][9*Cin] (zero where the window leaves the image), multiply by the weight seen as [9*Cin][Cout] on the
+// MFMA GEMM; backward data is the GEMM dcol = dy W^T followed by the inverse gather (each input pixel belongs to at
+// most four windows).  The direct kernels above reached ~1 TFLOP/s, which made the style encoder 30 % of a
+// configs[4]-shaped step; only the first layer (Cin = 1, 9 MACs per output) still uses them.
+__global__ __launch_bounds__(256) void im2col_s2_kernel(const float* __restrict__ x, float* __restrict__ col, int B,
+                                                         int H, int W, int Cin, int Ho, int Wo) {
+  const int c4n = Cin >> 2;
+  const long long total = (long long)B * Ho * Wo * 9 * c4n;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int c4 = (int)(idx % c4n);
+    long long r = idx / c4n;
+    const int tap = (int)(r % 9);
+    r /= 9;  // output pixel (b, ho, wo)
+    const int wo = (int)(r % Wo);
+    const long long bh = r / Wo;
+    const int ho = (int)(bh % Ho), b = (int)(bh / Ho);
+    const int hi = 2 * ho + tap / 3 - 1, wi = 2 * wo + tap % 3 - 1;
+    float4 v = make_float4(0, 0, 0, 0);
+    if (hi >= 0 && hi < H && wi >= 0 && wi < W)
+      v = *reinterpret_cast<const float4*>(x + (((long long)b * H + hi) * W + wi) * Cin + c4 * 4);
+    *reinterpret_cast<float4*>(col + r * (9LL * Cin) + (long long)tap * Cin + c4 * 4) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void col2im_s2_kernel(const float* __restrict__ dcol, float* __restrict__ dx, int B,
+                                                         int H, int W, int Cin, int Ho, int Wo) {
+  const int c4n = Cin >> 2;
+  const long long total = (long long)B * H * W * c4n;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int c4 = (int)(idx % c4n);
+    long long r = idx / c4n;
+    const int wi = (int)(r % W);
+    const long long bh = r / W;
+    const int hi = (int)(bh % H), b = (int)(bh / H);
+    float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int h2 = hi + 1 - kh;
+      if (h2 < 0 || (h2 & 1) || (h2 >> 1) >= Ho) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int w2 = wi + 1 - kw;
+        if (w2 < 0 || (w2 & 1) || (w2 >> 1) >= Wo) continue;
+        const long long m = ((long long)b * Ho + (h2 >> 1)) * Wo + (w2 >> 1);
+        const float4 v = *reinterpret_cast<const float4*>(dcol + m * (9LL * Cin) + (long long)(kh * 3 + kw) * Cin + c4 * 4);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    }
+    *reinterpret_cast<float4*>(dx + r * Cin + c4 * 4) = acc;
+  }
+}
+
 __global__ void gru_gate_fwd_kernel(const float* __restrict__ gi, long long gi_stride, const float* __restrict__ gh,
                                     const float* __restrict__ hprev, float* __restrict__ hnew, float* __restrict__ gates,
                                     int B, int U) {
@@ -207,6 +260,26 @@ extern "C" int fs2hip_conv2d_s2_bwd_data(const float* dy, const float* w, float*
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   const long long total = (long long)B * H * W * Cin;
   conv2d_s2_bwd_data_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, S_>>>(dy, w, dx, B, H, W, Cin, Ho, Wo, Cout);
+  FS2_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fs2hip_im2col_s2(const float* x, float* col, int B, int H, int W, int Cin, void* stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || ((uintptr_t)x % 16) || ((uintptr_t)col % 16)) return FS2HIP_EINVAL;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  long long blocks = ((long long)B * Ho * Wo * 9 * (Cin >> 2) + 255) / 256;
+  if (blocks > 65535 * 16) blocks = 65535 * 16;
+  im2col_s2_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(x, col, B, H, W, Cin, Ho, Wo);
+  FS2_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fs2hip_col2im_s2(const float* dcol, float* dx, int B, int H, int W, int Cin, void* stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || ((uintptr_t)dx % 16) || ((uintptr_t)dcol % 16)) return FS2HIP_EINVAL;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  long long blocks = ((long long)B * H * W * (Cin >> 2) + 255) / 256;
+  if (blocks > 65535 * 16) blocks = 65535 * 16;
+  col2im_s2_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(dcol, dx, B, H, W, Cin, Ho, Wo);
   FS2_LAUNCH_CHECK();
   return 0;
 }

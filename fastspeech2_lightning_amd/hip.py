@@ -95,6 +95,8 @@ SIGNATURES = {
     "fs2hip_attn_softmax_bwd": "ppppppiiip",
     "fs2hip_attn_dist_bwd": "pppppiiiip",
     "fs2hip_conv2d_s2_fwd": "pppiiiiip",
+    "fs2hip_im2col_s2": "ppiiiip",
+    "fs2hip_col2im_s2": "ppiiiip",
     "fs2hip_conv2d_s2_bwd_data": "pppiiiiip",
     "fs2hip_conv2d_s2_wgrad_parts": "iii",
     "fs2hip_conv2d_s2_bwd_weight": "ppppiiiiip",
@@ -973,9 +975,22 @@ def conv2d_s2_fwd(x, w):
     B, Hh, Ww, Cin = x.shape
     _req(w.shape[:3] == (3, 3, Cin), "conv2d_s2_fwd: weight shape")
     Cout = w.shape[3]
-    y = torch.empty(B, (Hh - 1) // 2 + 1, (Ww - 1) // 2 + 1, Cout, device=x.device, dtype=torch.float32)
+    Ho, Wo = (Hh - 1) // 2 + 1, (Ww - 1) // 2 + 1
+    y = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
+    if Cin % 4 == 0 and Cout % 4 == 0:  # gather the windows, then the MFMA GEMM: y[M, Cout] = col[M, 9 Cin] @ w[9 Cin, Cout]
+        col = _im2col_s2(x)
+        linear_bwd_data(col, w.view(9 * Cin, Cout), out=y.view(B * Ho * Wo, Cout))
+        return y
     _ok(lib().fs2hip_conv2d_s2_fwd(_p(x), _p(w), _p(y), B, Hh, Ww, Cin, Cout, _stream()), "conv2d_s2_fwd")
     return y
+
+
+def _im2col_s2(x):
+    B, Hh, Ww, Cin = x.shape
+    Ho, Wo = (Hh - 1) // 2 + 1, (Ww - 1) // 2 + 1
+    col = torch.empty(B * Ho * Wo, 9 * Cin, device=x.device, dtype=torch.float32)
+    _ok(lib().fs2hip_im2col_s2(_p(x), _p(col), B, Hh, Ww, Cin, _stream()), "im2col_s2")
+    return col
 
 
 def conv2d_s2_bwd(dy, x, w, dw, need_dx=True):
@@ -984,6 +999,17 @@ def conv2d_s2_bwd(dy, x, w, dw, need_dx=True):
     B, Hh, Ww, Cin = x.shape
     Cout = w.shape[3]
     _req(dy.shape == (B, (Hh - 1) // 2 + 1, (Ww - 1) // 2 + 1, Cout) and dw.numel() == w.numel(), "conv2d_s2_bwd: shapes")
+    if Cin % 4 == 0 and Cout % 4 == 0:
+        M = dy.numel() // Cout
+        dy2 = dy.view(M, Cout)
+        col = _im2col_s2(x)  # re-gathered rather than kept since the forward pass: one cheap pass against 9x the input
+        linear_bwd_weight(col, dy2, dw)                  # dw[9 Cin, Cout] = col^T @ dy
+        if not need_dx:
+            return None
+        dcol = linear_fwd(dy2, w.view(9 * Cin, Cout))    # dcol[M, 9 Cin] = dy @ w^T
+        dx = torch.empty_like(x)
+        _ok(lib().fs2hip_col2im_s2(_p(dcol), _p(dx), B, Hh, Ww, Cin, _stream()), "col2im_s2")
+        return dx
     parts = lib().fs2hip_conv2d_s2_wgrad_parts(B, Hh, Ww)
     ws = _workspace(parts * w.numel(), x.device)
     _ok(lib().fs2hip_conv2d_s2_bwd_weight(_p(x), _p(dy), _p(ws), _p(dw), B, Hh, Ww, Cin, Cout, _stream()), "conv2d_s2_bwd_weight")

@@ -247,3 +247,26 @@ def test_duration_round_half_to_even(H, golden_dir):
     logd = torch.log(torch.tensor([0.5, 1.5, 2.5, 3.5, 0.2]) + 1)
     ref = torch.clamp(torch.round(torch.exp(logd) - 1) * 1.7, min=0).int()
     assert torch.equal(H.duration_round(logd.cuda(), 1.7).cpu(), ref)
+
+
+@pytest.mark.parametrize("B,Hh,Ww,Cin,Cout", [(2, 37, 80, 1, 32), (3, 19, 40, 32, 32), (2, 10, 5, 64, 128), (1, 3, 2, 128, 128),
+                                               (2, 8, 6, 6, 10)])
+def test_conv2d_stride2_fwd_bwd(H, B, Hh, Ww, Cin, Cout):
+    """GST reference-encoder convolution (3x3, stride 2, pad 1, no bias, channels-last): the gather + MFMA GEMM route
+    (Cin, Cout multiples of 4) and the direct kernels (first layer / odd widths) against torch's conv2d."""
+    g = torch.Generator().manual_seed(B * 100 + Hh)
+    x = torch.randn(B, Cin, Hh, Ww, generator=g, requires_grad=True)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5).requires_grad_(True)
+    ref = F.conv2d(x, w, stride=2, padding=1)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    xc = x.detach().permute(0, 2, 3, 1).contiguous().cuda()           # [B, H, W, Cin]
+    wc = w.detach().permute(2, 3, 1, 0).contiguous().cuda()           # [kh, kw, Cin, Cout]
+    y = H.conv2d_s2_fwd(xc, wc)
+    assert y.shape == (B, (Hh - 1) // 2 + 1, (Ww - 1) // 2 + 1, Cout)
+    tol = 2e-5 * max(1.0, float(ref.abs().max()))
+    assert float((y.cpu() - ref.detach().permute(0, 2, 3, 1)).abs().max()) < tol
+    dw = torch.empty_like(wc)
+    dx = H.conv2d_s2_bwd(dy.permute(0, 2, 3, 1).contiguous().cuda(), xc, wc, dw)
+    assert float((dx.cpu() - x.grad.permute(0, 2, 3, 1)).abs().max()) < 2e-5 * max(1.0, float(x.grad.abs().max()))
+    assert float((dw.cpu() - w.grad.permute(2, 3, 1, 0)).abs().max()) < 1e-4 * max(1.0, float(w.grad.abs().max()))
