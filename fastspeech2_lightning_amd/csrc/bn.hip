@@ -14,7 +14,9 @@
 
 namespace {
 
-constexpr int CS_ROWS = 32;   // rows per workgroup in the column-statistics passes
+constexpr int CS_ROWS = 32;   // rows per workgroup in the column-statistics passes (more for very tall matrices,
+                              // so that the fp64 finish never walks more than ~2048 partial rows: cs_rows())
+__host__ __device__ inline int cs_rows(int M) { return CS_ROWS * ((M + CS_ROWS * 2048 - 1) / (CS_ROWS * 2048)); }
 
 // thread -> (row lane rl, float4 column c4): tpr = C/4 threads per row, rpi = 256/tpr rows per pass
 struct WideMap {
@@ -26,7 +28,8 @@ __global__ __launch_bounds__(256) void colstats_wide_kernel(const float* __restr
   __shared__ float4 red[2][256];
   const int tid = threadIdx.x;
   const int rl = tid / wm.tpr, c4 = tid - rl * wm.tpr;
-  const int r0 = blockIdx.x * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
+  const int rows = cs_rows(M);
+  const int r0 = blockIdx.x * rows, r1 = min(M, r0 + rows);
   float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
   if (rl < wm.rpi)
     for (int r = r0 + rl; r < r1; r += wm.rpi) {
@@ -137,7 +140,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   __shared__ float4 red[2][256];
   const int tid = threadIdx.x;
   const int rl = tid / wm.tpr, c4 = tid - rl * wm.tpr;
-  const int r0 = blockIdx.x * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
+  const int rows = cs_rows(M);
+  const int r0 = blockIdx.x * rows, r1 = min(M, r0 + rows);
   float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
   if (rl < wm.rpi) {
     const float4 sc = reinterpret_cast<const float4*>(stats)[c4], sh = reinterpret_cast<const float4*>(stats + C)[c4];
@@ -221,7 +225,7 @@ bool wide_ok(int C, WideMap& wm) {
 
 }  // namespace
 
-extern "C" int fs2hip_colstats_parts(int M) { return (M + CS_ROWS - 1) / CS_ROWS; }
+extern "C" int fs2hip_colstats_parts(int M) { return M > 0 ? (M + cs_rows(M) - 1) / cs_rows(M) : 0; }
 
 extern "C" int fs2hip_colstats(const float* y, int M, int C, float* partial, void* stream) {
   WideMap wm;

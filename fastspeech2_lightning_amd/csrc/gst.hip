@@ -116,6 +116,28 @@ __global__ __launch_bounds__(256) void im2col_s2_kernel(const float* __restrict_
   }
 }
 
+// single input channel (the mel itself): rows of 12 floats = 9 taps + 3 zeros, for the weight-gradient GEMM
+__global__ __launch_bounds__(256) void im2col_s2_c1_kernel(const float* __restrict__ x, float* __restrict__ col, int B,
+                                                            int H, int W, int Ho, int Wo) {
+  const long long total = (long long)B * Ho * Wo;
+  for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < total; r += (long long)gridDim.x * 256) {
+    const int wo = (int)(r % Wo);
+    const long long bh = r / Wo;
+    const int ho = (int)(bh % Ho), b = (int)(bh / Ho);
+    float v[12];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int hi = 2 * ho + tap / 3 - 1, wi = 2 * wo + tap % 3 - 1;
+      v[tap] = (hi >= 0 && hi < H && wi >= 0 && wi < W) ? x[((long long)b * H + hi) * W + wi] : 0.f;
+    }
+    v[9] = v[10] = v[11] = 0.f;
+    float4* dst = reinterpret_cast<float4*>(col + r * 12);
+    dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+    dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+    dst[2] = make_float4(v[8], v[9], v[10], v[11]);
+  }
+}
+
 __global__ __launch_bounds__(256) void col2im_s2_kernel(const float* __restrict__ dcol, float* __restrict__ dx, int B,
                                                          int H, int W, int Cin, int Ho, int Wo) {
   const int c4n = Cin >> 2;
@@ -265,8 +287,15 @@ extern "C" int fs2hip_conv2d_s2_bwd_data(const float* dy, const float* w, float*
 }
 
 extern "C" int fs2hip_im2col_s2(const float* x, float* col, int B, int H, int W, int Cin, void* stream) {
-  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || ((uintptr_t)x % 16) || ((uintptr_t)col % 16)) return FS2HIP_EINVAL;
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  if (Cin == 1 && B > 0 && H > 0 && W > 0 && !((uintptr_t)col % 16)) {  // col[M][12]
+    long long nb = ((long long)B * Ho * Wo + 255) / 256;
+    if (nb > 65535 * 16) nb = 65535 * 16;
+    im2col_s2_c1_kernel<<<dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream>>>(x, col, B, H, W, Ho, Wo);
+    FS2_LAUNCH_CHECK();
+    return 0;
+  }
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || ((uintptr_t)x % 16) || ((uintptr_t)col % 16)) return FS2HIP_EINVAL;
   long long blocks = ((long long)B * Ho * Wo * 9 * (Cin >> 2) + 255) / 256;
   if (blocks > 65535 * 16) blocks = 65535 * 16;
   im2col_s2_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(x, col, B, H, W, Cin, Ho, Wo);

@@ -1010,6 +1010,12 @@ def conv2d_s2_bwd(dy, x, w, dw, need_dx=True):
         dx = torch.empty_like(x)
         _ok(lib().fs2hip_col2im_s2(_p(dcol), _p(dx), B, Hh, Ww, Cin, _stream()), "col2im_s2")
         return dx
+    if Cin == 1 and Cout % 4 == 0 and not need_dx:  # first layer: taps padded to 12 columns, gradient rows 0..8
+        M = dy.numel() // Cout
+        col = torch.empty(M, 12, device=x.device, dtype=torch.float32)
+        _ok(lib().fs2hip_im2col_s2(_p(x), _p(col), B, Hh, Ww, 1, _stream()), "im2col_s2")
+        linear_bwd_weight(col, dy.view(M, Cout), dw, n_valid=9)
+        return None
     parts = lib().fs2hip_conv2d_s2_wgrad_parts(B, Hh, Ww)
     ws = _workspace(parts * w.numel(), x.device)
     _ok(lib().fs2hip_conv2d_s2_bwd_weight(_p(x), _p(dy), _p(ws), _p(dw), B, Hh, Ww, Cin, Cout, _stream()), "conv2d_s2_bwd_weight")

@@ -306,7 +306,8 @@ int fs2hip_conv2d_s2_fwd(const float* x, const float* w, float* y, int B, int H,
 int fs2hip_conv2d_s2_bwd_data(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Cout,
                               void* stream);
 /* The same convolution as GEMM operands (Cin % 4 == 0): col[B*Ho*Wo][9*Cin] gathers the 3x3 stride-2 windows (zero
- * outside the image), col2im sums dcol back into dx[B][H][W][Cin].  Weight seen as [9*Cin][Cout]. */
+ * outside the image), col2im sums dcol back into dx[B][H][W][Cin].  Weight seen as [9*Cin][Cout].
+ * im2col with Cin == 1 writes rows of 12 floats (9 taps + 3 zeros) for the first layer's weight gradient. */
 int fs2hip_im2col_s2(const float* x, float* col, int B, int H, int W, int Cin, void* stream);
 int fs2hip_col2im_s2(const float* dcol, float* dx, int B, int H, int W, int Cin, void* stream);
 int fs2hip_conv2d_s2_wgrad_parts(int B, int H, int W);

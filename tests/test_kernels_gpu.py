@@ -267,6 +267,10 @@ def test_conv2d_stride2_fwd_bwd(H, B, Hh, Ww, Cin, Cout):
     tol = 2e-5 * max(1.0, float(ref.abs().max()))
     assert float((y.cpu() - ref.detach().permute(0, 2, 3, 1)).abs().max()) < tol
     dw = torch.empty_like(wc)
+    if Cin == 1:  # the first layer needs no input gradient: its weight gradient takes the padded-gather GEMM route
+        dw1 = torch.empty_like(wc)
+        assert H.conv2d_s2_bwd(dy.permute(0, 2, 3, 1).contiguous().cuda(), xc, wc, dw1, need_dx=False) is None
+        assert float((dw1.cpu() - w.grad.permute(2, 3, 1, 0)).abs().max()) < 1e-4 * max(1.0, float(w.grad.abs().max()))
     dx = H.conv2d_s2_bwd(dy.permute(0, 2, 3, 1).contiguous().cuda(), xc, wc, dw)
     assert float((dx.cpu() - x.grad.permute(0, 2, 3, 1)).abs().max()) < 2e-5 * max(1.0, float(x.grad.abs().max()))
     assert float((dw.cpu() - w.grad.permute(2, 3, 1, 0)).abs().max()) < 1e-4 * max(1.0, float(w.grad.abs().max()))
