@@ -421,18 +421,23 @@ class FastSpeech2(_Base):
             inputs = H.linear_fwd(text, S.p("text_input_layer.weight"))
         else:
             inputs = H.embedding_fwd(text, S.p("text_input_layer.weight"))
+        gst_ctx, style = None, None
+        if self.gst is not None:
+            # fs2/model.py:196-203: a style-reference mel in inference, token 0 in free inference, else the target mel.
+            # The style encoder reads only the mel: it runs on the side stream beside the text encoder (whose
+            # kernels are small and latency-bound) and is joined where its vector is added.
+            ref_mel = batch.get("mel_style_reference")
+            with self.env.side(batch.get("mel"), ref_mel if torch.is_tensor(ref_mel) else None):
+                if inference and torch.is_tensor(ref_mel):
+                    style, _ = self.gst.fwd(self._dev(ref_mel, torch.float32))
+                elif inference and not teacher_forcing:
+                    style = self.gst.condition_on_gst_tokens(B)
+                else:
+                    style, gst_ctx = self.gst.fwd(batch["mel"])
         x = H.add_posenc(inputs, self._table(Ts), src_lens, B, Ts)
         x, enc_ctx = self.encoder.fwd(x, src_lens)
-        gst_ctx = None
         if self.gst is not None:
-            # fs2/model.py:196-203: a style-reference mel in inference, token 0 in free inference, else the target mel
-            ref_mel = batch.get("mel_style_reference")
-            if inference and torch.is_tensor(ref_mel):
-                style, _ = self.gst.fwd(self._dev(ref_mel, torch.float32))
-            elif inference and not teacher_forcing:
-                style = self.gst.condition_on_gst_tokens(B)
-            else:
-                style, gst_ctx = self.gst.fwd(batch["mel"])
+            self.env.join()
             x = H.add_rowvec(x, style, B, Ts)
         if m.multispeaker:
             x = H.add_rowvec(x, H.embedding_fwd(batch["speaker_id"], S.p("speaker_embedding.weight")), B, Ts)
@@ -500,7 +505,8 @@ class FastSpeech2(_Base):
         self._bucket_done(2)
         d, d_text = self.variance_adaptor.bwd(d, g, c["va"])
         if c.get("gst") is not None:
-            self.gst.bwd(self._rowsum(d), c["gst"])
+            with self.env.side(d):  # parameter gradients only: beside the encoder's backward pass
+                self.gst.bwd(self._rowsum(d), c["gst"])
         if m.multispeaker:
             self._rowvec_embedding_bwd("speaker_embedding.weight", c["batch"]["speaker_id"], d)
         if m.multilingual:
