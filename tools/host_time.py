@@ -39,4 +39,4 @@ step()
 pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(22)
+st.sort_stats("cumulative").print_stats(45)
