@@ -160,8 +160,13 @@ def main():
     if args.gst:
         batch["speaker_id"] = torch.arange(args.batch, dtype=torch.int32) % 16
     sync = None
-    if world > 1:
-        sync = GradSync(model.store)
+    force_sync = bool(os.environ.get("FS2_BENCH_FORCE_SYNC"))  # one rank, collectives issued anyway (RCCL call path)
+    if force_sync and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(f"cuda:{local}"))
+    if world > 1 or force_sync:
+        sync = GradSync(model.store, force=force_sync)
         sync.broadcast_parameters(0)
         model.grad_sync = sync
         opt.grad_scale = sync.grad_scale
@@ -317,7 +322,7 @@ def main():
         line["whole_step"] = {"algorithmic_tflop_per_step_per_gpu": round(f_step / 1e12, 4), "achieved_tflops_per_gpu": round(tf, 2),
                               "frac_of_fp32_mfma_peak": round(tf / PEAK_FP32_MFMA_TFLOPS, 4)}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or force_sync:
         dist.destroy_process_group()
 
 

@@ -19,15 +19,16 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, store, process_group=None, world_size: Optional[int] = None):
-        self.store, self.group = store, process_group
+    def __init__(self, store, process_group=None, world_size: Optional[int] = None, force: bool = False):
+        """``force``: issue the collectives even with one rank (exercises the RCCL call path on a one-GPU box)."""
+        self.store, self.group, self.force = store, process_group, force
         self.world = world_size if world_size is not None else dist.get_world_size(process_group)
         self.ranges = store.bucket_ranges()
         self._work = []
 
     def bucket_ready(self, bucket: int):
         """Called by ``FastSpeech2.backward`` right after the last gradient kernel of ``bucket``."""
-        if self.world == 1 or bucket >= len(self.ranges):
+        if (self.world == 1 and not self.force) or bucket >= len(self.ranges):
             return
         s, e = self.ranges[bucket]
         self._work.append(dist.all_reduce(self.store.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
@@ -40,7 +41,7 @@ class GradSync:
 
     def broadcast_parameters(self, src: int = 0):
         """Rank ``src``'s weights and BatchNorm buffers to every rank (start of training)."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         dist.broadcast(self.store.flat, src, group=self.group)
         for b in self.store.buffers.values():

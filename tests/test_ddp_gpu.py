@@ -64,3 +64,51 @@ def test_bucketed_exchange_world2_on_one_gpu():
     for rank, err, nbuckets in res:
         assert nbuckets >= 3
         assert err < 1e-5, (rank, err)
+
+
+def _rccl_single(port, q):
+    import torch.distributed as dist
+    from fastspeech2_lightning_amd.config import Stats
+    from fastspeech2_lightning_amd.model import FastSpeech2
+    from fastspeech2_lightning_amd.parallel import GradSync
+    from oracle import cases as C
+    from oracle import fs2_oracle as O
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda:0"))
+    config = C.small_config(learn_alignment=False)
+    model = FastSpeech2(config, Stats(**C.STATS), seed=1)
+    model.postnet.dropout_p = 0.0
+    model.train()
+    batch = O.synthetic_batch(B=3, ts_lo=6, ts_hi=12, n_symbols=C.N_SYMBOLS, n_mels=config.preprocessing.audio.n_mels,
+                              seed=5, dur_hi=4)
+    model.training_step(batch)
+    torch.cuda.synchronize()
+    want = model.store.grad.clone()
+    sync = GradSync(model.store, force=True)  # one rank, but every bucket goes through RCCL from the side stream
+    sync.broadcast_parameters(0)
+    model.grad_sync = sync
+    model.training_step(batch)
+    sync.wait()
+    torch.cuda.synchronize()
+    q.put(float((model.store.grad - want).abs().max() / want.abs().max()))
+    dist.destroy_process_group()
+
+
+def test_rccl_call_path_with_one_rank():
+    """backend "nccl" (= RCCL) with a single rank: the asynchronous bucket all-reduces issued from the side stream and
+    the wait before the optimizer must leave the gradient unchanged (sum over one rank)."""
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_single, args=(port, q))
+    p.start()
+    err = q.get(timeout=300)
+    p.join(120)
+    assert p.exitcode == 0
+    assert err < 1e-6, err
