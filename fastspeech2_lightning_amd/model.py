@@ -289,6 +289,7 @@ class FastSpeech2(_Base):
         S.add_buffer("position_embedding.inv_freq", 1 / (10000 ** (torch.arange(0.0, d, 2.0) / d)))
         self.encoder = M.Conformer(S, self.env, "encoder.", m.encoder)
         S.next_bucket()
+        self._bucket_va = S._bucket
         self.gst = None
         if m.use_global_style_token_module:
             self.gst = M.StyleEncoder(S, self.env, "gst.", config.preprocessing.audio.n_mels)
@@ -310,6 +311,7 @@ class FastSpeech2(_Base):
         S.next_bucket()
         self.decoder = M.Conformer(S, self.env, "decoder.", m.decoder)
         S.next_bucket()
+        self._bucket_head = S._bucket
         n_mels = config.preprocessing.audio.n_mels
         M.decl_linear(S, "mel_linear.", n_mels, m.decoder.input_dim)
         if m.use_postnet:
@@ -500,9 +502,9 @@ class FastSpeech2(_Base):
         H.linear_bwd_weight(d_out, c["dec_out"], S.g("mel_linear.weight"))
         H.colsum_grad(d_out, S.g("mel_linear.bias"))
         d = H.linear_bwd_data(d_out, S.p("mel_linear.weight"))
-        self._bucket_done(3)
-        d = self.decoder.bwd(d, c["dec"])
-        self._bucket_done(2)
+        self._bucket_done(self._bucket_head)                              # mel head + PostNet
+        d = self.decoder.bwd(d, c["dec"], layer_done=self._bucket_done)   # one bucket per decoder layer but the first
+        self._bucket_done(self.decoder.buckets[0])
         d, d_text = self.variance_adaptor.bwd(d, g, c["va"])
         if c.get("gst") is not None:
             with self.env.side(d):  # parameter gradients only: beside the encoder's backward pass
@@ -511,15 +513,15 @@ class FastSpeech2(_Base):
             self._rowvec_embedding_bwd("speaker_embedding.weight", c["batch"]["speaker_id"], d)
         if m.multilingual:
             self._rowvec_embedding_bwd("language_embedding.weight", c["batch"]["language_id"], d)
-        self._bucket_done(1)
-        d = self.encoder.bwd(d, c["enc"])
+        self._bucket_done(self._bucket_va)                                # variance adaptor, GST, speaker / language
+        d = self.encoder.bwd(d, c["enc"], layer_done=self._bucket_done)
         if d_text is not None:  # the aligner's keys are the raw text embedding (fs2/variance_adaptor.py:254)
             d = H.axpby(d, d_text)
         if self.use_pfs:
             H.linear_bwd_weight(d, c["text"], S.g("text_input_layer.weight"))
         else:
             H.embedding_bwd(c["text"].reshape(-1), d, S.g("text_input_layer.weight"), self.padding_idx)
-        self._bucket_done(0)
+        self._bucket_done(self.encoder.buckets[0])                        # + text embedding
         self.env.join()
         H.flush_grad_reductions()  # single GPU: everything at once, after the join
         self._ctx = self._loss_grads = None

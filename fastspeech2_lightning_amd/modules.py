@@ -306,8 +306,15 @@ class ConformerLayer:
 
 class Conformer:
     def __init__(self, S, env, prefix, cfg):
-        self.layers = [ConformerLayer(S, env, f"{prefix}conformer_layers.{i}.", cfg.input_dim, cfg.feedforward_dim,
-                                      cfg.heads, cfg.conv_kernel_size, cfg.dropout) for i in range(cfg.layers)]
+        """Every layer but the first opens a new gradient bucket (data-parallel exchange granularity): ``buckets[i]``
+        is the bucket layer i's parameters belong to; layer 0 shares the bucket that is open when the stack is declared."""
+        self.layers, self.buckets = [], []
+        for i in range(cfg.layers):
+            if i > 0:
+                S.next_bucket()
+            self.buckets.append(S._bucket)
+            self.layers.append(ConformerLayer(S, env, f"{prefix}conformer_layers.{i}.", cfg.input_dim, cfg.feedforward_dim,
+                                              cfg.heads, cfg.conv_kernel_size, cfg.dropout))
 
     def fwd(self, x, lens):
         saved = []
@@ -316,9 +323,13 @@ class Conformer:
             saved.append(c)
         return x, saved
 
-    def bwd(self, dy, saved):
-        for layer, c in zip(reversed(self.layers), reversed(saved)):
-            dy = layer.bwd(dy, c)
+    def bwd(self, dy, saved, layer_done=None):
+        """``layer_done(bucket)`` is called after the backward of every layer whose bucket is complete with it (all
+        but layer 0, whose bucket also holds what was declared before the stack)."""
+        for i in range(len(self.layers) - 1, -1, -1):
+            dy = self.layers[i].bwd(dy, saved[i])
+            if layer_done is not None and i > 0:
+                layer_done(self.buckets[i])
         return dy
 
 

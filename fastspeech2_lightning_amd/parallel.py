@@ -4,7 +4,7 @@
 The reference gets DDP implicitly from Lightning (``fs2/cli/train.py:33-41``).  Here
 the gradient already lives in one contiguous buffer laid out in forward order, so the backward
 pass -- which completes it from the end towards the beginning -- hands finished slices ("buckets":
-PostNet+mel head, decoder, variance adaptor, encoder+embedding) to an asynchronous sum-all-reduce
+PostNet+mel head, each decoder layer, variance adaptor, each encoder layer (+ embedding)) to an asynchronous sum-all-reduce
 as soon as their last kernel has been enqueued; the collective runs on RCCL's stream underneath the
 remaining backward kernels.  The 1/world_size factor is folded into the clip coefficient of the
 fused optimizer, so no extra pass over the gradient is needed.  BatchNorm statistics stay per rank
