@@ -8,6 +8,7 @@ processed like any other row because the reference does so too (SURVEY.md sectio
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -55,7 +56,7 @@ class Env:
     # backward -> ...) leaves idle in the partial last round of a GEMM and under its small kernels.  ``join()``
     # (bucket boundaries, end of backward) makes the main stream wait for it.  Tensors the side stream reads are
     # kept alive until the join, so the caching allocator cannot hand their memory to the main stream early.
-    side_enabled = True
+    side_enabled = os.environ.get("FS2_SIDE_STREAM", "1") != "0"  # FS2_SIDE_STREAM=0: everything on one stream
 
     def side(self, *tensors):
         """Context manager: run the enclosed launches on the side stream, after everything enqueued so far."""
