@@ -472,6 +472,8 @@ class FastSpeech2(_Base):
         if save:
             self._ctx = dict(text=text, enc=enc_ctx, va=va_ctx, dec=dec_ctx, dec_out=y, post=post_ctx, B=B, Ts=Ts, Tm=Tm,
                              batch=batch, gst=gst_ctx)
+        if self.env.training and self.store.bn_counters.numel():
+            self.store.bn_counters.add_(1)  # every BatchNorm of the model has run once in train mode
         self.env.join()  # variance predictors of a teacher-forced forward ran on the side stream under the decoder
         return {
             "output": output, "postnet_output": postnet_output,

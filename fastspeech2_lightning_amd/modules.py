@@ -142,8 +142,7 @@ class BatchNorm:
         S, p = self.S, self.prefix
         st = H.bn_finalize(partial, nparts, count, S.p(p + "weight"), S.p(p + "bias"), S.b(p + "running_mean"),
                            S.b(p + "running_var"), training=training)
-        if training:
-            S.b(p + "num_batches_tracked").add_(1)
+        # num_batches_tracked is advanced once per training forward for all layers (ParamStore.bn_counters)
         return st
 
     def grads(self):

@@ -154,6 +154,13 @@ class ParamStore:
         self.adam_v = torch.zeros_like(self.flat)
         for name, t in self._buffer_specs:
             self.buffers[name] = t.to(device)
+        # BatchNorm step counters: views of ONE int64 vector, so that a training forward advances all of them with a
+        # single launch (FastSpeech2.forward) instead of one per BatchNorm layer
+        names = [n for n, _ in self._buffer_specs if n.endswith("num_batches_tracked")]
+        self.bn_counters = torch.zeros(len(names), dtype=torch.long, device=device)
+        for i, n in enumerate(names):
+            self.bn_counters[i] = self.buffers[n]
+            self.buffers[n] = self.bn_counters[i]
         self.device = torch.device(device)
         self._pviews, self._gviews = {}, {}
         return self
