@@ -614,6 +614,13 @@ class FastSpeech2(_Base):
         if version < Version("1.2") and level == TargetTrainingTextRepresentationLevel.phonological_features.value:
             raise ValueError("There were breaking changes to the handling of phonological features in version 1.2; "
                              f"your model is version {version}.")
+        if version < Version("1.2"):
+            # fs2/model.py:313-352 re-orders the embedding table of pre-1.2 checkpoints with the parent toolkit's
+            # symbol_sorter / get_symbols_from_checkpoint_symbol_dict, which are not part of the reference repository:
+            # refuse rather than load an embedding table whose row order may not match the symbol table.
+            raise NotImplementedError(
+                f"checkpoint version {version} < 1.2: its text embedding rows follow the old symbol order; upgrade it "
+                "with the reference toolkit (it rewrites text_input_layer.weight) and load the upgraded file")
         return checkpoint
 
     def on_load_checkpoint(self, checkpoint):

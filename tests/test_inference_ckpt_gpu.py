@@ -74,6 +74,8 @@ def test_checkpoint_round_trip(tmp_path):
         model.on_load_checkpoint(bad)
     with pytest.raises(TypeError):
         model.on_load_checkpoint(dict(ckpt, model_info={"name": "HiFiGAN", "version": "1.0"}))
+    with pytest.raises(NotImplementedError):  # pre-1.2: the embedding rows follow the old symbol order (not silently loaded)
+        model.on_load_checkpoint(dict(ckpt, model_info={"name": "FastSpeech2", "version": "1.1"}))
 
 
 @pytest.mark.parametrize("mode", ["token", "style_reference"])
