@@ -192,7 +192,7 @@ def main():
         log(f"warm-up step {i}: {(time.perf_counter() - t_w) * 1e3:.1f} ms")
 
     use_graph = args.graph and not args.no_graph and world == 1
-    model.env.side_enabled = not use_graph
+    model.env.side_enabled = model.env.side_enabled and not use_graph  # (FS2_SIDE_STREAM=0 keeps it off)
     if args.refine and not use_graph:
         t_ref, n_ref = H.refine_tiles_in_step(step, log=log)
         log(f"in-step tile refinement: {n_ref} signatures changed, {t_ref:.2f} ms/step")
