@@ -16,6 +16,17 @@ namespace {
 
 constexpr float NEG_INF = -INFINITY;
 
+// lane i <- lane i-1 (lane 0 gets `fill`) / lane i <- lane i+1 (lane 63 gets `fill`): one DPP move instead of a
+// ds_bpermute round trip through the LDS crossbar -- these sit on the serial critical path of the recursions below
+__device__ __forceinline__ float wave_shr1(float x, float fill) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, x),
+                                                               0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_shl1(float x, float fill) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, x),
+                                                               0x130, 0xf, 0xf, false));
+}
+
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_dist_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                          float* __restrict__ logits, int B, int T1, int T2, int C) {
@@ -221,8 +232,7 @@ __global__ __launch_bounds__(64) void mas_wave_kernel(const float* __restrict__ 
   T1 = T1 < 0 ? 0 : (T1 > Tm ? Tm : T1);
   T2 = T2 < 1 ? 1 : (T2 > Ts ? Ts : T2);
   const float* src = in + (long long)b * Tm * Ts;
-  float* hb = hard + (long long)b * Tm * Ts;
-  for (long long i = lane; i < (long long)Tm * Ts; i += 64) hb[i] = 0.f;
+  float* hb = hard + (long long)b * Tm * Ts;  // zeroed by the launcher (a single wavefront is slow at bulk stores)
   for (int j = lane; j < Ts; j += 64) dur[b * Ts + j] = 0;
   for (int i = lane; i < Tm; i += 64) hard_idx[b * Tm + i] = -1;
   if (T1 == 0) return;
@@ -239,8 +249,9 @@ __global__ __launch_bounds__(64) void mas_wave_kernel(const float* __restrict__ 
 #pragma unroll
     for (int r = 0; r < CH; ++r) {
       const int i = i0 + r;
-      const float xa = (acta && i < T1) ? src[(long long)i * Ts + ja] : 1.f;
-      const float xb = (actb && i < T1) ? src[(long long)i * Ts + jb] : 1.f;
+      const int ii = i < T1 ? i : T1 - 1;  // clamped rows / columns: loads without divergence, values unused when inactive
+      const float xa = src[(long long)ii * Ts + (acta ? ja : 0)];
+      const float xb = src[(long long)ii * Ts + (actb ? jb : 0)];
       na[r] = is_log ? xa : logf(xa);
       nb[r] = is_log ? xb : logf(xb);
     }
@@ -257,12 +268,9 @@ __global__ __launch_bounds__(64) void mas_wave_kernel(const float* __restrict__ 
     for (int r = 0; r < CH; ++r) {
       const int i = i0 + r;
       if (i >= T1) break;  // uniform
-      float la = __shfl_up(pa, 1, 64), lb = __shfl_up(pb, 1, 64);
-      const float a63 = __shfl(pa, 63, 64);
-      if (lane == 0) {
-        la = NEG_INF;  // column 0 has no left neighbour
-        lb = a63;      // column 64's left neighbour is column 63
-      }
+      const float a63 = __shfl(pa, 63, 64);                 // column 64's left neighbour is column 63
+      const float la = wave_shr1(pa, NEG_INF);              // column 0 has no left neighbour
+      const float lb = wave_shr1(pb, a63);
       const bool left_a = acta && ja > 0 && la >= pa;  // fs2/attn/alignment.py:68 (ties move left)
       const bool left_b = actb && lb >= pb;
       const float xa = va[r] + fmaxf(la, pa), xb = vb[r] + fmaxf(lb, pb);
@@ -324,6 +332,9 @@ __global__ void avg_variance_kernel(const float* __restrict__ var, const int* __
 // CTC (fs2/attn/attention_loss.py:22-62): classes 0 = blank (logit -1), k+1 = key k (attn_logprob, or -1e15
 // beyond key_len); log_softmax over classes; targets 1..L; loss_b = nll_b / max(L, 1); mean over the batch.
 // One workgroup per utterance; extended states s = 0..2L (even = blank, odd s = label (s+1)/2).
+// (A one-wavefront-per-utterance version with five states per lane was measured at 1.6 ms against 1.4 ms for this
+// kernel: the recursion is bound by the instruction count of a single wavefront, not by the barrier.  It was dropped;
+// in a training step this kernel runs on the side stream under the decoder.)
 __device__ __forceinline__ float lse2(float a, float b) {
   const float m = fmaxf(a, b);
   return m == NEG_INF ? NEG_INF : m + logf(expf(a - m) + expf(b - m));
@@ -420,211 +431,6 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logp
     cur ^= 1;
   }
   (void)red;
-}
-
-// ---- the same recursion with ONE wavefront per utterance (texts of at most 128 tokens) -----------------------------
-// Lane l owns the extended states 5l .. 5l+4 in registers; the two left (alpha) / right (beta) neighbours of its edge
-// states come by lane shift, so a time step is ~15 exp/log evaluations and two shuffles per lane -- no LDS exchange, no
-// workgroup barrier, and the step's inputs (at most three key log-probabilities per lane, the row's log-sum-exp, for
-// the backward sweep the stored alphas) are fetched a chunk of steps ahead.  The row log-sum-exps come from a
-// separate, fully parallel kernel.  exp / log use the hardware approximations (1 ulp on values in [0, 1] / [1, 3]),
-// far below the rounding of the ~-1000-sized running sums themselves.
-__global__ __launch_bounds__(256) void ctc_row_lse_kernel(const float* __restrict__ logprob, const int* __restrict__ key_lens,
-                                                           const int* __restrict__ query_lens, float* __restrict__ lse_ws,
-                                                           float blank_logit, int B, int Tm, int Ts) {
-  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (row >= (long long)B * Tm) return;
-  const int b = (int)(row / Tm), t = (int)(row % Tm);
-  int T = query_lens[b], L = key_lens[b];
-  T = T > Tm ? Tm : T;
-  L = L > Ts ? Ts : L;
-  if (t >= T || L <= 0) return;
-  const float* z = logprob + row * Ts;
-  float m = blank_logit;
-  for (int k = lane; k < L; k += 64) m = fmaxf(m, z[k]);
-  m = fs2_wave_max(m);
-  float sum = lane == 0 ? expf(blank_logit - m) : 0.f;
-  for (int k = lane; k < L; k += 64) sum += expf(z[k] - m);
-  sum = fs2_wave_sum(sum);
-  if (lane == 0) lse_ws[row] = m + logf(sum);
-}
-
-__device__ __forceinline__ float lse3_fast(float a, float b, float c) {
-  const float m = fmaxf(fmaxf(a, b), c);
-  return m == NEG_INF ? NEG_INF : m + __logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
-}
-
-__global__ __launch_bounds__(64) void ctc_wave_kernel(const float* __restrict__ logprob, const int* __restrict__ key_lens,
-                                                       const int* __restrict__ query_lens, float* __restrict__ alpha_ws,
-                                                       const float* __restrict__ lse_ws, float* __restrict__ nll_out,
-                                                       float* __restrict__ dlogprob, float weight, float blank_logit,
-                                                       int B, int Tm, int Ts) {
-  constexpr int PER = 5, CH = 4;
-  const int b = blockIdx.x, lane = threadIdx.x;
-  int T = query_lens[b], L = key_lens[b];
-  T = T > Tm ? Tm : T;
-  L = L > Ts ? Ts : L;
-  const int S = 2 * L + 1, Smax = 2 * Ts + 1;
-  const float* z = logprob + (long long)b * Tm * Ts;
-  float* alpha = alpha_ws + (long long)b * Tm * Smax;
-  const float* lse = lse_ws + (long long)b * Tm;
-  float* dz = dlogprob ? dlogprob + (long long)b * Tm * Ts : nullptr;
-  if (dz)
-    for (long long i = lane; i < (long long)Tm * Ts; i += 64) dz[i] = 0.f;
-  if (T <= 0 || L <= 0) {
-    if (lane == 0) nll_out[b] = 0.f;
-    return;
-  }
-  const int s0 = PER * lane;            // first state of this lane
-  const int k0 = s0 >> 1;               // first key any of its odd states refers to
-  const int par = s0 & 1;
-  // state i of the lane: odd (a label) iff ((s0 + i) & 1); its key is k0 + ((par + i) >> 1)
-  auto lp_of = [&](int i, const float (&zk)[3], float row_lse) -> float {
-    const int s = s0 + i;
-    if (s >= S) return NEG_INF;
-    return ((s & 1) ? zk[(par + i) >> 1] : blank_logit) - row_lse;
-  };
-  auto load_row = [&](int t, float (&zk)[3], float& row_lse) {
-    const bool ok = t >= 0 && t < T;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) zk[j] = (ok && k0 + j < L) ? z[(long long)t * Ts + k0 + j] : NEG_INF;
-    row_lse = ok ? lse[t] : 0.f;
-  };
-
-  // ---- alpha sweep -------------------------------------------------------------------------------------------------
-  float a[PER];
-  float zc[CH][3], lc[CH], zn[CH][3], ln[CH];
-  {
-    float zk[3], rl;
-    load_row(0, zk, rl);
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int s = s0 + i;
-      a[i] = (s == 0 || s == 1) ? lp_of(i, zk, rl) : NEG_INF;
-      if (s < S) alpha[s] = a[i];
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < CH; ++r) load_row(1 + r, zn[r], ln[r]);
-  for (int t0 = 1; t0 < T; t0 += CH) {
-#pragma unroll
-    for (int r = 0; r < CH; ++r) {
-      lc[r] = ln[r];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) zc[r][j] = zn[r][j];
-    }
-#pragma unroll
-    for (int r = 0; r < CH; ++r) load_row(t0 + CH + r, zn[r], ln[r]);
-#pragma unroll
-    for (int r = 0; r < CH; ++r) {
-      const int t = t0 + r;
-      if (t >= T) break;  // uniform
-      float l4 = __shfl_up(a[4], 1, 64), l3 = __shfl_up(a[3], 1, 64);
-      if (lane == 0) l4 = l3 = NEG_INF;
-      float n[PER];
-#pragma unroll
-      for (int i = 0; i < PER; ++i) {
-        const int s = s0 + i;
-        const float a1 = i >= 1 ? a[i - 1] : l4;
-        const float a2raw = i >= 2 ? a[i - 2] : (i == 1 ? l4 : l3);
-        const float a2 = ((s & 1) && s >= 3) ? a2raw : NEG_INF;
-        n[i] = s < S ? lse3_fast(a[i], a1, a2) + lp_of(i, zc[r], lc[r]) : NEG_INF;
-      }
-#pragma unroll
-      for (int i = 0; i < PER; ++i) {
-        a[i] = n[i];
-        if (s0 + i < S) alpha[(long long)t * Smax + s0 + i] = n[i];
-      }
-    }
-  }
-  // log-likelihood = lse(alpha_T[S-1], alpha_T[S-2]): fetch both from their lanes
-  const float aS1 = __shfl(a[(S - 1) % PER], (S - 1) / PER, 64);
-  const float aS2 = S >= 2 ? __shfl(a[(S - 2) % PER], (S - 2) / PER, 64) : NEG_INF;
-  const float ll = lse2(aS1, aS2);
-  const float nll = -ll;
-  const bool inf = !(nll < INFINITY);  // zero_infinity=True
-  if (lane == 0) nll_out[b] = inf ? 0.f : nll / (float)(L > 1 ? L : 1);
-  if (!dz || inf) return;
-  const float scale = weight / ((float)(L > 1 ? L : 1) * (float)B);
-
-  // ---- beta sweep + gradient ---------------------------------------------------------------------------------------
-  float bt[PER];
-  {
-    float zk[3], rl;
-    load_row(T - 1, zk, rl);
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int s = s0 + i;
-      bt[i] = (s == S - 1 || s == S - 2) ? lp_of(i, zk, rl) : NEG_INF;
-    }
-  }
-  float ac[CH][PER], an[CH][PER];
-  auto load_alpha = [&](int t, float (&dst)[PER]) {
-#pragma unroll
-    for (int i = 0; i < PER; ++i) dst[i] = (t >= 0 && t < T && s0 + i < S) ? alpha[(long long)t * Smax + s0 + i] : NEG_INF;
-  };
-  // chunk r = 0 is time t, r = 1 is t - 1, ...
-#pragma unroll
-  for (int r = 0; r < CH; ++r) {
-    load_row(T - 1 - r, zn[r], ln[r]);
-    load_alpha(T - 1 - r, an[r]);
-  }
-  for (int t0 = T - 1; t0 >= 0; t0 -= CH) {
-#pragma unroll
-    for (int r = 0; r < CH; ++r) {
-      lc[r] = ln[r];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) zc[r][j] = zn[r][j];
-#pragma unroll
-      for (int i = 0; i < PER; ++i) ac[r][i] = an[r][i];
-    }
-#pragma unroll
-    for (int r = 0; r < CH; ++r) {
-      load_row(t0 - CH - r, zn[r], ln[r]);
-      load_alpha(t0 - CH - r, an[r]);
-    }
-#pragma unroll
-    for (int r = 0; r < CH; ++r) {
-      const int t = t0 - r;
-      if (t < 0) break;  // uniform
-      // gradient of the key classes at time t (beta of time t is in bt)
-#pragma unroll
-      for (int i = 0; i < PER; ++i) {
-        const int s = s0 + i;
-        if ((s & 1) && s < S) {
-          const float l = lp_of(i, zc[r], lc[r]);
-          dz[(long long)t * Ts + (s >> 1)] = scale * (__expf(l) - __expf(ac[r][i] + bt[i] + nll - l));
-        }
-      }
-      if (t == 0) break;
-      // beta of time t - 1: row t - 1 is chunk entry r + 1 (or the first entry of the next chunk)
-      float r0 = __shfl_down(bt[0], 1, 64), r1 = __shfl_down(bt[1], 1, 64);
-      if (lane == 63) r0 = r1 = NEG_INF;
-      float zk[3], rl;
-      if (r + 1 < CH) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) zk[j] = zc[r + 1][j];
-        rl = lc[r + 1];
-      } else {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) zk[j] = zn[0][j];
-        rl = ln[0];
-      }
-      float n[PER];
-#pragma unroll
-      for (int i = 0; i < PER; ++i) {
-        const int s = s0 + i;
-        const float b1raw = i + 1 < PER ? bt[i + 1] : r0;
-        const float b2raw = i + 2 < PER ? bt[i + 2] : (i + 2 == PER ? r0 : r1);
-        const float b1 = s + 1 < S ? b1raw : NEG_INF;
-        const float b2 = ((s & 1) && s + 2 < S) ? b2raw : NEG_INF;
-        n[i] = s < S ? lse3_fast(bt[i], b1, b2) + lp_of(i, zk, rl) : NEG_INF;
-      }
-#pragma unroll
-      for (int i = 0; i < PER; ++i) bt[i] = n[i];
-    }
-  }
 }
 
 // loss = weight * mean_b(nll_b)  (nll_b already divided by the target length)
@@ -763,6 +569,7 @@ extern "C" int fs2hip_mas(const float* in, int is_log, const int* in_lens, const
                           int* hard_idx, int* dur, unsigned* dirs_ws, int B, int Tm, int Ts, void* stream) {
   if (B <= 0 || Tm <= 0 || Ts <= 0) return FS2HIP_EINVAL;
   if (Ts <= 128 && (size_t)Tm * 16 <= 60 * 1024) {  // one wavefront per utterance, everything on chip
+    if (hipMemsetAsync(hard, 0, (size_t)B * Tm * Ts * sizeof(float), S_) != hipSuccess) return FS2HIP_EINVAL;
     mas_wave_kernel<<<dim3(B), dim3(64), (size_t)Tm * 16, S_>>>(in, is_log, in_lens, out_lens, hard, hard_idx, dur, B, Tm, Ts);
     FS2_LAUNCH_CHECK();
     return 0;
@@ -794,17 +601,6 @@ extern "C" int fs2hip_attn_ctc_loss(const float* logprob, const int* key_lens, c
                                     float* lse_ws, float* nll_ws, float* dlogprob, float weight, float* loss_out, int B,
                                     int Tm, int Ts, void* stream) {
   if (B <= 0 || Tm <= 0 || Ts <= 0) return FS2HIP_EINVAL;
-  if (Ts <= 128) {  // one wavefront per utterance (5 extended states per lane)
-    ctc_row_lse_kernel<<<dim3((unsigned)(((long long)B * Tm + 3) / 4)), dim3(256), 0, S_>>>(logprob, key_lens, query_lens,
-                                                                                         lse_ws, -1.0f, B, Tm, Ts);
-    FS2_LAUNCH_CHECK();
-    ctc_wave_kernel<<<dim3(B), dim3(64), 0, S_>>>(logprob, key_lens, query_lens, alpha_ws, lse_ws, nll_ws, dlogprob, weight,
-                                                  -1.0f, B, Tm, Ts);
-    FS2_LAUNCH_CHECK();
-    ctc_finish_kernel<<<dim3(1), dim3(64), 0, S_>>>(nll_ws, B, weight, loss_out);
-    FS2_LAUNCH_CHECK();
-    return 0;
-  }
   const size_t smem = (size_t)(2 * (2 * Ts + 1) + 4) * sizeof(float);
   if (smem > 64 * 1024) return FS2HIP_EINVAL;
   ctc_kernel<<<dim3(B), dim3(256), smem, S_>>>(logprob, key_lens, query_lens, alpha_ws, lse_ws, nll_ws, dlogprob, weight,
