@@ -238,7 +238,7 @@ extern "C" int fs2hip_gemm(const Fs2GemmArgs* args, void* stream) {
                         ((long long)((a.Mc + 127) / 128) * ((a.Nc + 127) / 128) * nz < 384);
     // conv taps that core v2 cannot keep uniform per K-tile run on its generic-decode kernel (tile 7 only)
     const bool odd_taps = a.taps > 1 && (a.shift_operand == 0 ? (p.Rper % 32) != 0 : a.T < 32);
-    tile = v2_ok ? (odd_taps ? (v1_ok ? 3 : 7) : (narrow ? 5 : 4)) : (narrow ? 2 : 1);
+    tile = v2_ok ? (odd_taps ? (v1_ok && !a.operand_bf16 ? 3 : 7) : (narrow ? 5 : 4)) : (narrow ? 2 : 1);  // (core v1 is fp32 only)
   }
   if (tile >= 4) {
     if (!v2_ok) return FS2HIP_EINVAL;

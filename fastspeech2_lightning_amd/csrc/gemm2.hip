@@ -19,7 +19,7 @@
 #include "gemm2_core.h"
 namespace {
 
-template <int BM, int BN, bool AKC, bool BKC, int NST, int TAPS>
+template <int BM, int BN, bool AKC, bool BKC, int NST, int TAPS, bool BF>
 __global__ __launch_bounds__(256) void gemm2_kernel(GemmP p) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int A_TILE = BM * BK2, B_TILE = BN * BK2, STAGE = A_TILE + B_TILE;
@@ -91,11 +91,18 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmP p) {
     else wait_vmcnt_barrier<0>();
     if (kt + NST - 1 < nkt) issue(kt + NST - 1, stage == 0 ? NST - 1 : stage - 1);  // the stage read in iteration kt-1
     const unsigned sa = lds0 + stage * (STAGE * 4), sb = sa + A_TILE * 4;
-    compute_ktile<BM, BN, AKC, BKC>(acc, rda, rdb, sa, sb);
+    compute_ktile_any<BF, BM, BN, AKC, BKC>(acc, rda, rdb, sa, sb);
     stage = stage + 1 == NST ? 0 : stage + 1;
   }
   gemm_epilogue<BM, BN>(p, acc, m0, n0, wm, wn, lane, split, tapz);
 }
+
+// fp32 or bf16-operand instance of one kernel shape
+#define FS2_GO(AKC_, BKC_, TAPS_)                                                          \
+  do {                                                                                     \
+    if (a.operand_bf16) gemm2_kernel<BM, BN, AKC_, BKC_, NST, TAPS_, true><<<grid, block, 0, s>>>(p);  \
+    else gemm2_kernel<BM, BN, AKC_, BKC_, NST, TAPS_, false><<<grid, block, 0, s>>>(p);    \
+  } while (0)
 
 template <int BM, int BN, int NST, bool GENERIC_TOO>
 int launch_tile(GemmP& p, int nz, hipStream_t s) {
@@ -110,24 +117,24 @@ int launch_tile(GemmP& p, int nz, hipStream_t s) {
   }
   if (mode == TAPS_GENERIC) {
     if constexpr (GENERIC_TOO) {
-      if (a.a_kcontig && a.b_kcontig) gemm2_kernel<BM, BN, true, true, NST, TAPS_GENERIC><<<grid, block, 0, s>>>(p);
-      else if (a.a_kcontig) gemm2_kernel<BM, BN, true, false, NST, TAPS_GENERIC><<<grid, block, 0, s>>>(p);
-      else if (!a.b_kcontig) gemm2_kernel<BM, BN, false, false, NST, TAPS_GENERIC><<<grid, block, 0, s>>>(p);
+      if (a.a_kcontig && a.b_kcontig) FS2_GO(true, true, TAPS_GENERIC);
+      else if (a.a_kcontig) FS2_GO(true, false, TAPS_GENERIC);
+      else if (!a.b_kcontig) FS2_GO(false, false, TAPS_GENERIC);
       else return FS2HIP_EINVAL;
     } else {
       return FS2HIP_EINVAL;  // odd tap widths: only the 64x64 2-stage tile carries the generic decode
     }
   } else if (a.a_kcontig && a.b_kcontig) {  // forward: taps only as TAPS_RED
-    if (mode == TAPS_RED) gemm2_kernel<BM, BN, true, true, NST, TAPS_RED><<<grid, block, 0, s>>>(p);
-    else if (mode == TAPS_NONE) gemm2_kernel<BM, BN, true, true, NST, TAPS_NONE><<<grid, block, 0, s>>>(p);
+    if (mode == TAPS_RED) FS2_GO(true, true, TAPS_RED);
+    else if (mode == TAPS_NONE) FS2_GO(true, true, TAPS_NONE);
     else return FS2HIP_EINVAL;
   } else if (a.a_kcontig && !a.b_kcontig) {  // backward data
-    if (mode == TAPS_RED) gemm2_kernel<BM, BN, true, false, NST, TAPS_RED><<<grid, block, 0, s>>>(p);
-    else if (mode == TAPS_NONE) gemm2_kernel<BM, BN, true, false, NST, TAPS_NONE><<<grid, block, 0, s>>>(p);
+    if (mode == TAPS_RED) FS2_GO(true, false, TAPS_RED);
+    else if (mode == TAPS_NONE) FS2_GO(true, false, TAPS_NONE);
     else return FS2HIP_EINVAL;
   } else if (!a.a_kcontig && !a.b_kcontig) {  // weight gradient
-    if (mode == TAPS_ROWS) gemm2_kernel<BM, BN, false, false, NST, TAPS_ROWS><<<grid, block, 0, s>>>(p);
-    else if (mode == TAPS_NONE) gemm2_kernel<BM, BN, false, false, NST, TAPS_NONE><<<grid, block, 0, s>>>(p);
+    if (mode == TAPS_ROWS) FS2_GO(false, false, TAPS_ROWS);
+    else if (mode == TAPS_NONE) FS2_GO(false, false, TAPS_NONE);
     else return FS2HIP_EINVAL;
   } else {
     return FS2HIP_EINVAL;
@@ -135,6 +142,8 @@ int launch_tile(GemmP& p, int nz, hipStream_t s) {
   FS2_LAUNCH_CHECK();
   return 0;
 }
+
+#undef FS2_GO
 
 }  // namespace
 

@@ -363,4 +363,59 @@ __device__ __forceinline__ void compute_ktile(f32x16 (&acc)[BM / 64][BN / 64], c
 #undef FS2_GROUP
 }
 
+// "bf16-mixed" operands (Fs2GemmArgs.operand_bf16): the same fp32 LDS images and the same reads, but two
+// reduction groups (lane half h: k = 8g+4h..+3 for g = 2P, 2P+1) are rounded to eight bf16 and go through ONE
+// v_mfma_f32_32x32x16_bf16 (8 passes) instead of eight v_mfma_f32_32x32x2_f32 (16 passes each).  A and B use the
+// same (g, h, j) -> k-slot map, so the k order inside the instruction is again irrelevant.  At this MFMA rate
+// the K-tile is bound by its LDS traffic, so all reads of the tile are issued at once and waited for in halves.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+template <int T, bool KC>
+__device__ __forceinline__ bf16x8 frag_bf16(const Frag<T, KC>& lo, const Frag<T, KC>& hi, int i) {
+  const f32x8 v = {lo.get(i, 0), lo.get(i, 1), lo.get(i, 2), lo.get(i, 3), hi.get(i, 0), hi.get(i, 1), hi.get(i, 2), hi.get(i, 3)};
+  return __builtin_convertvector(v, bf16x8);  // v_cvt_pk_bf16_f32, round to nearest even
+}
+
+template <int BM, int BN, bool AKC, bool BKC>
+__device__ __forceinline__ void compute_ktile_bf16(f32x16 (&acc)[BM / 64][BN / 64], const RdAddr<BM, AKC>& rda,
+                                                   const RdAddr<BN, BKC>& rdb, unsigned sa, unsigned sb) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  Frag<TM, AKC> fa[4];
+  Frag<TN, BKC> fb[4];
+  constexpr int RD = Frag<TM, AKC>::READS + Frag<TN, BKC>::READS;
+  frag_read<0, BM>(fa[0], rda, sa);
+  frag_read<0, BN>(fb[0], rdb, sb);
+  frag_read<1, BM>(fa[1], rda, sa);
+  frag_read<1, BN>(fb[1], rdb, sb);
+  frag_read<2, BM>(fa[2], rda, sa);
+  frag_read<2, BN>(fb[2], rdb, sb);
+  frag_read<3, BM>(fa[3], rda, sa);
+  frag_read<3, BN>(fb[3], rdb, sb);
+#define FS2_PAIR(P, WAIT)                                                                                   \
+  {                                                                                                          \
+    lds_wait<WAIT>();                                                                                        \
+    fa[2 * P].pin_all();                                                                                     \
+    fa[2 * P + 1].pin_all();                                                                                 \
+    fb[2 * P].pin_all();                                                                                     \
+    fb[2 * P + 1].pin_all();                                                                                 \
+    bf16x8 ua[TM], ub[TN];                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) ua[i] = frag_bf16(fa[2 * P], fa[2 * P + 1], i);           \
+    _Pragma("unroll") for (int jn = 0; jn < TN; ++jn) ub[jn] = frag_bf16(fb[2 * P], fb[2 * P + 1], jn);      \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                           \
+    _Pragma("unroll") for (int jn = 0; jn < TN; ++jn)                                                        \
+        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua[i], ub[jn], acc[i][jn], 0, 0, 0);            \
+  }
+  FS2_PAIR(0, 2 * RD)
+  FS2_PAIR(1, 0)
+#undef FS2_PAIR
+}
+
+template <bool BF, int BM, int BN, bool AKC, bool BKC>
+__device__ __forceinline__ void compute_ktile_any(f32x16 (&acc)[BM / 64][BN / 64], const RdAddr<BM, AKC>& rda,
+                                                  const RdAddr<BN, BKC>& rdb, unsigned sa, unsigned sb) {
+  if constexpr (BF) compute_ktile_bf16<BM, BN, AKC, BKC>(acc, rda, rdb, sa, sb);
+  else compute_ktile<BM, BN, AKC, BKC>(acc, rda, rdb, sa, sb);
+}
+
 }  // namespace

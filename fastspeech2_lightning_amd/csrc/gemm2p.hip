@@ -67,7 +67,7 @@ __device__ __forceinline__ Unit decode_unit(const GemmP& p, const Hybrid& hy, in
   return q;
 }
 
-template <int BM, int BN, bool AKC, bool BKC, int TAPS>
+template <int BM, int BN, bool AKC, bool BKC, int TAPS, bool BF>
 __global__ __launch_bounds__(256) void gemm2p_kernel(GemmP p, Hybrid hy, int nunits, int tiles) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int A_TILE = BM * BK2, B_TILE = BN * BK2, STAGE = A_TILE + B_TILE;
@@ -132,12 +132,12 @@ __global__ __launch_bounds__(256) void gemm2p_kernel(GemmP p, Hybrid hy, int nun
   for (int u_c = blockIdx.x; u_c < nunits; u_c += G) {
     const Unit uc = decode_unit(p, hy, u_c, nunits, tiles, BM, BN);
     clear();
-    compute_ktile<BM, BN, AKC, BKC>(acc, rda, rdb, lds0 + stage * (STAGE * 4), lds0 + stage * (STAGE * 4) + A_TILE * 4);
+    compute_ktile_any<BF, BM, BN, AKC, BKC>(acc, rda, rdb, lds0 + stage * (STAGE * 4), lds0 + stage * (STAGE * 4) + A_TILE * 4);
     stage ^= 1;
     for (int kt = 1; kt < uc.nkt; ++kt) {
       wait_vmcnt_barrier<0>();  // this K-tile has landed for everybody; the other stage is no longer read
       produce(stage ^ 1);
-      compute_ktile<BM, BN, AKC, BKC>(acc, rda, rdb, lds0 + stage * (STAGE * 4), lds0 + stage * (STAGE * 4) + A_TILE * 4);
+      compute_ktile_any<BF, BM, BN, AKC, BKC>(acc, rda, rdb, lds0 + stage * (STAGE * 4), lds0 + stage * (STAGE * 4) + A_TILE * 4);
       stage ^= 1;
     }
     if (u_c + G < nunits) {  // first K-tile of the next unit: its sync and the following DMA go ahead of the
@@ -151,6 +151,12 @@ __global__ __launch_bounds__(256) void gemm2p_kernel(GemmP p, Hybrid hy, int nun
       gemm_epilogue<BM, BN>(p, acc, uc.m0, uc.n0, wm, wn, lane, uc.split, uc.tapz);
   }
 }
+
+#define FS2_GO(AKC_, BKC_, TAPS_)                                                                             \
+  do {                                                                                                        \
+    if (a.operand_bf16) gemm2p_kernel<BM, BN, AKC_, BKC_, TAPS_, true><<<grid, block, 0, s>>>(p, hy, nunits, tiles);  \
+    else gemm2p_kernel<BM, BN, AKC_, BKC_, TAPS_, false><<<grid, block, 0, s>>>(p, hy, nunits, tiles);        \
+  } while (0)
 
 template <int BM, int BN, int WG_PER_CU, bool SPLIT_TAIL>
 int launch_persistent(GemmP& p, int nz, hipStream_t s) {
@@ -202,16 +208,16 @@ int launch_persistent(GemmP& p, int nz, hipStream_t s) {
   }
   if (mode == TAPS_GENERIC) return FS2HIP_EINVAL;  // odd tap widths: gemm2.hip tile 7
   if (a.a_kcontig && a.b_kcontig) {
-    if (mode == TAPS_RED) gemm2p_kernel<BM, BN, true, true, TAPS_RED><<<grid, block, 0, s>>>(p, hy, nunits, tiles);
-    else if (mode == TAPS_NONE) gemm2p_kernel<BM, BN, true, true, TAPS_NONE><<<grid, block, 0, s>>>(p, hy, nunits, tiles);
+    if (mode == TAPS_RED) FS2_GO(true, true, TAPS_RED);
+    else if (mode == TAPS_NONE) FS2_GO(true, true, TAPS_NONE);
     else return FS2HIP_EINVAL;
   } else if (a.a_kcontig && !a.b_kcontig) {
-    if (mode == TAPS_RED) gemm2p_kernel<BM, BN, true, false, TAPS_RED><<<grid, block, 0, s>>>(p, hy, nunits, tiles);
-    else if (mode == TAPS_NONE) gemm2p_kernel<BM, BN, true, false, TAPS_NONE><<<grid, block, 0, s>>>(p, hy, nunits, tiles);
+    if (mode == TAPS_RED) FS2_GO(true, false, TAPS_RED);
+    else if (mode == TAPS_NONE) FS2_GO(true, false, TAPS_NONE);
     else return FS2HIP_EINVAL;
   } else if (!a.a_kcontig && !a.b_kcontig) {
-    if (mode == TAPS_ROWS) gemm2p_kernel<BM, BN, false, false, TAPS_ROWS><<<grid, block, 0, s>>>(p, hy, nunits, tiles);
-    else if (mode == TAPS_NONE) gemm2p_kernel<BM, BN, false, false, TAPS_NONE><<<grid, block, 0, s>>>(p, hy, nunits, tiles);
+    if (mode == TAPS_ROWS) FS2_GO(false, false, TAPS_ROWS);
+    else if (mode == TAPS_NONE) FS2_GO(false, false, TAPS_NONE);
     else return FS2HIP_EINVAL;
   } else {
     return FS2HIP_EINVAL;
@@ -220,6 +226,8 @@ int launch_persistent(GemmP& p, int nz, hipStream_t s) {
   if (hy.S) return fs2_tail_fixup(hy.ws, hy.S, hy.slab, a.C, a.ldc, a.bias, a.alpha, hy.m_tail0, a.Mc, a.Nc, s);
   return 0;
 }
+
+#undef FS2_GO
 
 }  // namespace
 

@@ -39,6 +39,7 @@ class GemmArgs(C.Structure):
         ("out_pre", C.c_void_p), ("ldpre", C.c_int),
         ("drop_p", C.c_float), ("drop_seed", C.c_ulonglong), ("drop_step", C.c_void_p),
         ("splitk", C.c_int), ("workspace", C.c_void_p), ("tile", C.c_int), ("workspace_floats", C.c_longlong),
+        ("operand_bf16", C.c_int),
     ]
 
 
@@ -220,6 +221,24 @@ GEMM_PROFILE = None
 #: a few launches with HIP events) the first time it is launched outside a graph capture; the launch
 #: is idempotent (outputs are only overwritten), so re-running it for timing is safe.
 GEMM_TUNE = True
+#: "bf16-mixed": every algorithmic GEMM rounds its operands to bf16 in registers (v_mfma_f32_32x32x16_bf16, fp32
+#: accumulate / epilogue / storage).  Set through ``set_precision``; the fp32 path is the parity path and the default.
+GEMM_BF16 = False
+PRECISIONS = {"32-true": False, "32": False, "fp32": False, "bf16-mixed": True, "bf16": True}
+
+
+def set_precision(precision) -> None:
+    """Mirror of Lightning's ``Trainer(precision=...)`` for this path: "32-true" (default) or "bf16-mixed"."""
+    global GEMM_BF16
+    key = str(precision)
+    _req(key in PRECISIONS, f"precision must be one of {sorted(PRECISIONS)}, got {precision!r}")
+    GEMM_BF16 = PRECISIONS[key]
+
+
+def get_precision() -> str:
+    return "bf16-mixed" if GEMM_BF16 else "32-true"
+
+
 GEMM_TILES = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14)  # 1-3: register-staged BK=16 core; 4-9: direct-to-LDS BK=32 core;
 #                                                      10-12: persistent direct-to-LDS core; 13-14: + split tail
 _TILE_CACHE = {}
@@ -266,7 +285,7 @@ def refine_tiles_in_step(step, rounds: int = 5, candidates: int = 2, top: int = 
 
 
 def _tune_tile(a) -> int:
-    key = (a.Mc, a.Nc, a.R, a.taps, a.a_kcontig, a.b_kcontig, a.shift_operand, a.splitk, a.epi)
+    key = (a.Mc, a.Nc, a.R, a.taps, a.a_kcontig, a.b_kcontig, a.shift_operand, a.splitk, a.epi, a.operand_bf16)
     t = _TILE_CACHE.get(key)
     if t is not None:
         c = _TILE_CALLS.get(key)
@@ -278,7 +297,11 @@ def _tune_tile(a) -> int:
     L, s = lib(), _stream()
     best, best_ms = 0, float("inf")
     timings = []
-    for tile in GEMM_TILES:
+    # the BK=16 core has no bf16 instance (it runs in fp32): last resort in bf16-mixed mode
+    order = sorted(GEMM_TILES, key=lambda t: (t < 4, t)) if a.operand_bf16 else GEMM_TILES
+    for tile in order:
+        if a.operand_bf16 and tile < 4 and best:
+            break
         a.tile = tile
         rc = L.fs2hip_gemm(C.byref(a), s)  # warm; -22 = this core/tile does not take the shape
         if rc == -22:
@@ -311,6 +334,7 @@ def _gemm(_algorithmic=True, **kw):
     if not a.workspace:  # scratch for the split-tail tiles (13/14): at most one slab of partial sums per workgroup slot
         ws = _workspace(HYBRID_WS_FLOATS, _current_device())
         a.workspace, a.workspace_floats = _p(ws), ws.numel()
+    a.operand_bf16 = 1 if (GEMM_BF16 and _algorithmic) else 0
     a.tile = _tune_tile(a)
     if GEMM_PROFILE is None or not _algorithmic:  # (the one-hot embedding GEMM's flops are not algorithmic)
         _ok(lib().fs2hip_gemm(C.byref(a), _stream()), "gemm")

@@ -255,8 +255,12 @@ class FastSpeech2(_Base):
     _VERSION: str = "1.2"
 
     def __init__(self, config, stats=None, lang2id: Optional[dict] = None, speaker2id: Optional[dict] = None,
-                 device: Optional[str] = None, seed: int = 1234):
+                 device: Optional[str] = None, seed: int = 1234, precision: str = "32-true"):
         super().__init__()
+        # Lightning's Trainer(precision=...) for this path: "32-true" (the parity path) or "bf16-mixed" (GEMM operands
+        # rounded to bf16 for the bf16 MFMA; parameters, activations, accumulation and the optimizer stay fp32)
+        H.set_precision(precision)
+        self.precision = H.get_precision()
         if not isinstance(config, FastSpeech2Config):
             from pydantic import ValidationError
             try:
@@ -408,6 +412,7 @@ class FastSpeech2(_Base):
 
     # ---- forward (fs2/model.py:153-268) -------------------------------------------------------------
     def forward(self, batch, control=None, inference=False):
+        H.set_precision(self.precision)
         control = control or InferenceControl()
         if "duration_control" in batch and batch["duration_control"] and batch["duration_control"][0]:
             control.duration = batch["duration_control"][0]
@@ -493,6 +498,7 @@ class FastSpeech2(_Base):
         """Fills ``store.grad`` with d(total loss)/d(parameters) for the last training forward + loss."""
         if self._ctx is None or self._loss_grads is None:
             raise RuntimeError("backward() needs a training-mode forward() and loss() first")
+        H.set_precision(self.precision)
         S, c, g, m = self.store, self._ctx, self._loss_grads, self.config.model
         sync = self.grad_sync
         self.variance_adaptor.bwd_predictors_early(g, c["va"])

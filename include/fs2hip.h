@@ -44,7 +44,7 @@ enum {
 int fs2hip_version(void);
 
 /* ------------------------------------------------------------------------------------
- * GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32):  C[Mc][Nc] = epi( sum_r A(m,r) * B(r,n) )
+ * GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32; bf16 operands on request):  C[Mc][Nc] = epi( sum_r A(m,r) * B(r,n) )
  *
  * Replaces every nn.Linear / pointwise nn.Conv1d / k-tap nn.Conv1d contraction on the
  * path, forward and backward:
@@ -95,6 +95,10 @@ typedef struct {
                64x64, 128x64, 128x128, 13/14 = persistent 128x128, 128x64 whose last partial round of tiles is cut
                along the reduction (needs `workspace`; epi = FS2_EPI_STORE only) */
   long long workspace_floats; /* capacity of `workspace` */
+  int operand_bf16; /* 0: fp32 MFMA (the default, the parity path).  1: "bf16-mixed" -- A and B stay fp32 in memory and
+                       in LDS, are rounded to bf16 (RNE) in registers and multiplied with v_mfma_f32_32x32x16_bf16;
+                       accumulation, bias/epilogue and C stay fp32.  Only the direct-to-LDS cores (tile >= 4) carry it;
+                       shapes those cores refuse run in fp32 */
 } Fs2GemmArgs;
 
 int fs2hip_gemm(const Fs2GemmArgs* args, void* stream);

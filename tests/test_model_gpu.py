@@ -189,3 +189,71 @@ def test_ragged_and_extreme_batches_vs_oracle(B, ts_lo, ts_hi, dur_hi, tol):
     for k, p in oracle.named_parameters():
         if p.grad is not None:
             assert float((got[k].cpu() - p.grad).abs().max()) < tol * gmax, k
+
+
+def test_bf16_mixed_train_step_within_the_reference_autocast_error():
+    """``precision="bf16-mixed"`` (BASELINE.json configs[2]): GEMM operands rounded to bf16, everything else fp32.
+    Stated bf16 tolerance, default-width 4+4-layer model, train step on a fresh batch, against the fp32 CPU oracle:
+      * mel (postnet output, rms ~1.45): MSE < 1e-3 (measured 4.0e-4) and max abs < 0.25 (measured 0.096);
+      * every loss term within 1 % (measured <= 0.32 %), total within 0.1 % (measured 0.024 %);
+      * all parameter gradients together: relative L2 error < 0.1 (measured 0.064);
+    and, as the anchor for those numbers, not worse than what the reference's own bf16 semantics give on the same
+    inputs -- the oracle run under ``torch.autocast("cpu", torch.bfloat16)`` (Lightning's bf16-mixed is autocast):
+    measured mel MSE 3.5e-3, total loss 0.11 %, gradients 0.083.  The integer outputs stay bit-exact."""
+    from fastspeech2_lightning_amd.config import FastSpeech2Config
+    from fastspeech2_lightning_amd.model import FastSpeech2
+    conf = dict(layers=4, dropout=0.0)
+    vp = dict(dropout=0.0)
+    config = FastSpeech2Config(
+        model=dict(encoder=conf, decoder=conf, learn_alignment=False,
+                   variance_predictors=dict(energy=vp, pitch=vp, duration=vp)),
+        text=dict(symbols=dict(letters=[f"s{i}" for i in range(40)])))
+    batch = O.synthetic_batch(B=4, ts_lo=20, ts_hi=40, n_symbols=41, n_mels=80, seed=3, dur_hi=6)
+    oracle = O.FastSpeech2Oracle(config, Stats(**C.STATS), n_symbols=41)
+    sd = O.seeded_state_dict(oracle.state_dict())
+    oracle.load_state_dict(sd)
+    oracle.train()
+    oracle.postnet.dropout_p = 0.0
+    ref = oracle(batch)
+    ref_losses = oracle.loss(ref, batch, 0)
+    ref_losses["total"].backward()
+    ref_grads = {k: p.grad.clone() for k, p in oracle.named_parameters() if p.grad is not None}
+
+    def errors(out, losses, grads):
+        o, r = out["postnet_output"].detach().float().cpu(), ref["postnet_output"].detach()
+        num = sum(float((grads[k].detach().float().cpu() - g).pow(2).sum()) for k, g in ref_grads.items())
+        den = sum(float(g.pow(2).sum()) for g in ref_grads.values())
+        lrel = {k: abs(float(losses[k].detach()) - float(v.detach())) / abs(float(v.detach())) for k, v in ref_losses.items()}
+        return float(((o - r) ** 2).mean()), float((o - r).abs().max()), lrel, (num / den) ** 0.5
+
+    model = FastSpeech2(config, Stats(**C.STATS), precision="bf16-mixed")
+    assert model.precision == "bf16-mixed"
+    model.load_state_dict(sd)
+    model.train()
+    model.postnet.dropout_p = 0.0
+    model.training_step(batch)
+    losses = dict(model.last_losses)
+    grads = model.store.grad_state_dict()
+    out = model(batch)
+    mse, mx, lrel, gerr = errors(out, losses, grads)
+    assert mse < 1e-3 and mx < 0.25, (mse, mx)
+    assert all(v < 1e-2 for v in lrel.values()) and lrel["total"] < 1e-3, lrel
+    assert gerr < 0.1, gerr
+    for k in ("src_mask", "tgt_mask"):  # integer / boolean outputs do not depend on the precision
+        assert torch.equal(out[k].cpu().bool(), ref[k].bool()), k
+
+    oracle.zero_grad()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        a_out = oracle(batch)
+        a_losses = oracle.loss(a_out, batch, 0)
+    a_losses["total"].backward()
+    a_mse, a_mx, a_lrel, a_gerr = errors(a_out, a_losses, {k: p.grad for k, p in oracle.named_parameters() if p.grad is not None})
+    assert mse <= a_mse and lrel["total"] <= a_lrel["total"] and gerr <= a_gerr, ((mse, a_mse), (lrel, a_lrel), (gerr, a_gerr))
+
+    # and the switch is per model: a 32-true model built afterwards is back on the fp32 MFMA
+    m32 = FastSpeech2(config, Stats(**C.STATS))
+    m32.load_state_dict(sd)
+    m32.train()
+    m32.postnet.dropout_p = 0.0
+    o32 = m32(batch)
+    assert rel(o32["postnet_output"].detach().cpu().numpy(), ref["postnet_output"].detach().numpy()) < 1e-4
