@@ -1,5 +1,5 @@
 // Multi-head self-attention with key-padding mask, flash-style (scores never reach HBM), fp32
-// on v_mfma_f32_16x16x4_f32.  Replaces nn.MultiheadAttention's softmax(QK^T/sqrt(d) + mask)V
+// on v_mfma_f32_16x16x4_f32 (or, on request, bf16-rounded operands on v_mfma_f32_16x16x32_bf16).  Replaces nn.MultiheadAttention's softmax(QK^T/sqrt(d) + mask)V
 // inside torchaudio's ConformerLayer (call sites fs2/model.py:193, :241) forward and backward.
 //
 // Layout: qkv is the in_proj output [B*T][3*D] (q | k | v, head h = columns h*HD..), o is [B*T][D].
@@ -23,6 +23,75 @@ __device__ __forceinline__ float xor_sum16_32(float v) {
   v += __shfl_xor(v, 16, 64);
   return v + __shfl_xor(v, 32, 64);
 }
+
+// MFMA operands of one lane.  Every product of these kernels pairs "this lane's own row/column" (registers) with
+// rows of an LDS tile, four reduction values per lane group g = lane >> 4 at a time:
+//   fp32        : four v_mfma_f32_16x16x4_f32, element e of A with element e of B;
+//   "bf16-mixed": EIGHT values (two such groups of four) rounded to bf16 (RNE) for ONE v_mfma_f32_16x16x32_bf16,
+//                 whose operand layout is: lane group g holds reduction slots 8g..8g+7 of A and of B -- A and B use
+//                 the same (group, element) -> slot map, so which eight values share an instruction is free.
+//                 Accumulation, softmax statistics and storage stay fp32.
+// The conversions are left to the compiler (8-wide convert consumed whole by the MFMA = four v_cvt_pk_bf16_f32):
+// a v_cvt_pk_bf16_f32 emitted through inline asm is invisible to the hazard recogniser, which then places the
+// MFMA one wait state behind it -- one too few on gfx950 (measured: stale operand registers, tools/scratch/bf16_probe.hip).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 cvt8(float4 a, float4 b) {
+  const f32x8 v = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  return __builtin_convertvector(v, bf16x8);
+}
+__device__ __forceinline__ f32x4 mfma4(float4 a, float4 b, f32x4 c) {
+  c = mfma16(a.x, b.x, c);
+  c = mfma16(a.y, b.y, c);
+  c = mfma16(a.z, b.z, c);
+  return mfma16(a.w, b.w, c);
+}
+__device__ __forceinline__ f32x4 mfma8(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// this lane's own row: values d = 16 j + 4 g + e (j < HD/16), loaded through f(j) -> float4
+template <int HD, bool BF>
+struct Own;
+template <int HD>
+struct Own<HD, false> {
+  float4 v[HD / 16];
+  template <class F>
+  __device__ __forceinline__ void load(F f) {
+#pragma unroll
+    for (int j = 0; j < HD / 16; ++j) v[j] = f(j);
+  }
+};
+template <int HD>
+struct Own<HD, true> {
+  static constexpr int NP = (HD / 16 + 1) / 2;
+  bf16x8 v[NP];
+  template <class F>
+  __device__ __forceinline__ void load(F f) {
+#pragma unroll
+    for (int jj = 0; jj < NP; ++jj)
+      v[jj] = cvt8(f(2 * jj), 2 * jj + 1 < HD / 16 ? f(2 * jj + 1) : make_float4(0, 0, 0, 0));
+  }
+};
+
+// this lane's weights for TWO 16-row blocks of a tile: w0[r] / w1[r] belong to rows 4 g + r of block 2 kp / 2 kp + 1
+template <bool BF>
+struct W2;
+template <>
+struct W2<false> {
+  float4 a, b;
+  __device__ __forceinline__ void set(const f32x4& w0, const f32x4& w1) {
+    a = make_float4(w0[0], w0[1], w0[2], w0[3]);
+    b = make_float4(w1[0], w1[1], w1[2], w1[3]);
+  }
+};
+template <>
+struct W2<true> {
+  bf16x8 v;
+  __device__ __forceinline__ void set(const f32x4& w0, const f32x4& w1) {
+    v = cvt8(make_float4(w0[0], w0[1], w0[2], w0[3]), make_float4(w1[0], w1[1], w1[2], w1[3]));
+  }
+};
 
 struct AttnP {
   const float* qkv;
@@ -66,23 +135,42 @@ __device__ __forceinline__ void commit_rows(float* __restrict__ dst, const RowRe
   }
 }
 
-// X^T[rows of tile][own] = sum_d tile[row][d] * own_reg[d]   (tile rows 16*kt + (lane&15))
-template <int HD>
-__device__ __forceinline__ f32x4 dot_tile(const float* __restrict__ tile, const float4 (&own)[HD / 16], int kt, int c, int g) {
-  constexpr int LDT = HD + 4;
+// X^T[rows of tile][own] = sum_d tile[row][d] * own[d]   (tile rows 16*kt + (lane&15))
+template <int HD, bool BF>
+__device__ __forceinline__ f32x4 dot_tile(const float* __restrict__ tile, const Own<HD, BF>& own, int kt, int c, int g) {
+  constexpr int LDT = HD + 4, NJ = HD / 16;
+  const float* row = tile + (16 * kt + c) * LDT + 4 * g;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (BF) {
 #pragma unroll
-  for (int j = 0; j < HD / 16; ++j) {
-    float4 t = *reinterpret_cast<const float4*>(tile + (16 * kt + c) * LDT + 16 * j + 4 * g);
-    acc = mfma16(t.x, own[j].x, acc);
-    acc = mfma16(t.y, own[j].y, acc);
-    acc = mfma16(t.z, own[j].z, acc);
-    acc = mfma16(t.w, own[j].w, acc);
+    for (int jj = 0; jj < (NJ + 1) / 2; ++jj) {
+      const float4 t0 = *reinterpret_cast<const float4*>(row + 32 * jj);
+      const float4 t1 = 2 * jj + 1 < NJ ? *reinterpret_cast<const float4*>(row + 32 * jj + 16) : make_float4(0, 0, 0, 0);
+      acc = mfma8(cvt8(t0, t1), own.v[jj], acc);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc = mfma4(*reinterpret_cast<const float4*>(row + 16 * j), own.v[j], acc);
   }
   return acc;
 }
 
-template <int HD>
+// acc^T[d = 16*dt + c][own] += sum over the 32 tile rows of block pair kp: tile[row][d] * w[row]
+template <int HD, bool BF>
+__device__ __forceinline__ f32x4 acc_pair(const float* __restrict__ tile, int kp, const W2<BF>& w, int dt, int c, int g, f32x4 acc) {
+  constexpr int LDT = HD + 4;
+  const float* q0 = tile + (32 * kp + 4 * g) * LDT + 16 * dt + c;
+  const float* q1 = q0 + 16 * LDT;
+  const float4 t0 = make_float4(q0[0], q0[LDT], q0[2 * LDT], q0[3 * LDT]);
+  const float4 t1 = make_float4(q1[0], q1[LDT], q1[2 * LDT], q1[3 * LDT]);
+  if constexpr (BF) {
+    return mfma8(cvt8(t0, t1), w.v, acc);
+  } else {
+    return mfma4(t1, w.b, mfma4(t0, w.a, acc));
+  }
+}
+
+template <int HD, bool BF>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p, float* __restrict__ o, float* __restrict__ lse) {
   constexpr int LDT = HD + 4, NJ = HD / 16;
   __shared__ __attribute__((aligned(16))) float Ks[64 * LDT];
@@ -93,13 +181,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p, float* __rest
   const int len = p.lens[b];
   const Fs2Drop drop = fs2_resolve_drop(p.drop);
   const float* base = p.qkv + (long long)b * T * ld;
-  float4 qr[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
+  Own<HD, BF> qr;
+  qr.load([&](int j) {
     float4 v = q < T ? *reinterpret_cast<const float4*>(base + (long long)q * ld + h * HD + 16 * j + 4 * g)
                      : make_float4(0, 0, 0, 0);
-    qr[j] = make_float4(v.x * p.scale, v.y * p.scale, v.z * p.scale, v.w * p.scale);
-  }
+    return make_float4(v.x * p.scale, v.y * p.scale, v.z * p.scale, v.w * p.scale);
+  });
   f32x4 oacc[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) oacc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -122,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p, float* __rest
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-      s[kt] = dot_tile<HD>(Ks, qr, kt, c, g);
+      s[kt] = dot_tile<HD, BF>(Ks, qr, kt, c, g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int key = key0 + 16 * kt + 4 * g + r;
@@ -145,14 +232,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p, float* __rest
     rs = xor_sum16_32(rs);
     l = l * alpha + rs;
     m = mnew;
+    W2<BF> pw[2];
+    pw[0].set(s[0], s[1]);
+    pw[1].set(s[2], s[3]);
 #pragma unroll
     for (int dt = 0; dt < NJ; ++dt) {
       oacc[dt] *= alpha;
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          oacc[dt] = mfma16(Vs[(16 * kt + 4 * g + r) * LDT + 16 * dt + c], s[kt][r], oacc[dt]);
+      oacc[dt] = acc_pair<HD, BF>(Vs, 1, pw[1], dt, c, g, acc_pair<HD, BF>(Vs, 0, pw[0], dt, c, g, oacc[dt]));
     }
   }
   if (q < T) {
@@ -188,8 +274,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict
 }
 
 // dQ: same walk as the forward (own = queries, tiles = keys)
-template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p, const float* __restrict__ dout,
+template <int HD, bool BF>
+__global__ __launch_bounds__(256, BF ? 2 : 1) void attn_bwd_dq_kernel(AttnP p, const float* __restrict__ dout,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
                                                            float* __restrict__ dqkv) {
   constexpr int LDT = HD + 4, NJ = HD / 16;
@@ -201,15 +287,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p, const float* 
   const int len = p.lens[b];
   const Fs2Drop drop = fs2_resolve_drop(p.drop);
   const float* base = p.qkv + (long long)b * T * ld;
-  float4 qr[NJ], dor[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
+  Own<HD, BF> qr, dor;
+  qr.load([&](int j) {
     float4 v = q < T ? *reinterpret_cast<const float4*>(base + (long long)q * ld + h * HD + 16 * j + 4 * g)
                      : make_float4(0, 0, 0, 0);
-    qr[j] = make_float4(v.x * p.scale, v.y * p.scale, v.z * p.scale, v.w * p.scale);
-    dor[j] = q < T ? *reinterpret_cast<const float4*>(dout + ((long long)b * T + q) * D + h * HD + 16 * j + 4 * g)
-                   : make_float4(0, 0, 0, 0);
-  }
+    return make_float4(v.x * p.scale, v.y * p.scale, v.z * p.scale, v.w * p.scale);
+  });
+  dor.load([&](int j) {
+    return q < T ? *reinterpret_cast<const float4*>(dout + ((long long)b * T + q) * D + h * HD + 16 * j + 4 * g)
+                 : make_float4(0, 0, 0, 0);
+  });
   const float lse_q = q < T ? lse[((long long)b * p.H + h) * T + q] : INFINITY;
   const float delta_q = q < T ? delta[((long long)b * p.H + h) * T + q] : 0.f;
   f32x4 dq[NJ];
@@ -232,8 +319,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p, const float* 
     f32x4 ds[4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-      f32x4 s = dot_tile<HD>(Ks, qr, kt, c, g);
-      f32x4 dp = dot_tile<HD>(Vs, dor, kt, c, g);
+      f32x4 s = dot_tile<HD, BF>(Ks, qr, kt, c, g);
+      f32x4 dp = dot_tile<HD, BF>(Vs, dor, kt, c, g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int key = key0 + 16 * kt + 4 * g + r;
@@ -242,13 +329,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p, const float* 
         ds[kt][r] = pv * (dp[r] * f - delta_q);
       }
     }
+    W2<BF> dsw[2];
+    dsw[0].set(ds[0], ds[1]);
+    dsw[1].set(ds[2], ds[3]);
 #pragma unroll
     for (int dt = 0; dt < NJ; ++dt)
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          dq[dt] = mfma16(Ks[(16 * kt + 4 * g + r) * LDT + 16 * dt + c], ds[kt][r], dq[dt]);
+      dq[dt] = acc_pair<HD, BF>(Ks, 1, dsw[1], dt, c, g, acc_pair<HD, BF>(Ks, 0, dsw[0], dt, c, g, dq[dt]));
   }
   if (q < T) {
     float* row = dqkv + ((long long)b * T + q) * ld + h * HD;
@@ -260,7 +346,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p, const float* 
 }
 
 // dK, dV: own = keys (registers), tiles = queries (Q and dO staged in LDS)
-template <int HD>
+template <int HD, bool BF>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p, const float* __restrict__ dout,
                                                             const float* __restrict__ lse, const float* __restrict__ delta,
                                                             float* __restrict__ dqkv) {
@@ -286,15 +372,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p, const float*
     }
     return;
   }
-  float4 kr[NJ], vr[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
+  Own<HD, BF> kr, vr;
+  kr.load([&](int j) {
     float4 v = key < T ? *reinterpret_cast<const float4*>(base + (long long)key * ld + D + h * HD + 16 * j + 4 * g)
                        : make_float4(0, 0, 0, 0);
-    kr[j] = make_float4(v.x * p.scale, v.y * p.scale, v.z * p.scale, v.w * p.scale);
-    vr[j] = key < T ? *reinterpret_cast<const float4*>(base + (long long)key * ld + 2 * D + h * HD + 16 * j + 4 * g)
-                    : make_float4(0, 0, 0, 0);
-  }
+    return make_float4(v.x * p.scale, v.y * p.scale, v.z * p.scale, v.w * p.scale);
+  });
+  vr.load([&](int j) {
+    return key < T ? *reinterpret_cast<const float4*>(base + (long long)key * ld + 2 * D + h * HD + 16 * j + 4 * g)
+                   : make_float4(0, 0, 0, 0);
+  });
   f32x4 dk[NJ], dv[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
@@ -321,25 +408,30 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p, const float*
       fetch_rows<HD>(oreg, dout + (long long)b * T * D, D, h * HD, q0 + 64, T, tid);
     }
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
-      f32x4 s = dot_tile<HD>(Qs, kr, qt, c, g);
-      f32x4 dp = dot_tile<HD>(Os, vr, qt, c, g);
-      f32x4 pd, ds;
+    for (int qp = 0; qp < 2; ++qp) {  // two 16-query blocks at a time (one bf16 MFMA covers both)
+      f32x4 pd[2], ds[2];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int ql = 16 * qt + 4 * g + r;
-        float pv = key_ok ? __expf(s[r] - lse_s[ql]) : 0.f;
-        float f = fs2_drop_factor(drop, (headidx + (unsigned long long)(q0 + ql)) * T + (unsigned long long)key);
-        pd[r] = pv * f;
-        ds[r] = pv * (dp[r] * f - delta_s[ql]);
-      }
-#pragma unroll
-      for (int dt = 0; dt < NJ; ++dt)
+      for (int u = 0; u < 2; ++u) {
+        const int qt = 2 * qp + u;
+        f32x4 s = dot_tile<HD, BF>(Qs, kr, qt, c, g);
+        f32x4 dp = dot_tile<HD, BF>(Os, vr, qt, c, g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          dv[dt] = mfma16(Os[(16 * qt + 4 * g + r) * LDT + 16 * dt + c], pd[r], dv[dt]);
-          dk[dt] = mfma16(Qs[(16 * qt + 4 * g + r) * LDT + 16 * dt + c], ds[r], dk[dt]);
+          int ql = 16 * qt + 4 * g + r;
+          float pv = key_ok ? __expf(s[r] - lse_s[ql]) : 0.f;
+          float f = fs2_drop_factor(drop, (headidx + (unsigned long long)(q0 + ql)) * T + (unsigned long long)key);
+          pd[u][r] = pv * f;
+          ds[u][r] = pv * (dp[r] * f - delta_s[ql]);
         }
+      }
+      W2<BF> pdw, dsw;
+      pdw.set(pd[0], pd[1]);
+      dsw.set(ds[0], ds[1]);
+#pragma unroll
+      for (int dt = 0; dt < NJ; ++dt) {
+        dv[dt] = acc_pair<HD, BF>(Os, qp, pdw, dt, c, g, dv[dt]);
+        dk[dt] = acc_pair<HD, BF>(Qs, qp, dsw, dt, c, g, dk[dt]);
+      }
     }
   }
   if (key < T) {
@@ -361,21 +453,24 @@ bool attn_args_ok(const void* qkv, int B, int T, int H, int HD) {
 
 }  // namespace
 
-#define ATTN_DISPATCH(HD_, CALL)           \
-  switch (HD_) {                           \
+#define ATTN_DISPATCH_HD(HD_, CALL)                     \
+  switch (HD_) {                                        \
     case 16: { constexpr int HDc = 16; CALL; } break;   \
     case 32: { constexpr int HDc = 32; CALL; } break;   \
     case 64: { constexpr int HDc = 64; CALL; } break;   \
     default: { constexpr int HDc = 128; CALL; } break;  \
   }
+#define ATTN_DISPATCH(HD_, BF_, CALL)                              \
+  if (BF_) { constexpr bool BFc = true; ATTN_DISPATCH_HD(HD_, CALL) } \
+  else { constexpr bool BFc = false; ATTN_DISPATCH_HD(HD_, CALL) }
 
 extern "C" int fs2hip_attention_fwd(const float* qkv, const int* lens, float* o, float* lse, int B, int T, int H,
                                     int HD, float drop_p, unsigned long long drop_seed,
-                                    const unsigned long long* drop_step, void* stream) {
+                                    const unsigned long long* drop_step, int operand_bf16, void* stream) {
   if (!attn_args_ok(qkv, B, T, H, HD) || ((uintptr_t)o % 16)) return FS2HIP_EINVAL;
   AttnP p{qkv, lens, B, T, H, 1.f / sqrtf((float)HD), fs2_make_drop(drop_p, drop_seed, drop_step)};
   dim3 grid((T + 63) / 64, H, B);
-  ATTN_DISPATCH(HD, (attn_fwd_kernel<HDc><<<grid, dim3(256), 0, (hipStream_t)stream>>>(p, o, lse)));
+  ATTN_DISPATCH(HD, operand_bf16, (attn_fwd_kernel<HDc, BFc><<<grid, dim3(256), 0, (hipStream_t)stream>>>(p, o, lse)));
   FS2_LAUNCH_CHECK();
   return 0;
 }
@@ -383,7 +478,7 @@ extern "C" int fs2hip_attention_fwd(const float* qkv, const int* lens, float* o,
 extern "C" int fs2hip_attention_bwd(const float* qkv, const int* lens, const float* o, const float* dout,
                                     const float* lse, float* delta, float* dqkv, int B, int T, int H, int HD,
                                     float drop_p, unsigned long long drop_seed,
-                                    const unsigned long long* drop_step, void* stream) {
+                                    const unsigned long long* drop_step, int operand_bf16, void* stream) {
   if (!attn_args_ok(qkv, B, T, H, HD) || ((uintptr_t)o % 16) || ((uintptr_t)dout % 16) || ((uintptr_t)dqkv % 16))
     return FS2HIP_EINVAL;
   hipStream_t s = (hipStream_t)stream;
@@ -391,9 +486,9 @@ extern "C" int fs2hip_attention_bwd(const float* qkv, const int* lens, const flo
   FS2_LAUNCH_CHECK();
   AttnP p{qkv, lens, B, T, H, 1.f / sqrtf((float)HD), fs2_make_drop(drop_p, drop_seed, drop_step)};
   dim3 grid((T + 63) / 64, H, B);
-  ATTN_DISPATCH(HD, (attn_bwd_dq_kernel<HDc><<<grid, dim3(256), 0, s>>>(p, dout, lse, delta, dqkv)));
+  ATTN_DISPATCH(HD, operand_bf16, (attn_bwd_dq_kernel<HDc, BFc><<<grid, dim3(256), 0, s>>>(p, dout, lse, delta, dqkv)));
   FS2_LAUNCH_CHECK();
-  ATTN_DISPATCH(HD, (attn_bwd_dkv_kernel<HDc><<<grid, dim3(256), 0, s>>>(p, dout, lse, delta, dqkv)));
+  ATTN_DISPATCH(HD, operand_bf16, (attn_bwd_dkv_kernel<HDc, BFc><<<grid, dim3(256), 0, s>>>(p, dout, lse, delta, dqkv)));
   FS2_LAUNCH_CHECK();
   return 0;
 }

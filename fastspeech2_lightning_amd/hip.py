@@ -56,8 +56,8 @@ SIGNATURES = {
     "fs2hip_layernorm_fwd": "ppppppiifp",
     "fs2hip_layernorm_bwd_blocks": "i",
     "fs2hip_layernorm_bwd": "ppppppppppiip",
-    "fs2hip_attention_fwd": "ppppiiiifQpp",
-    "fs2hip_attention_bwd": "pppppppiiiifQpp",
+    "fs2hip_attention_fwd": "ppppiiiifQpip",
+    "fs2hip_attention_bwd": "pppppppiiiifQpip",
     "fs2hip_dwconv_blocks": "ii",
     "fs2hip_dwconv_fwd": "pippppiiiiiip",
     "fs2hip_dwconv_bwd": "ppipppppiiiiip",
@@ -562,7 +562,7 @@ def attention_fwd(qkv, lens, B, T, H, drop: Drop = NO_DROP):
     o = torch.empty(B, T, D, device=qkv.device, dtype=torch.float32)
     lse = torch.empty(B, H, T, device=qkv.device, dtype=torch.float32)
     _ok(lib().fs2hip_attention_fwd(_p(qkv), _p(lens), _p(o), _p(lse), B, T, H, D // H, drop.p, drop.seed,
-                                   drop.step_ptr, _stream()), "attention_fwd")
+                                   drop.step_ptr, int(GEMM_BF16), _stream()), "attention_fwd")
     return o, lse
 
 
@@ -576,7 +576,7 @@ def attention_bwd(qkv, lens, o, dout, lse, B, T, H, drop: Drop = NO_DROP):
     dqkv = torch.empty_like(qkv)
     delta = torch.empty_like(lse)
     _ok(lib().fs2hip_attention_bwd(_p(qkv), _p(lens), _p(o), _p(dout), _p(lse), _p(delta), _p(dqkv), B, T, H, D // H,
-                                   drop.p, drop.seed, drop.step_ptr, _stream()), "attention_bwd")
+                                   drop.p, drop.seed, drop.step_ptr, int(GEMM_BF16), _stream()), "attention_bwd")
     return dqkv
 
 

@@ -148,14 +148,16 @@ int fs2hip_layernorm_bwd(const float* dy, const float* x, const float* gamma, co
  *   dropout acts on the normalised probabilities (attention dropout), mask regenerated
  *   from (seed, b, h, q, k) in the backward.  HD in {16, 32, 64, 128}.
  * bwd: delta [B][H][T] scratch; dqkv [B*T][3*H*HD] fully written.
+ * operand_bf16 = 1 ("bf16-mixed"): the operands of all five products (Q, K, V, dO, P, dS) are rounded to bf16 for
+ *   v_mfma_f32_16x16x32_bf16; scores, softmax statistics, accumulators and outputs stay fp32.
  * ------------------------------------------------------------------------------------ */
 int fs2hip_attention_fwd(const float* qkv, const int* lens, float* o, float* lse, int B, int T, int H,
                          int HD, float drop_p, unsigned long long drop_seed,
-                         const unsigned long long* drop_step, void* stream);
+                         const unsigned long long* drop_step, int operand_bf16, void* stream);
 int fs2hip_attention_bwd(const float* qkv, const int* lens, const float* o, const float* dout,
                          const float* lse, float* delta, float* dqkv, int B, int T, int H, int HD,
                          float drop_p, unsigned long long drop_seed,
-                         const unsigned long long* drop_step, void* stream);
+                         const unsigned long long* drop_step, int operand_bf16, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Depthwise Conv1d over time on (B, T, C), 'same' padding, K in {3,5,7,9,15,31}; w is [K][C].
