@@ -15,7 +15,8 @@
 //    COUNTED `s_waitcnt vmcnt(N)` (N = loads of the newer tiles, never 0 in steady state) -- the wait
 //    retires this wave's oldest tile, the barrier publishes everybody's and also retires all reads of the
 //    stage that the next DMA (issued right after it) overwrites;
-//  * XCD-aware workgroup order (tiles sharing an M-tile's A rows run on one XCD's L2).
+//  * XCD-aware workgroup order (tiles sharing an M-tile's A rows, and the tiles of one split-K / tap slice, run on
+//    one XCD's L2).
 #include "gemm2_core.h"
 namespace {
 
@@ -30,14 +31,22 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmP p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int wg = fs2_xcd_remap(blockIdx.x, gridDim.x);
+  // one grid dimension over (reduction slice, tile): the XCD remap then keeps the tiles of one split-K / tap slice
+  // -- the workgroups that read the same reduction chunk of both operands -- on one XCD's L2.  [With the slices in
+  // gridDim.z a slice's tiles were dealt over all eight XCDs and every XCD fetched the chunk: the 1024x256
+  // weight gradient read X eight times, 255 MB for 106 MB of operands.]
+  const int ntile = p.tiles_m * p.tiles_n;
+  const int unit = fs2_xcd_remap(blockIdx.x, gridDim.x);
+  const int z = unit / ntile;
+  const int wg = unit - z * ntile;
   const int tile_m = wg / p.tiles_n, tile_n = wg - tile_m * p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   int tapz = 0, split = 0;
-  if (a.shift_operand == 1 || a.splitk > 1) {
-    tapz = blockIdx.z / a.splitk;
-    split = blockIdx.z % a.splitk;
+  if (a.shift_operand == 1 || a.splitk > 1) {  // slice order (split, tap): the taps of one reduction chunk are neighbours
+    const int ntap = a.shift_operand == 1 ? a.taps : 1;
+    split = z / ntap;
+    tapz = z - split * ntap;
   }
   const int r_begin = split * p.r_chunk;
   const int r_end = min(a.R, r_begin + p.r_chunk);
@@ -109,7 +118,8 @@ int launch_tile(GemmP& p, int nz, hipStream_t s) {
   const Fs2GemmArgs& a = p.a;
   p.tiles_m = (a.Mc + BM - 1) / BM;
   p.tiles_n = (a.Nc + BN - 1) / BN;
-  dim3 grid(p.tiles_m * p.tiles_n, 1, nz), block(256);
+  if ((long long)p.tiles_m * p.tiles_n * nz > 0x7fffffffLL) return FS2HIP_EINVAL;
+  dim3 grid(p.tiles_m * p.tiles_n * nz), block(256);
   int mode = TAPS_NONE;
   if (a.taps > 1) {
     if (a.shift_operand == 0) mode = (p.Rper % BK2 == 0) ? TAPS_RED : TAPS_GENERIC;

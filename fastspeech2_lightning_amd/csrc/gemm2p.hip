@@ -40,8 +40,9 @@ __device__ __forceinline__ Unit decode_unit(const GemmP& p, const Hybrid& hy, in
     const int uu = fs2_xcd_remap(u, nunits);
     const int z = uu / tiles;
     t = uu - z * tiles;
-    q.tapz = z / a.splitk;
-    q.split = z - q.tapz * a.splitk;
+    const int ntap = a.shift_operand == 1 ? a.taps : 1;  // slice order (split, tap): the taps of one reduction chunk
+    q.split = z / ntap;                                    // (same dY rows, X rows shifted by one) share an XCD's L2
+    q.tapz = z - q.split * ntap;
     q.r_begin = q.split * p.r_chunk;
     q.r_end = min(a.R, q.r_begin + p.r_chunk);
     q.slice = -1;

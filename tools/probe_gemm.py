@@ -20,6 +20,9 @@ if kind == "nt":
 elif kind == "nn":
     dy = torch.randn(m, k, device=dev); w = torch.randn(k, n, device=dev); out = torch.empty(m, n, device=dev)
     fn = lambda: H.linear_bwd_data(dy, w, out=out)
+elif kind == "cdw":  # 5-tap conv weight gradient, rows = 32 utterances of m / 32 frames
+    dy = torch.randn(m, n, device=dev); x = torch.randn(m, k, device=dev); out = torch.empty(5, n, k, device=dev)
+    fn = lambda: H.linear_bwd_weight(dy, x, out, taps=5, T=m // 32)
 else:
     dy = torch.randn(m, n, device=dev); x = torch.randn(m, k, device=dev); out = torch.empty(n, k, device=dev)
     fn = lambda: H.linear_bwd_weight(dy, x, out)
