@@ -257,3 +257,69 @@ def test_bf16_mixed_train_step_within_the_reference_autocast_error():
     m32.postnet.dropout_p = 0.0
     o32 = m32(batch)
     assert rel(o32["postnet_output"].detach().cpu().numpy(), ref["postnet_output"].detach().numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("learn_alignment", [False, True])
+def test_five_optimizer_steps_track_the_oracle(learn_alignment):
+    """The whole train step repeated: forward + losses + backward + gradient-norm clip (1.0) + AdamW under the Noam
+    schedule, five times on one batch, HIP path against the CPU oracle driven by torch's own AdamW /
+    ``clip_grad_norm_`` / the reference's Noam factor (fs2/noam.py:20-26, stepped after the optimizer step).  The
+    learning rate is raised (1e-2 base, 2 warm-up steps) so that the loss really moves (it roughly halves); every step's
+    loss terms must agree to 2e-3 and the accumulated parameter update to 2 % (relative L2 over all parameters), i.e.
+    the per-step differences do not compound."""
+    from fastspeech2_lightning_amd.model import FastSpeech2
+    config = C.small_config(learn_alignment=learn_alignment)
+    config.training.optimizer.learning_rate = 1e-2
+    config.training.optimizer.warmup_steps = 2
+    kw = dict(learn_alignment=True) if learn_alignment else {}
+    batch = O.synthetic_batch(B=4, ts_lo=8, ts_hi=20, n_symbols=C.N_SYMBOLS, n_mels=config.preprocessing.audio.n_mels,
+                              seed=21, dur_hi=5, **kw)
+    model = FastSpeech2(config, Stats(**C.STATS))
+    oracle = O.FastSpeech2Oracle(config, Stats(**C.STATS), n_symbols=C.N_SYMBOLS)
+    sd = O.seeded_state_dict(oracle.state_dict())
+    oracle.load_state_dict(sd)
+    model.load_state_dict(sd)
+    model.train(); oracle.train()
+    model.postnet.dropout_p = 0.0
+    oracle.postnet.dropout_p = 0.0
+    o = config.training.optimizer
+    ref_opt = torch.optim.AdamW(oracle.parameters(), o.learning_rate, betas=tuple(o.betas), eps=o.eps,
+                                weight_decay=o.weight_decay)
+    opt = model.configure_optimizers()[0][0]
+    first = last = None
+    for k in range(1, 6):
+        for grp in ref_opt.param_groups:
+            grp["lr"] = o.learning_rate * O.noam_scale(k - 1, o.warmup_steps)
+        ref_opt.zero_grad()
+        ref_losses = oracle.loss(oracle(batch), batch, 0)
+        ref_losses["total"].backward()
+        torch.nn.utils.clip_grad_norm_(oracle.parameters(), 1.0)
+        ref_opt.step()
+        model.training_step(batch)
+        opt.step()
+        for name, v in ref_losses.items():
+            got, want = float(model.last_losses[name]), float(v.detach())
+            assert abs(got - want) < 2e-3 * max(abs(want), 1e-3), (k, name, got, want)
+        rec = opt.record()
+        assert rec["step"] == k and abs(rec["lr"] - ref_opt.param_groups[0]["lr"]) < 1e-9
+        first = first if first is not None else float(ref_losses["total"].detach())
+        last = float(ref_losses["total"].detach())
+    assert last < 0.8 * first, (first, last)  # the comparison above was made on a loss that moved
+    # Parameters after the five updates.  Adam's early updates are +-lr per element whatever the gradient's size, so an
+    # element whose gradient is rounding noise may move the other way on the two sides: compare the UPDATE (final -
+    # initial) as a whole -- relative L2 error over all parameters -- and bound single elements by the total step length.
+    got = model.state_dict()
+    num = den = 0.0
+    lr_sum = sum(o.learning_rate * O.noam_scale(k - 1, o.warmup_steps) for k in range(1, 6))
+    for name, p in oracle.named_parameters():
+        d_ref = p.detach() - sd[name]
+        d_got = got[name].cpu() - sd[name]
+        num += float((d_got - d_ref).pow(2).sum())
+        den += float(d_ref.pow(2).sum())
+        assert float((d_got - d_ref).abs().max()) <= 2.0 * lr_sum * 1.01, name
+    assert (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5
+    for name, b in oracle.named_buffers():  # BatchNorm running statistics / counters after five training forwards
+        if b.dtype.is_floating_point:
+            assert rel(got[name].cpu().numpy(), b.numpy()) < 5e-3, name  # (they see the slightly different weights)
+        else:
+            assert int(got[name]) == int(b), name
