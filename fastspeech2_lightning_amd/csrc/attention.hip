@@ -155,6 +155,47 @@ __device__ __forceinline__ f32x4 dot_tile(const float* __restrict__ tile, const 
   return acc;
 }
 
+// The same product for NT consecutive 16-row blocks at once (blocks kt0 .. kt0+NT-1).  Source order = issue order
+// the fp32 path wants: the operand rows of reduction slice j+1 are fetched from LDS before the MFMAs of slice j, and
+// the NT accumulators are interleaved element by element, so that neither an LDS round trip (the compiler's own
+// schedule read two rows, waited, issued eight MFMAs, read the next two ...) nor the back-to-back dependence of one
+// accumulator chain is exposed.  Every accumulator still adds its products in the order (j, element): bit-identical
+// to dot_tile.
+template <int HD, bool BF, int NT>
+__device__ __forceinline__ void dot_tiles(const float* __restrict__ tile, const Own<HD, BF>& own, int kt0, int c, int g,
+                                          f32x4 (&out)[NT]) {
+  constexpr int LDT = HD + 4, NJ = HD / 16;
+  if constexpr (BF) {
+#pragma unroll
+    for (int u = 0; u < NT; ++u) out[u] = dot_tile<HD, true>(tile, own, kt0 + u, c, g);
+  } else {
+    const float* row = tile + (16 * kt0 + c) * LDT + 4 * g;
+    float4 cur[NT], nxt[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      out[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      cur[u] = *reinterpret_cast<const float4*>(row + u * 16 * LDT);
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if (j + 1 < NJ) {
+#pragma unroll
+        for (int u = 0; u < NT; ++u) nxt[u] = *reinterpret_cast<const float4*>(row + u * 16 * LDT + 16 * (j + 1));
+      }
+#pragma unroll
+      for (int u = 0; u < NT; ++u) out[u] = mfma16(cur[u].x, own.v[j].x, out[u]);
+#pragma unroll
+      for (int u = 0; u < NT; ++u) out[u] = mfma16(cur[u].y, own.v[j].y, out[u]);
+#pragma unroll
+      for (int u = 0; u < NT; ++u) out[u] = mfma16(cur[u].z, own.v[j].z, out[u]);
+#pragma unroll
+      for (int u = 0; u < NT; ++u) out[u] = mfma16(cur[u].w, own.v[j].w, out[u]);
+#pragma unroll
+      for (int u = 0; u < NT; ++u) cur[u] = nxt[u];
+    }
+  }
+}
+
 // acc^T[d = 16*dt + c][own] += sum over the 32 tile rows of block pair kp: tile[row][d] * w[row]
 template <int HD, bool BF>
 __device__ __forceinline__ f32x4 acc_pair(const float* __restrict__ tile, int kp, const W2<BF>& w, int dt, int c, int g, f32x4 acc) {
@@ -207,9 +248,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p, float* __rest
     }
     f32x4 s[4];
     float mx = -INFINITY;
+    dot_tiles<HD, BF, 4>(Ks, qr, 0, c, g, s);
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-      s[kt] = dot_tile<HD, BF>(Ks, qr, kt, c, g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int key = key0 + 16 * kt + 4 * g + r;
@@ -316,17 +357,17 @@ __global__ __launch_bounds__(256, BF ? 2 : 1) void attn_bwd_dq_kernel(AttnP p, c
       fetch_rows<HD>(kreg, base, ld, D + h * HD, key0 + 64, T, tid);
       fetch_rows<HD>(vreg, base, ld, 2 * D + h * HD, key0 + 64, T, tid);
     }
-    f32x4 ds[4];
+    f32x4 ds[4], s4[4], dp4[4];
+    dot_tiles<HD, BF, 4>(Ks, qr, 0, c, g, s4);
+    dot_tiles<HD, BF, 4>(Vs, dor, 0, c, g, dp4);
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-      f32x4 s = dot_tile<HD, BF>(Ks, qr, kt, c, g);
-      f32x4 dp = dot_tile<HD, BF>(Vs, dor, kt, c, g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int key = key0 + 16 * kt + 4 * g + r;
-        float pv = key < len ? __expf(s[r] - lse_q) : 0.f;
+        float pv = key < len ? __expf(s4[kt][r] - lse_q) : 0.f;
         float f = fs2_drop_factor(drop, rowidx + (unsigned long long)key);
-        ds[kt][r] = pv * (dp[r] * f - delta_q);
+        ds[kt][r] = pv * (dp4[kt][r] * f - delta_q);
       }
     }
     W2<BF> dsw[2];
@@ -409,19 +450,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p, const float*
     }
 #pragma unroll
     for (int qp = 0; qp < 2; ++qp) {  // two 16-query blocks at a time (one bf16 MFMA covers both)
-      f32x4 pd[2], ds[2];
+      f32x4 pd[2], ds[2], s2[2], dp2[2];
+      dot_tiles<HD, BF, 2>(Qs, kr, 2 * qp, c, g, s2);
+      dot_tiles<HD, BF, 2>(Os, vr, 2 * qp, c, g, dp2);
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int qt = 2 * qp + u;
-        f32x4 s = dot_tile<HD, BF>(Qs, kr, qt, c, g);
-        f32x4 dp = dot_tile<HD, BF>(Os, vr, qt, c, g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           int ql = 16 * qt + 4 * g + r;
-          float pv = key_ok ? __expf(s[r] - lse_s[ql]) : 0.f;
+          float pv = key_ok ? __expf(s2[u][r] - lse_s[ql]) : 0.f;
           float f = fs2_drop_factor(drop, (headidx + (unsigned long long)(q0 + ql)) * T + (unsigned long long)key);
           pd[u][r] = pv * f;
-          ds[u][r] = pv * (dp[r] * f - delta_s[ql]);
+          ds[u][r] = pv * (dp2[u][r] * f - delta_s[ql]);
         }
       }
       W2<BF> pdw, dsw;
