@@ -153,6 +153,44 @@ __global__ __launch_bounds__(256) void gemm2p_kernel(GemmP p, Hybrid hy, int nun
   }
 }
 
+// Finishes the tail tiles of a split-tail launch whose epilogue is more than "+ bias": sums the S slices and applies
+// gemm_epilogue_impl's arithmetic element by element (same order of operations, same element index m * ldc + n for the
+// dropout mask, so forward and backward masks of a site agree whichever path wrote an element).
+__global__ __launch_bounds__(256) void tail_fixup_epi_kernel(GemmP p, Hybrid hy) {
+  const Fs2GemmArgs& a = p.a;
+  const Fs2Drop drop = fs2_resolve_drop(p.drop);
+  const int n4 = a.Nc >> 2;
+  const long long total = (long long)(a.Mc - hy.m_tail0) * n4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int r = (int)(i / n4), n = (int)(i - (long long)r * n4) * 4, m = hy.m_tail0 + r;
+    const float* src = hy.ws + (long long)r * a.Nc + n;
+    float4 sum = *reinterpret_cast<const float4*>(src);
+    for (int k = 1; k < hy.S; ++k) {
+      const float4 t = *reinterpret_cast<const float4*>(src + k * hy.slab);
+      sum.x += t.x; sum.y += t.y; sum.z += t.z; sum.w += t.w;
+    }
+    const float4 b = a.bias ? *reinterpret_cast<const float4*>(a.bias + n) : make_float4(0, 0, 0, 0);
+    float v[4] = {a.alpha * sum.x + b.x, a.alpha * sum.y + b.y, a.alpha * sum.z + b.z, a.alpha * sum.w + b.w};
+    if (a.epi == FS2_EPI_ACT) {
+      if (a.out_pre) *reinterpret_cast<float4*>(a.out_pre + (long long)m * a.ldpre + n) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fs2_act(a.act, v[e]);
+    } else if (a.epi == FS2_EPI_DACT) {
+      const float4 x = *reinterpret_cast<const float4*>(a.aux + (long long)m * a.ldaux + n);
+      v[0] *= fs2_dact(a.act, x.x); v[1] *= fs2_dact(a.act, x.y); v[2] *= fs2_dact(a.act, x.z); v[3] *= fs2_dact(a.act, x.w);
+    }
+    if (a.epi > 0 && drop.on) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= fs2_drop_factor(drop, (unsigned long long)(unsigned)(m * a.ldc + n + e));
+    }
+    if (a.epi == FS2_EPI_RESID) {
+      const float4 x = *reinterpret_cast<const float4*>(a.resid + (long long)m * a.ldr + n);
+      v[0] = x.x + a.res_scale * v[0]; v[1] = x.y + a.res_scale * v[1]; v[2] = x.z + a.res_scale * v[2]; v[3] = x.w + a.res_scale * v[3];
+    }
+    *reinterpret_cast<float4*>(a.C + (long long)m * a.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
 #define FS2_GO(AKC_, BKC_, TAPS_)                                                                             \
   do {                                                                                                        \
     if (a.operand_bf16) gemm2p_kernel<BM, BN, AKC_, BKC_, TAPS_, true><<<grid, block, 0, s>>>(p, hy, nunits, tiles);  \
@@ -178,9 +216,13 @@ int launch_persistent(GemmP& p, int nz, hipStream_t s) {
   const int slots = n_cu * WG_PER_CU;
   Hybrid hy{0, 0, 0, 0, nullptr, 0};
   if (SPLIT_TAIL) {
-    // only where a separate pass can finish the tiles: plain store (+ bias), one reduction range, 16-byte rows
-    if (nz != 1 || a.splitk != 1 || a.epi != FS2_EPI_STORE || a.out_pre || (a.Nc % 4) || (a.ldc % 4) || !a.workspace ||
-        ((uintptr_t)a.C % 16) || (a.bias && ((uintptr_t)a.bias % 16)))
+    // only where a separate pass can finish the tiles: one reduction range, rows of every tensor the epilogue touches
+    // addressable as float4
+    auto vec_ok = [](const float* ptr, int ld) { return ((uintptr_t)ptr % 16) == 0 && (ld % 4) == 0; };
+    if (nz != 1 || a.splitk != 1 || (a.Nc % 4) || !a.workspace || !vec_ok(a.C, a.ldc) ||
+        (a.bias && ((uintptr_t)a.bias % 16)) || (a.out_pre && (a.epi != FS2_EPI_ACT || !vec_ok(a.out_pre, a.ldpre))) ||
+        (a.epi == FS2_EPI_RESID && !vec_ok(a.resid, a.ldr)) || (a.epi == FS2_EPI_DACT && !vec_ok(a.aux, a.ldaux)) ||
+        a.epi < FS2_EPI_STORE || a.epi > FS2_EPI_DACT)
       return FS2HIP_EINVAL;
     const int rem = tiles % slots;
     if (rem == 0 || rem * 5 >= slots * 4) return FS2HIP_EINVAL;  // no tail worth cutting: tiles 11/12 do this shape
@@ -189,7 +231,10 @@ int launch_persistent(GemmP& p, int nz, hipStream_t s) {
     if (tail_tiles > tiles) return FS2HIP_EINVAL;
     const int nkt = (a.R + BK2 - 1) / BK2;
     int S = slots / tail_tiles;
-    if (S > nkt / 4) S = nkt / 4;  // at least 4 K-tiles per slice
+    // at least 4 K-tiles per slice; 8 when the second pass also has an epilogue to apply (K = 256 slices of 4 K-tiles
+    // plus that pass measured slower inside the step than one-tile-per-workgroup kernels, although faster in isolation)
+    const int min_kt = a.epi == FS2_EPI_STORE ? 4 : 8;
+    if (S > nkt / min_kt) S = nkt / min_kt;
     if (S < 2) return FS2HIP_EINVAL;
     hy.S = S;
     hy.chunk = ((nkt + S - 1) / S) * BK2;
@@ -224,7 +269,15 @@ int launch_persistent(GemmP& p, int nz, hipStream_t s) {
     return FS2HIP_EINVAL;
   }
   FS2_LAUNCH_CHECK();
-  if (hy.S) return fs2_tail_fixup(hy.ws, hy.S, hy.slab, a.C, a.ldc, a.bias, a.alpha, hy.m_tail0, a.Mc, a.Nc, s);
+  if (hy.S) {
+    if (a.epi == FS2_EPI_STORE)
+      return fs2_tail_fixup(hy.ws, hy.S, hy.slab, a.C, a.ldc, a.bias, a.alpha, hy.m_tail0, a.Mc, a.Nc, s);
+    const long long total = (long long)(a.Mc - hy.m_tail0) * (a.Nc >> 2);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    tail_fixup_epi_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(p, hy);
+    FS2_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -232,7 +285,7 @@ int launch_persistent(GemmP& p, int nz, hipStream_t s) {
 
 }  // namespace
 
-// tile ids 10-12: persistent 64x64 (4 workgroups / CU), 128x64 (3), 128x128 (2); 13/14: 128x128 / 128x64 + split tail
+// tile ids 10-12: persistent 64x64 (4 workgroups / CU), 128x64 (3), 128x128 (2); 13/14/15: 128x128 / 128x64 / 64x64 + split tail
 int fs2_gemm2p_launch(GemmP& p, int tile, int nz, hipStream_t s) {
   const Fs2GemmArgs& a = p.a;
   const int chunk = (a.R + a.splitk - 1) / a.splitk;
@@ -245,6 +298,7 @@ int fs2_gemm2p_launch(GemmP& p, int tile, int nz, hipStream_t s) {
     case 12: return launch_persistent<128, 128, 2, false>(p, nz, s);
     case 13: return launch_persistent<128, 128, 2, true>(p, nz, s);
     case 14: return launch_persistent<128, 64, 3, true>(p, nz, s);
+    case 15: return launch_persistent<64, 64, 4, true>(p, nz, s);
     default: return FS2HIP_EINVAL;
   }
 }

@@ -240,8 +240,8 @@ def get_precision() -> str:
     return "bf16-mixed" if GEMM_BF16 else "32-true"
 
 
-GEMM_TILES = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14)  # 1-3: register-staged BK=16 core; 4-9: direct-to-LDS BK=32 core;
-#                                                      10-12: persistent direct-to-LDS core; 13-14: + split tail
+GEMM_TILES = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)  # 1-3: register-staged BK=16 core; 4-9: direct-to-LDS BK=32 core;
+#                                                      10-12: persistent direct-to-LDS core; 13-15: + split tail
 _TILE_CACHE = {}
 #: per signature: [(isolated ms for 4 launches, tile), ...] sorted, and how often the signature was launched --
 #: what ``refine_tiles_in_step`` works from
@@ -332,7 +332,7 @@ def _gemm(_algorithmic=True, **kw):
     a.taps, a.alpha, a.res_scale, a.splitk = 1, 1.0, 1.0, 1
     for k, v in kw.items():
         setattr(a, k, v)
-    if not a.workspace:  # scratch for the split-tail tiles (13/14): at most one slab of partial sums per workgroup slot
+    if not a.workspace:  # scratch for the split-tail tiles (13-15): at most one slab of partial sums per workgroup slot
         ws = _workspace(HYBRID_WS_FLOATS, _current_device())
         a.workspace, a.workspace_floats = _p(ws), ws.numel()
     a.operand_bf16 = 1 if (GEMM_BF16 and _algorithmic) else 0

@@ -92,8 +92,8 @@ typedef struct {
   int tile; /* 0 = heuristic; workgroup tile chosen by the host autotuner: 1/2/3 = 128x128, 128x64, 64x64 on the
                register-staged BK=16 core, 4..9 = direct-to-LDS BK=32 core (128x128, 128x64, 64x64 with a 3/3/4-stage LDS
                ring; 7/8/9 = 64x64, 128x64, 128x128 with 2 stages and more workgroups per CU), 10/11/12 = persistent
-               64x64, 128x64, 128x128, 13/14 = persistent 128x128, 128x64 whose last partial round of tiles is cut
-               along the reduction (needs `workspace`; epi = FS2_EPI_STORE only) */
+               64x64, 128x64, 128x128, 13/14/15 = persistent 128x128, 128x64, 64x64 whose last partial round of tiles
+               is cut along the reduction and finished (sum + the same epilogue) by a second pass (needs `workspace`) */
   long long workspace_floats; /* capacity of `workspace` */
   int operand_bf16; /* 0: fp32 MFMA (the default, the parity path).  1: "bf16-mixed" -- A and B stay fp32 in memory and
                        in LDS, are rounded to bf16 (RNE) in registers and multiplied with v_mfma_f32_32x32x16_bf16;

@@ -52,7 +52,7 @@ def test_precision_switch_is_validated(H):
     assert H.get_precision() == "bf16-mixed" and H.GEMM_BF16
 
 
-@pytest.mark.parametrize("tile", [4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14])
+@pytest.mark.parametrize("tile", [4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15])
 def test_bf16_operands_every_direct_to_lds_tile(H, tile):
     """Forward (NT), backward-data (NN), weight-gradient (TN, split-K) and a 5-tap convolution (forward, data and
     weight gradient) with one tile forced; ragged M/N edges and a reduction that is not a multiple of the K-tile."""

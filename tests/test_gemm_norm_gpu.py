@@ -77,7 +77,7 @@ def test_conv_taps_fwd_bwd(H, taps, Cin, Cout):
     close(dw, w.grad.permute(2, 0, 1), B * T, "conv bwd weight")
 
 
-@pytest.mark.parametrize("tile", [13, 14, 12, 11, 10])
+@pytest.mark.parametrize("tile", [13, 14, 15, 12, 11, 10])
 def test_persistent_and_split_tail_tiles_at_full_size(H, tile):
     """Benchmark-size shapes (more tiles than workgroup slots, with a partial last round): the persistent cores and
     the variants that cut the tail tiles along the reduction (finished by the fix-up pass), forced one at a time.
@@ -104,6 +104,48 @@ def test_persistent_and_split_tail_tiles_at_full_size(H, tile):
         close(yc, ref, Cin * taps, f"tile {tile} conv fwd")
         # the forced tile really ran (0 = the tile does not take that shape and the built-in heuristic chose)
         assert set(H._TILE_CACHE.values()) <= {tile, 0} and tile in H._TILE_CACHE.values(), H._TILE_CACHE
+    finally:
+        H.GEMM_TILES = saved[0]
+        H._TILE_CACHE.clear()
+        H._TILE_CACHE.update(saved[1])
+
+
+@pytest.mark.parametrize("tile", [13, 14, 15])
+def test_split_tail_tiles_with_fused_epilogues(H, tile):
+    """The tail tiles of tiles 13-15 are finished by a second pass that has to reproduce the fused epilogue: SiLU with the
+    pre-activation output and dropout (FFN first linear), residual + dropout (FFN second linear), activation derivative
+    + dropout (backward through the first linear).  Reference = the same call on a one-tile-per-workgroup kernel
+    (tile 8) with the same dropout seed: the masks are functions of the element index, so the two results must agree
+    element by element to fp32 summation-order tolerance, zeros included."""
+    saved = H.GEMM_TILES, dict(H._TILE_CACHE)
+    M = 20736 + 40
+    step = torch.zeros(4, dtype=torch.int64, device="cuda")
+    drop = H.Drop(0.2, 4242, step)
+    # reductions of 512 and more: slices of an epilogue-carrying GEMM are at least 8 K-tiles (256) long
+    x, w1, b1 = rnd(M, 512, seed=1).cuda(), rnd(1024, 512, seed=2, scale=1 / 22).cuda(), rnd(1024, seed=3).cuda()
+    a, w2, b2 = rnd(M, 1024, seed=4).cuda(), rnd(512, 1024, seed=5, scale=1 / 32).cuda(), rnd(512, seed=6).cuda()
+    r2 = rnd(M, 512, seed=7).cuda()
+    dz, w3, u = rnd(M, 512, seed=8).cuda(), rnd(512, 1024, seed=9, scale=1 / 22).cuda(), rnd(M, 1024, seed=10).cuda()
+
+    def run():
+        pre = torch.empty(M, 1024, device="cuda")
+        y1 = H.linear_fwd(x, w1, b1, epi=H.EPI_ACT, act="silu", out_pre=pre, drop=drop)
+        y2 = H.linear_fwd(a, w2, b2, epi=H.EPI_RESID, resid=r2, res_scale=0.5, drop=drop)
+        y3 = H.linear_bwd_data(dz, w3, epi=H.EPI_DACT, act="silu", aux=u, alpha=0.5, drop=drop)
+        return dict(pre=pre, act=y1, resid=y2, dact=y3)
+
+    try:
+        H.GEMM_TILES = (8,)
+        H._TILE_CACHE.clear()
+        ref = run()
+        H.GEMM_TILES = (tile,)
+        H._TILE_CACHE.clear()
+        got = run()
+        ran = sorted(H._TILE_CACHE.values())
+        assert tile in ran, (tile, H._TILE_CACHE)  # at least one of the three shapes has a tail this tile cuts
+        for k, K in (("pre", 512), ("act", 512), ("resid", 1024), ("dact", 512)):
+            close(got[k], ref[k], K, f"tile {tile} {k}")
+            assert torch.equal(got[k] == 0, ref[k] == 0), f"tile {tile} {k}: dropout pattern differs"
     finally:
         H.GEMM_TILES = saved[0]
         H._TILE_CACHE.clear()
