@@ -35,6 +35,13 @@ __global__ __launch_bounds__(256, 2) void probe_fwd(AttnP p, float* __restrict__
   RowRegs<HD> kreg, vreg;
   fetch_rows<HD>(kreg, base, ld, D + h * HD, 0, T, tid);
   fetch_rows<HD>(vreg, base, ld, 2 * D + h * HD, 0, T, tid);
+  if constexpr ((FLAGS & 32) != 0) {  // stagger: the workgroup in the odd wave slots starts half a tile period later
+    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);  // HW_ID.WAVE_ID
+    if (slot & 1) {
+      __builtin_amdgcn_s_sleep(127);
+      if constexpr ((FLAGS & 64) != 0) __builtin_amdgcn_s_sleep(127);
+    }
+  }
   if constexpr ((FLAGS & 24) != 0) {
     commit_rows<HD>(Ks, kreg, tid);
     commit_rows<HD>(Vs, vreg, tid);
@@ -153,5 +160,8 @@ int main() {
   printf("S only                              %7.1f us\n", run<22>(p, o, lse, grid));
   printf("PV only                             %7.1f us\n", run<19>(p, o, lse, grid));
   printf("staging only                        %7.1f us\n", run<7>(p, o, lse, grid));
+  printf("full kernel, staggered start (3.4us)%7.1f us\n", run<32>(p, o, lse, grid));
+  printf("full kernel, staggered start (6.8us)%7.1f us\n", run<96>(p, o, lse, grid));
+  printf("full kernel again                   %7.1f us\n", run<0>(p, o, lse, grid));
   return 0;
 }
