@@ -161,7 +161,10 @@ def main():
                         precision=args.precision)
     model.train()
     opt = model.configure_optimizers()[0][0]
-    batch = synthetic_batch(B=args.batch, ts_lo=96, ts_hi=128, n_symbols=64, n_mels=80, seed=1234 + rank,
+    # every rank gets the N = 1 batch's structure (lengths and durations: the same padded shapes, i.e. the same work per
+    # GPU -- weak scaling) with its own contents; rank 0's batch is exactly the single-GPU one
+    batch = synthetic_batch(B=args.batch, ts_lo=96, ts_hi=128, n_symbols=64, n_mels=80, seed=1234,
+                            content_seed=None if rank == 0 else 1234 + rank,
                             dur_hi=18 if args.gst else 9, learn_alignment=args.learn_alignment)
     if args.gst:
         batch["speaker_id"] = torch.arange(args.batch, dtype=torch.int32) % 16

@@ -9,13 +9,19 @@ import torch
 
 
 def synthetic_batch(B=2, ts_lo=48, ts_hi=64, n_symbols=64, n_mels=80, seed=1234,
-                    learn_alignment=False, dur_hi=9, frame_level=False):
+                    learn_alignment=False, dur_hi=9, frame_level=False, content_seed=None):
+    """``seed`` fixes the batch's structure (text lengths, durations, hence every padded shape); ``content_seed``, when
+    given, draws the token ids / mel / pitch / energy values from a second generator -- data-parallel ranks then get
+    batches of identical shape (the same work per GPU, which is what weak scaling means) with different contents."""
     g = torch.Generator().manual_seed(seed)
     src_lens = torch.randint(ts_lo, ts_hi + 1, (B,), generator=g, dtype=torch.int32)
     src_lens[0] = ts_hi
     Ts = int(src_lens.max())
     text = torch.randint(1, n_symbols, (B, Ts), generator=g, dtype=torch.int32)
     dur = torch.randint(1, dur_hi + 1, (B, Ts), generator=g, dtype=torch.int32)
+    if content_seed is not None:
+        g = torch.Generator().manual_seed(content_seed)
+        text = torch.randint(1, n_symbols, (B, Ts), generator=g, dtype=torch.int32)
     smask = torch.arange(Ts)[None, :] < src_lens[:, None]
     text = text * smask
     dur = dur * smask
