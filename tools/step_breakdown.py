@@ -46,3 +46,13 @@ for s_, e_ in iv[1:]:
 union += cur_e - cur_s
 print(f"-- timeline: union of kernel intervals {union / 1e6 / back:.2f} ms/step, idle {(t1 - t0 - union) / 1e6 / back:.2f} ms/step, "
       f"overlapped {(busy - union) / 1e6 / back:.2f} ms/step")
+
+# ---- per queue (= HIP stream): busy time and the largest kernels' share, to see which stream is the critical path
+if "Queue_Id" in seg[0]:
+    per_q = defaultdict(lambda: [0, 0])
+    for r in seg:
+        per_q[r["Queue_Id"]][0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        per_q[r["Queue_Id"]][1] += 1
+    for q_, (d, n) in sorted(per_q.items(), key=lambda kv: -kv[1][0]):
+        print(f"-- queue {q_}: busy {d / 1e6 / back:.2f} ms/step in {n // back} launches/step "
+              f"(idle inside the step {(t1 - t0 - d) / 1e6 / back:.2f} ms/step)")
