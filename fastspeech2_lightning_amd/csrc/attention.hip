@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p, const float*
   const float* base = p.qkv + (long long)b * T * ld;
   float* krow = dqkv + ((long long)b * T + key) * ld + D + h * HD;
   float* vrow = krow + D;
-  if (blockIdx.x * 64 >= len) {  // every key of this workgroup is padding: gradients are zero
+  if ((int)(blockIdx.x * 64) >= len) {  // every key of this workgroup is padding: gradients are zero
     if (key < T) {
 #pragma unroll
       for (int dt = 0; dt < NJ; ++dt) {

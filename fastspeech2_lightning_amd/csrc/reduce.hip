@@ -101,7 +101,7 @@ __global__ __launch_bounds__(1024) void reduce_rows_multi_kernel(ReduceJobs jobs
   const Fs2ReduceJob& jb = jobs.j[blockIdx.y];
   const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
-  if (blockIdx.x * 64 >= jb.n) return;  // uniform per workgroup
+  if ((int)(blockIdx.x * 64) >= jb.n) return;  // uniform per workgroup
   const float* __restrict__ src = jb.src;
   const long long stride = jb.stride;
   const int rows = jb.rows;
