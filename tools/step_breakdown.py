@@ -56,3 +56,20 @@ if "Queue_Id" in seg[0]:
     for q_, (d, n) in sorted(per_q.items(), key=lambda kv: -kv[1][0]):
         print(f"-- queue {q_}: busy {d / 1e6 / back:.2f} ms/step in {n // back} launches/step "
               f"(idle inside the step {(t1 - t0 - d) / 1e6 / back:.2f} ms/step)")
+    # the largest gaps on the busiest queue (the main chain): is it waiting for the other stream, or for the host?
+    main_q = max(per_q.items(), key=lambda kv: kv[1][0])[0]
+    mq = [r for r in seg if r["Queue_Id"] == main_q]
+    gaps = []
+    for a_, b_ in zip(mq[:-1], mq[1:]):
+        gap = int(b_["Start_Timestamp"]) - int(a_["End_Timestamp"])
+        if gap > 0:
+            gaps.append((gap, a_["Kernel_Name"], b_["Kernel_Name"]))
+    tot = sum(g[0] for g in gaps)
+    print(f"-- queue {main_q}: {len(gaps)} gaps, {tot / 1e6 / back:.2f} ms/step in total; the largest:")
+    short = lambda n: re.sub(r"\(.*", "", re.sub(r"\(anonymous namespace\)::", "", n)).replace("void ", "")[:60]
+    for gap, a_, b_ in sorted(gaps, reverse=True)[:12]:
+        print(f"   {gap / 1e3:8.1f} us  after {short(a_)}  before {short(b_)}")
+    hist = defaultdict(int)
+    for gap, _, _ in gaps:
+        hist[min(int(gap / 1e3), 20)] += 1
+    print("   gap histogram (us: count): " + " ".join(f"{k}{'+' if k == 20 else ''}:{v // back}" for k, v in sorted(hist.items())))
