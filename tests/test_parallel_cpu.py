@@ -86,3 +86,19 @@ def test_gradsync_world2_gloo():
     assert torch.equal(r0["flat"], r1["flat"])  # rank 0's weights everywhere
     assert float(r1["buf"][0]) == 1.0  # BatchNorm buffers too
     assert r0["scale"] == 0.5
+
+
+def test_weak_scaling_batches_share_the_structure_and_differ_in_content():
+    """bench.py --gpus N: every rank's synthetic batch has rank 0's lengths and durations (same padded shapes = same
+    work per GPU) and its own token ids / mel / pitch / energy."""
+    from fastspeech2_lightning_amd.synthetic import synthetic_batch
+    kw = dict(B=8, ts_lo=20, ts_hi=40, n_symbols=64, n_mels=80, dur_hi=9)
+    a = synthetic_batch(seed=1234, **kw)
+    again = synthetic_batch(seed=1234, content_seed=None, **kw)
+    b = synthetic_batch(seed=1234, content_seed=1237, **kw)
+    assert all(torch.equal(a[k], again[k]) for k in ("text", "mel", "duration", "pitch", "energy"))
+    for k in ("src_lens", "mel_lens", "duration"):
+        assert torch.equal(a[k], b[k]), k
+    assert a["mel"].shape == b["mel"].shape and a["text"].shape == b["text"].shape
+    assert not torch.equal(a["text"], b["text"]) and not torch.equal(a["mel"], b["mel"])
+    assert torch.equal(a["text"] != 0, b["text"] != 0)  # padding positions are structure too
