@@ -29,6 +29,8 @@ def ref_attention(qkv, lens, B, T, Hh):
 @pytest.mark.parametrize("B,T,Hh,hd,lens", [
     (2, 37, 2, 16, [37, 5]), (3, 130, 2, 128, [130, 64, 1]), (2, 64, 4, 32, [64, 63]), (1, 200, 2, 64, [200]),
     (2, 648, 2, 128, [648, 500]),
+    # benchmark size (more row-block workgroups than slots), ragged lengths, one very short sequence
+    (32, 648, 2, 128, [648, 430, 40] + [430 + 7 * i for i in range(29)]),
 ])
 def test_attention_fwd_bwd(H, B, T, Hh, hd, lens):
     g = torch.Generator().manual_seed(B * 1000 + T)
