@@ -4,8 +4,9 @@
 // Replaces nn.BatchNorm1d (+SiLU) in torchaudio's Conformer conv module (call sites
 // fs2/model.py:193, :241) and nn.BatchNorm1d + tanh + F.dropout in PostNet (fs2/layers.py:204-212).
 //
-//   statistics : colstats (or the depthwise-conv kernel's fused partials)  -> partial[nparts][2][C]
-//   finalize   : fp64 finish of the partials (64 channels x 16 part lanes per workgroup),
+//   statistics : colstats (or the depthwise-conv kernel's fused partials)  -> partial[nparts][2][C] = per-part
+//                (mean, sum of squared deviations), computed on pivot-shifted values
+//   finalize   : Chan merge of the parts in fp64 (64 channels x 16 part lanes per workgroup),
 //                running-stat update, per-channel scale/shift
 //   apply      : out = dropout(act(y*scale + shift))                         (one pass)
 //   backward   : reduce (sum dz, sum dz*xhat) -> finalize (dgamma, dbeta, means) -> apply
@@ -23,6 +24,10 @@ struct WideMap {
   int tpr, rpi;
 };
 
+// Per-stripe (mean, M2 = sum of squared deviations) per channel.  Sums are taken of d = y - pivot with the stripe's
+// first row as the pivot, so M2 = sum d^2 - (sum d)^2 / n subtracts two numbers of the size of the variance, not of
+// the squared mean (a plain E[y^2] - E[y]^2 in fp32 loses the variance of a channel whose |mean| >> std; torch's
+// BatchNorm is Welford).  bn_finalize merges the stripes with Chan's formula in fp64.
 __global__ __launch_bounds__(256) void colstats_wide_kernel(const float* __restrict__ y, int M, int C,
                                                              float* __restrict__ partial, WideMap wm) {
   __shared__ float4 red[2][256];
@@ -30,13 +35,16 @@ __global__ __launch_bounds__(256) void colstats_wide_kernel(const float* __restr
   const int rl = tid / wm.tpr, c4 = tid - rl * wm.tpr;
   const int rows = cs_rows(M);
   const int r0 = blockIdx.x * rows, r1 = min(M, r0 + rows);
-  float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
-  if (rl < wm.rpi)
+  float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0), pv = make_float4(0, 0, 0, 0);
+  if (rl < wm.rpi) {
+    pv = *reinterpret_cast<const float4*>(y + (long long)r0 * C + c4 * 4);
     for (int r = r0 + rl; r < r1; r += wm.rpi) {
       float4 v = *reinterpret_cast<const float4*>(y + (long long)r * C + c4 * 4);
+      v.x -= pv.x; v.y -= pv.y; v.z -= pv.z; v.w -= pv.w;
       s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
       s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
     }
+  }
   red[0][tid] = s1;
   red[1][tid] = s2;
   __syncthreads();
@@ -46,8 +54,14 @@ __global__ __launch_bounds__(256) void colstats_wide_kernel(const float* __restr
       s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
       s2.x += b.x; s2.y += b.y; s2.z += b.z; s2.w += b.w;
     }
-    *reinterpret_cast<float4*>(partial + ((long long)blockIdx.x * 2 + 0) * C + c4 * 4) = s1;
-    *reinterpret_cast<float4*>(partial + ((long long)blockIdx.x * 2 + 1) * C + c4 * 4) = s2;
+    const float inv = 1.f / (float)(r1 - r0);
+    float4 mean, m2;
+    mean.x = pv.x + s1.x * inv; m2.x = fmaxf(s2.x - s1.x * s1.x * inv, 0.f);
+    mean.y = pv.y + s1.y * inv; m2.y = fmaxf(s2.y - s1.y * s1.y * inv, 0.f);
+    mean.z = pv.z + s1.z * inv; m2.z = fmaxf(s2.z - s1.z * s1.z * inv, 0.f);
+    mean.w = pv.w + s1.w * inv; m2.w = fmaxf(s2.w - s1.w * s1.w * inv, 0.f);
+    *reinterpret_cast<float4*>(partial + ((long long)blockIdx.x * 2 + 0) * C + c4 * 4) = mean;
+    *reinterpret_cast<float4*>(partial + ((long long)blockIdx.x * 2 + 1) * C + c4 * 4) = m2;
   }
 }
 
@@ -72,22 +86,53 @@ __device__ __forceinline__ void reduce_parts(const float* __restrict__ partial, 
     }
 }
 
+// rows of part p: the parts tile groups of group_rows rows (one group = the whole matrix for colstats, one utterance
+// for the depthwise conv's fused statistics) in stripes of part_rows
+__device__ __forceinline__ int part_count(int p, int part_rows, int group_rows) {
+  const int ppg = (group_rows + part_rows - 1) / part_rows;
+  return min(part_rows, group_rows - (p % ppg) * part_rows);
+}
+
 // stats layout (per channel): [0]=scale (gamma*invstd) [1]=shift (beta-mean*scale) [2]=mean [3]=invstd
+// training: Chan's parallel merge of the per-part (n, mean, M2) in fp64 -- mean = sum n_p mean_p / N, then
+// M2 = sum [M2_p + n_p (mean_p - mean)^2]
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ partial, int nparts,
-                                                            long long count, const float* __restrict__ gamma,
+                                                            long long count, int part_rows, int group_rows,
+                                                            const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ rmean,
                                                             float* __restrict__ rvar, float momentum, float eps,
                                                             int training, float* __restrict__ stats, int C) {
-  __shared__ double red[2][16][64];
+  __shared__ double red[16][64];
+  __shared__ double mu_s[64];
   const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
   float mean = 0.f, invstd = 0.f;
   if (training) {
-    double s1, s2;
-    reduce_parts(partial, nparts, C, c, rl, lane, red, s1, s2);
+    double a = 0.0;
+    if (c < C)
+      for (int p = rl; p < nparts; p += 16)
+        a += (double)part_count(p, part_rows, group_rows) * (double)partial[((long long)p * 2 + 0) * C + c];
+    red[rl][lane] = a;
+    __syncthreads();
+    if (rl == 0) {
+      double s = 0.0;
+      for (int l = 0; l < 16; ++l) s += red[l][lane];
+      mu_s[lane] = s / (double)count;
+    }
+    __syncthreads();
+    const double mu = mu_s[lane];
+    a = 0.0;
+    if (c < C)
+      for (int p = rl; p < nparts; p += 16) {
+        const double d = (double)partial[((long long)p * 2 + 0) * C + c] - mu;
+        a += (double)partial[((long long)p * 2 + 1) * C + c] + (double)part_count(p, part_rows, group_rows) * d * d;
+      }
+    red[rl][lane] = a;
+    __syncthreads();
     if (rl != 0 || c >= C) return;
-    double mu = s1 / (double)count;
-    double var = s2 / (double)count - mu * mu;
+    double m2 = 0.0;
+    for (int l = 0; l < 16; ++l) m2 += red[l][lane];
+    double var = m2 / (double)count;
     if (var < 0.0) var = 0.0;
     mean = (float)mu;
     invstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -226,6 +271,7 @@ bool wide_ok(int C, WideMap& wm) {
 }  // namespace
 
 extern "C" int fs2hip_colstats_parts(int M) { return M > 0 ? (M + cs_rows(M) - 1) / cs_rows(M) : 0; }
+extern "C" int fs2hip_colstats_part_rows(int M) { return M > 0 ? cs_rows(M) : 0; }
 
 extern "C" int fs2hip_colstats(const float* y, int M, int C, float* partial, void* stream) {
   WideMap wm;
@@ -235,13 +281,19 @@ extern "C" int fs2hip_colstats(const float* y, int M, int C, float* partial, voi
   return 0;
 }
 
-extern "C" int fs2hip_bn_finalize(const float* partial, int nparts, long long count, const float* gamma,
-                                  const float* beta, float* running_mean, float* running_var, float momentum,
-                                  float eps, int training, float* stats, int C, void* stream) {
+extern "C" int fs2hip_bn_finalize(const float* partial, int nparts, long long count, int part_rows, int group_rows,
+                                  const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                  float momentum, float eps, int training, float* stats, int C, void* stream) {
   if (C <= 0 || (training && (nparts <= 0 || count <= 0 || !partial)) || (!training && (!running_mean || !running_var)))
     return FS2HIP_EINVAL;
+  if (training) {  // the parts must tile `count` rows exactly: groups of group_rows rows in stripes of part_rows
+    if (part_rows <= 0 || group_rows <= 0 || count % group_rows) return FS2HIP_EINVAL;
+    const long long ppg = (group_rows + part_rows - 1) / part_rows;
+    if (ppg * (count / group_rows) != nparts) return FS2HIP_EINVAL;
+  }
   bn_finalize_kernel<<<dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream>>>(
-      partial, nparts, count, gamma, beta, running_mean, running_var, momentum, eps, training, stats, C);
+      partial, nparts, count, part_rows, group_rows, gamma, beta, running_mean, running_var, momentum, eps, training,
+      stats, C);
   FS2_LAUNCH_CHECK();
   return 0;
 }

@@ -39,7 +39,9 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict
     }
     a[i] = v;
   }
-  float s1 = 0.f, s2 = 0.f;
+  // BatchNorm statistics of this thread's run as (n, mean, M2): sums of (y - pivot), pivot = the run's first output
+  // (bn.hip explains why not sum / sum of squares)
+  float s1 = 0.f, s2 = 0.f, pivot = 0.f;
 #pragma unroll
   for (int o = 0; o < RUN; ++o) {
     int t = t0 + o;
@@ -48,18 +50,35 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict
 #pragma unroll
       for (int k = 0; k < K; ++k) acc = fmaf(wk[k], a[o + k], acc);
       y[((long long)b * T + t) * C + c] = acc;
-      s1 += acc;
-      s2 += acc * acc;
+      if (STATS) {
+        if (o == 0) pivot = acc;
+        const float d = acc - pivot;
+        s1 += d;
+        s2 += d * d;
+      }
     }
   }
   if (STATS) {
-    red[wave][0][lane] = s1;
-    red[wave][1][lane] = s2;
+    const int nw = max(0, min(RUN, T - t0));  // rows of this wavefront's run (uniform over its lanes)
+    const float inv = nw > 0 ? 1.f / (float)nw : 0.f;
+    red[wave][0][lane] = pivot + s1 * inv;
+    red[wave][1][lane] = fmaxf(s2 - s1 * s1 * inv, 0.f);
     __syncthreads();
     if (wave == 0 && cok) {
+      float n = 0.f, mean = 0.f, m2 = 0.f;  // Chan merge of the four runs
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const float nr = (float)max(0, min(RUN, T - (t0 + w * RUN)));
+        if (nr > 0.f) {
+          const float delta = red[w][0][lane] - mean, nt = n + nr;
+          mean += delta * (nr / nt);
+          m2 += red[w][1][lane] + delta * delta * (n * nr / nt);
+          n = nt;
+        }
+      }
       long long blk = (long long)b * gridDim.y + blockIdx.y;
-      partial[(blk * 2 + 0) * C + c] = red[0][0][lane] + red[1][0][lane] + red[2][0][lane] + red[3][0][lane];
-      partial[(blk * 2 + 1) * C + c] = red[0][1][lane] + red[1][1][lane] + red[2][1][lane] + red[3][1][lane];
+      partial[(blk * 2 + 0) * C + c] = mean;
+      partial[(blk * 2 + 1) * C + c] = m2;
     }
   }
 }
@@ -141,6 +160,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict
 }  // namespace
 
 extern "C" int fs2hip_dwconv_blocks(int B, int T) { return B * ((T + 4 * RUN - 1) / (4 * RUN)); }
+extern "C" int fs2hip_dwconv_part_rows(void) { return 4 * RUN; }
 
 #define DW_FWD(KK)                                                                                              \
   if (glu && stats) dwconv_fwd_kernel<KK, true, true><<<grid, dim3(256), 0, s>>>(x, ldx, w, bias, y, partial, B, T, C); \

@@ -138,9 +138,9 @@ class BatchNorm:
         S.add_buffer(prefix + "running_var", torch.ones(dim))
         S.add_buffer(prefix + "num_batches_tracked", torch.zeros((), dtype=torch.long))
 
-    def stats(self, partial, nparts, count, training):
+    def stats(self, parts, training):
         S, p = self.S, self.prefix
-        st = H.bn_finalize(partial, nparts, count, S.p(p + "weight"), S.p(p + "bias"), S.b(p + "running_mean"),
+        st = H.bn_finalize(parts, S.p(p + "weight"), S.p(p + "bias"), S.b(p + "running_mean"),
                            S.b(p + "running_var"), training=training)
         # num_batches_tracked is advanced once per training forward for all layers (ParamStore.bn_counters)
         return st
@@ -254,8 +254,8 @@ class ConvModule:
         B, T, _ = x.shape
         h, ln_saved = self.ln.fwd(x)
         g2 = H.linear_fwd(h, S.p(self.w1), S.p(self.b1))
-        c, partial, nparts = H.dwconv_fwd(g2, S.p(self.wd), S.p(self.bd), B, T, glu=True, stats=env.training)
-        stats = self.bn.stats(partial, nparts, B * T, env.training)
+        c, parts = H.dwconv_fwd(g2, S.p(self.wd), S.p(self.bd), B, T, glu=True, stats=env.training)
+        stats = self.bn.stats(parts, env.training)
         s = H.bn_act_fwd(c, stats, "silu")
         y = H.linear_fwd(s, S.p(self.w2), S.p(self.b2), epi=H.EPI_RESID, resid=x, drop=env.drop(self.p, self.site))
         return y, Ctx(ln=ln_saved, h=h, g2=g2, c=c, stats=stats, s=s)
@@ -368,7 +368,7 @@ class VariancePredictor:
         saved = []
         for L in self.layers:
             if self.depthwise:
-                c, _, _ = H.dwconv_fwd(x, S.p(L["wd"]), S.p(L["bd"]), B, T)
+                c, _ = H.dwconv_fwd(x, S.p(L["wd"]), S.p(L["bd"]), B, T)
                 r = H.linear_fwd(c, S.p(L["wp"]), S.p(L["bp"]), epi=H.EPI_ACT, act="relu")
             else:
                 c = None
@@ -523,8 +523,7 @@ class StyleEncoder:
         for w, bn, c in self.convs:
             raw = H.conv2d_s2_fwd(x, S.p(w))
             rows = raw.numel() // c
-            partial, nparts = H.colstats(raw.view(rows, c)) if env.training else (None, 0)
-            stats = bn.stats(partial, nparts, rows, env.training)
+            stats = bn.stats(H.colstats(raw.view(rows, c)) if env.training else None, env.training)
             y = H.bn_act_fwd(raw.view(rows, c), stats, "relu").view(raw.shape)
             conv_saved.append((x, raw, stats))
             x = y
@@ -625,8 +624,7 @@ class PostNet:
         saved = []
         for i, (w, b, bn, site) in enumerate(self.convs):
             raw = H.linear_fwd(x, S.p(w), S.p(b), taps=self.k, T=T)
-            partial, nparts = H.colstats(raw) if env.training else (None, 0)
-            stats = bn.stats(partial, nparts, B * T, env.training)
+            stats = bn.stats(H.colstats(raw) if env.training else None, env.training)
             act = "tanh" if i < self.n - 1 else None
             out = H.bn_act_fwd(raw, stats, act, env.drop(self.dropout_p, site))
             saved.append((x, raw, stats))

@@ -163,12 +163,14 @@ int fs2hip_attention_bwd(const float* qkv, const int* lens, const float* o, cons
  * Depthwise Conv1d over time on (B, T, C), 'same' padding, K in {3,5,7,9,15,31}; w is [K][C].
  * glu = 1: the input has 2C columns (value | gate) and a = value * sigmoid(gate) is formed on
  * the fly (torchaudio conv module: Conv1d(D,2D,1) -> GLU -> depthwise Conv1d).
- * stats = 1: also writes per-workgroup (sum, sum of squares) per channel for BatchNorm:
- *            partial[fs2hip_dwconv_blocks(B,T)][2][C].
+ * stats = 1: also writes per-workgroup (mean, sum of squared deviations) per channel for BatchNorm:
+ *            partial[fs2hip_dwconv_blocks(B,T)][2][C]; a workgroup covers fs2hip_dwconv_part_rows()
+ *            time steps of one utterance (bn_finalize: part_rows = that, group_rows = T).
  * Also the depthwise half of fs2/blocks.py:8-13.
  * bwd: dx has the layout of x; partial [blocks][K+1][C]; dw [K][C] and dbias [C] are finished.
  * ------------------------------------------------------------------------------------ */
 int fs2hip_dwconv_blocks(int B, int T);
+int fs2hip_dwconv_part_rows(void);
 int fs2hip_dwconv_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, float* partial,
                       int B, int T, int C, int K, int glu, int stats, void* stream);
 int fs2hip_dwconv_bwd(const float* dy, const float* x, int ldx, const float* w, float* dx, float* partial,
@@ -177,17 +179,22 @@ int fs2hip_dwconv_bwd(const float* dy, const float* x, int ldx, const float* w, 
 /* ------------------------------------------------------------------------------------
  * BatchNorm1d over the channels of [M][C] (+ activation + dropout), fs2/layers.py:204-212 and
  * the Conformer conv module.  stats is [4][C]: scale, shift, mean, invstd.
- *   colstats   : partial[fs2hip_colstats_parts(M)][2][C] = per-stripe (sum, sum sq)
- *   finalize   : training: batch statistics (fp64 finish) + running-stat update (momentum,
- *                unbiased variance); eval: running statistics
+ *   colstats   : partial[fs2hip_colstats_parts(M)][2][C] = per-stripe (mean, sum of squared
+ *                deviations) over stripes of fs2hip_colstats_part_rows(M) rows, accumulated on
+ *                pivot-shifted values (torch's BatchNorm is Welford: a plain E[x^2]-E[x]^2 in fp32
+ *                loses the variance of a channel whose |mean| >> std)
+ *   finalize   : training: Chan merge of the parts in fp64 (the parts tile `count` rows in groups
+ *                of group_rows rows, each in stripes of part_rows) + running-stat update
+ *                (momentum, unbiased variance); eval: running statistics
  *   bn_act_fwd : out = dropout(act(y*scale + shift))
  *   bn_act_bwd : dy (grad of y), dgamma, dbeta; partial as colstats, coef [2][C] scratch
  * ------------------------------------------------------------------------------------ */
 int fs2hip_colstats_parts(int M);
+int fs2hip_colstats_part_rows(int M);
 int fs2hip_colstats(const float* y, int M, int C, float* partial, void* stream);
-int fs2hip_bn_finalize(const float* partial, int nparts, long long count, const float* gamma,
-                       const float* beta, float* running_mean, float* running_var, float momentum,
-                       float eps, int training, float* stats, int C, void* stream);
+int fs2hip_bn_finalize(const float* partial, int nparts, long long count, int part_rows, int group_rows,
+                       const float* gamma, const float* beta, float* running_mean, float* running_var,
+                       float momentum, float eps, int training, float* stats, int C, void* stream);
 int fs2hip_bn_act_fwd(const float* y, const float* stats, float* out, int M, int C, int act, float drop_p,
                       unsigned long long drop_seed, const unsigned long long* drop_step, void* stream);
 int fs2hip_bn_act_bwd(const float* dout, const float* y, const float* stats, float* partial, float* coef,

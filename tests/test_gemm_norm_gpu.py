@@ -8,7 +8,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.tuned_tiles]
 
 
 @pytest.fixture(scope="module")

@@ -37,10 +37,19 @@ def test_dwconv(H, K, C, glu):
     a = F.glu(x, dim=-1) if glu else x
     ref = F.conv1d(a.transpose(1, 2), w, b, padding=(K - 1) // 2, groups=C).transpose(1, 2)
     wk = w.detach()[:, 0, :].t().contiguous().cuda()  # [K, C]
-    y, partial, nparts = H.dwconv_fwd(x.detach().cuda(), wk, b.detach().cuda(), B, T, glu=glu, stats=True)
+    y, parts = H.dwconv_fwd(x.detach().cuda(), wk, b.detach().cuda(), B, T, glu=glu, stats=True)
     close(y, ref, msg="dwconv fwd")
-    close(partial.sum(0)[0], ref.reshape(-1, C).sum(0), 1e-4, "stats sum")
-    close(partial.sum(0)[1], (ref ** 2).reshape(-1, C).sum(0), 1e-4, "stats sumsq")
+    # fused BatchNorm statistics: per part (mean, sum of squared deviations) over 64-step stripes of one utterance
+    assert parts.part_rows == 64 and parts.group_rows == T and parts.count == B * T
+    stripes = [ref[bb, t0:t0 + 64].double() for bb in range(B) for t0 in range(0, T, 64)]
+    assert parts.nparts == len(stripes)
+    close(parts.partial[:, 0], torch.stack([sp.mean(0) for sp in stripes]), 1e-5, "stripe means")
+    close(parts.partial[:, 1], torch.stack([((sp - sp.mean(0)) ** 2).sum(0) for sp in stripes]), 1e-5, "stripe M2")
+    one, zero = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+    st = H.bn_finalize(parts, one, zero, None, None, training=True)
+    flat = ref.reshape(-1, C).double()
+    close(st[2], flat.mean(0), 1e-6, "fused mean")
+    close(st[3], 1 / torch.sqrt(flat.var(0, unbiased=False) + 1e-5), 1e-6, "fused invstd")
     dy = rnd(B, T, C, seed=4)
     ref.backward(dy)
     dw, db = torch.empty(K, C, device="cuda"), torch.empty(C, device="cuda")
@@ -60,8 +69,7 @@ def test_batchnorm_train_and_eval(H, act, C):
     f = {"silu": F.silu, "tanh": torch.tanh, None: lambda t: t}[act]
     ref = f(F.batch_norm(y, rm_ref, rv_ref, g, b, training=True, momentum=0.1, eps=1e-5))
     rm_d, rv_d = rm.cuda(), rv.cuda()
-    partial, nparts = H.colstats(y.detach().cuda())
-    stats = H.bn_finalize(partial, nparts, M, g.detach().cuda(), b.detach().cuda(), rm_d, rv_d, training=True)
+    stats = H.bn_finalize(H.colstats(y.detach().cuda()), g.detach().cuda(), b.detach().cuda(), rm_d, rv_d, training=True)
     out = H.bn_act_fwd(y.detach().cuda(), stats, act)
     close(out, ref, msg="bn fwd")
     close(rm_d, rm_ref, msg="running mean")
@@ -74,10 +82,61 @@ def test_batchnorm_train_and_eval(H, act, C):
     close(dg, g.grad, 1e-4, "bn dgamma")
     close(db, b.grad, 1e-4, "bn dbeta")
     # eval mode uses the running statistics
-    stats_e = H.bn_finalize(None, 0, 0, g.detach().cuda(), b.detach().cuda(), rm_d, rv_d, training=False)
+    stats_e = H.bn_finalize(None, g.detach().cuda(), b.detach().cuda(), rm_d, rv_d, training=False)
     out_e = H.bn_act_fwd(y.detach().cuda(), stats_e, act)
     ref_e = f(F.batch_norm(y.detach(), rm_ref, rv_ref, g.detach(), b.detach(), training=False, eps=1e-5))
     close(out_e, ref_e, msg="bn eval")
+
+
+@pytest.mark.parametrize("M,C,offset,std", [
+    (1234, 256, 50.0, 1e-2),    # |mean| / std = 5000: E[x^2] - E[x]^2 in fp32 has no correct digit left here
+    (20736, 512, 100.0, 1.0),   # benchmark-size column, |mean| / std = 100
+    (3, 256, 5.0, 0.05),        # three rows (the smallest decoder the ragged-batch test builds)
+    (2, 64, -3.0, 0.5),         # two rows
+    (70000, 32, 10.0, 0.1),     # more stripes than one finalize pass of 16 lanes (and cs_rows > 32)
+])
+def test_batchnorm_statistics_are_welford_accurate(H, M, C, offset, std):
+    """Batch statistics of channels whose |mean| >> std, and of 2-3 rows, against float64 and ``F.batch_norm``
+    (torch's CPU BatchNorm is Welford).  The variance must be right to fp32 accuracy OF THE VARIANCE: invstd within
+    1e-4 relative where a sum / sum-of-squares formula is off by tens of percent."""
+    g0 = torch.Generator().manual_seed(M + C)
+    y = (offset * (1 + 0.1 * torch.randn(C, generator=g0)) + std * torch.randn(M, C, generator=g0)).float()
+    yd = y.double()
+    mean64, var64 = yd.mean(0), yd.var(0, unbiased=False)
+    one, zero = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+    rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    st = H.bn_finalize(H.colstats(y.cuda()), one, zero, rm, rv, training=True)
+    inv64 = 1 / torch.sqrt(var64 + 1e-5)
+    assert float(((st[2].cpu().double() - mean64).abs() / mean64.abs()).max()) < 1e-6
+    assert float(((st[3].cpu().double() - inv64).abs() / inv64).max()) < 1e-4
+    rm_ref, rv_ref = torch.zeros(C), torch.ones(C)
+    ref = F.batch_norm(y, rm_ref, rv_ref, None, None, training=True, momentum=0.1, eps=1e-5)
+    out = H.bn_act_fwd(y.cuda(), st, None).cpu().double()
+    # the normalised values carry the rounding of mean * invstd (a number of size |mean| / std, per channel) whatever
+    # the algorithm: bound each channel by that, against float64, and require to be no worse than torch's own result
+    ref64 = (yd - mean64) * inv64
+    bound = 2e-5 + 4 * 6e-8 * mean64.abs() * inv64
+    assert bool(((out - ref64).abs().amax(0) < bound).all())
+    assert float((out - ref64).abs().max()) < 2 * float((ref.double() - ref64).abs().max()) + 2e-5
+    close(rv, rv_ref, 1e-4, "running var")
+    close(rm, rm_ref, 1e-6, "running mean")
+
+
+def test_dwconv_fused_statistics_large_offset(H):
+    """The depthwise conv's fused statistics with a bias that puts every channel at |mean| / std ~ 1000."""
+    B, T, C, K = 3, 150, 256, 9
+    x = rnd(B, T, C, seed=11) * 0.01
+    w = rnd(K, C, seed=12, scale=0.3)
+    b = 20.0 + rnd(C, seed=13)
+    ref = F.conv1d(x.transpose(1, 2), w.t().unsqueeze(1), b, padding=4, groups=C).transpose(1, 2).reshape(-1, C).double()
+    y, parts = H.dwconv_fwd(x.cuda(), w.cuda(), b.cuda(), B, T, stats=True)
+    one, zero = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+    st = H.bn_finalize(parts, one, zero, None, None, training=True)
+    yd = y.reshape(-1, C).cpu().double()  # statistics of the values the kernel itself produced
+    inv64 = 1 / torch.sqrt(yd.var(0, unbiased=False) + 1e-5)
+    assert float(((st[3].cpu().double() - inv64).abs() / inv64).max()) < 1e-4
+    assert float(((st[2].cpu().double() - yd.mean(0)).abs() / yd.mean(0).abs()).max()) < 1e-6
+    assert float((yd - ref).abs().max()) < 1e-4
 
 
 def test_posenc_embedding_bucketize(H, golden_dir):

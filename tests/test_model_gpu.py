@@ -159,8 +159,8 @@ def test_against_oracle_on_fresh_inputs_with_default_widths(level):
 
 
 @pytest.mark.parametrize("B,ts_lo,ts_hi,dur_hi,tol", [
-    (1, 2, 2, 2, 5e-2),       # two tokens, three frames: BatchNorm over 2-3 rows is ill-conditioned on both sides
-                              # (fp32 summation order alone moves these gradients by up to ~1 %): a smoke-level bound
+    (1, 2, 2, 2, 5e-3),       # two tokens, three frames: BatchNorm over 2-3 rows (Welford-accurate statistics in
+                              # bn.hip / conv.hip and the deterministic tile mode keep this at the 5e-3 bound)
     (2, 1, 9, 3, 1e-5),       # a one-token utterance beside a longer one
     (5, 3, 40, 6, 1e-5),      # ragged batch, lengths not multiples of anything
     (1, 130, 140, 9, 1e-5),   # more than 128 tokens / one long utterance (generic alignment / tile edges)
