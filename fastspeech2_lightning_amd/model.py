@@ -568,7 +568,7 @@ class FastSpeech2(_Base):
         output = self(batch)
         losses = self.loss(output, self._ctx["batch"], self.current_epoch)
         self.backward()
-        self.last_losses = losses
+        self.last_losses, self.last_output = losses, output
         return losses["total"]
 
     def validation_step(self, batch, batch_idx=0):

@@ -30,14 +30,53 @@ from torch import nn
 
 
 # --------------------------------------------------------------------------- #
+# Dropout with an injectable mask (test infrastructure only)
+# --------------------------------------------------------------------------- #
+class MaskedDropout(nn.Dropout):
+    """``nn.Dropout`` whose random mask can be replaced by a given one: ``factor`` (0 or 1/(1-p) per element, in the
+    layout of this site's input) is what the HIP kernels' stateless hash draws for the site, exported by
+    ``tests/dropout_masks.py`` -- the only way to compare a dropout-ON train step element by element.  With
+    ``factor = None`` it is ``nn.Dropout``.  No parameters: state-dict keys are unchanged."""
+    factor: Optional[torch.Tensor] = None
+
+    def forward(self, x):
+        if self.factor is None or not self.training:
+            return super().forward(x)
+        assert self.factor.shape == x.shape, (tuple(self.factor.shape), tuple(x.shape))
+        return x * self.factor
+
+
+def _mha_with_prob_factor(mha: nn.MultiheadAttention, x, key_padding_mask, factor):
+    """``nn.MultiheadAttention`` (seq-first self-attention, need_weights=False) written out so that the dropout on the
+    attention probabilities can take an injected mask: ``factor`` [B, H, T, T].  Same arithmetic as
+    ``F.multi_head_attention_forward``: in_proj -> split heads -> q / sqrt(hd) -> softmax(q k^T + key mask) -> dropout
+    -> @ v -> out_proj (``tests/test_oracle_golden.py`` checks it against the module with dropout off)."""
+    T, B, D = x.shape
+    H = mha.num_heads
+    hd = D // H
+    qkv = F.linear(x, mha.in_proj_weight, mha.in_proj_bias)
+    q, k, v = qkv.chunk(3, dim=-1)
+    q = q.reshape(T, B * H, hd).transpose(0, 1) * (hd ** -0.5)
+    k = k.reshape(T, B * H, hd).transpose(0, 1)
+    v = v.reshape(T, B * H, hd).transpose(0, 1)
+    s = torch.bmm(q, k.transpose(1, 2)).view(B, H, T, T)
+    s = s.masked_fill(key_padding_mask[:, None, None, :], float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    if factor is not None:
+        p = p * factor
+    o = torch.bmm(p.view(B * H, T, T), v).transpose(0, 1).reshape(T, B, D)
+    return F.linear(o, mha.out_proj.weight, mha.out_proj.bias)
+
+
+# --------------------------------------------------------------------------- #
 # Conformer (torchaudio.models.Conformer restated; call sites fs2/model.py:95-119)
 # --------------------------------------------------------------------------- #
 class _FeedForward(nn.Module):
     def __init__(self, d: int, f: int, p: float):
         super().__init__()
         self.sequential = nn.Sequential(
-            nn.LayerNorm(d), nn.Linear(d, f), nn.SiLU(), nn.Dropout(p),
-            nn.Linear(f, d), nn.Dropout(p),
+            nn.LayerNorm(d), nn.Linear(d, f), nn.SiLU(), MaskedDropout(p),
+            nn.Linear(f, d), MaskedDropout(p),
         )
 
     def forward(self, x):
@@ -51,7 +90,7 @@ class _ConvModule(nn.Module):
         self.sequential = nn.Sequential(
             nn.Conv1d(d, 2 * d, 1), nn.GLU(dim=1),
             nn.Conv1d(d, d, k, padding=(k - 1) // 2, groups=d),
-            nn.BatchNorm1d(d), nn.SiLU(), nn.Conv1d(d, d, 1), nn.Dropout(p),
+            nn.BatchNorm1d(d), nn.SiLU(), nn.Conv1d(d, d, 1), MaskedDropout(p),
         )
 
     def forward(self, x):  # x: (B, T, D)
@@ -65,7 +104,8 @@ class _ConformerLayer(nn.Module):
         self.ffn1 = _FeedForward(d, f, p)
         self.self_attn_layer_norm = nn.LayerNorm(d)
         self.self_attn = nn.MultiheadAttention(d, heads, dropout=p)
-        self.self_attn_dropout = nn.Dropout(p)
+        self.self_attn_dropout = MaskedDropout(p)
+        self.attn_prob_factor = None  # injected attention-probability dropout mask [B, H, T, T] (tests only)
         self.conv_module = _ConvModule(d, k, p)
         self.ffn2 = _FeedForward(d, f, p)
         self.final_layer_norm = nn.LayerNorm(d)
@@ -74,7 +114,10 @@ class _ConformerLayer(nn.Module):
         x = 0.5 * self.ffn1(x) + x
         r = x
         h = self.self_attn_layer_norm(x)
-        h, _ = self.self_attn(h, h, h, key_padding_mask=key_padding_mask, need_weights=False)
+        if self.attn_prob_factor is not None and self.training:
+            h = _mha_with_prob_factor(self.self_attn, h, key_padding_mask, self.attn_prob_factor)
+        else:
+            h, _ = self.self_attn(h, h, h, key_padding_mask=key_padding_mask, need_weights=False)
         x = self.self_attn_dropout(h) + r
         x = x + self.conv_module(x.transpose(0, 1)).transpose(0, 1)
         x = 0.5 * self.ffn2(x) + x
@@ -114,7 +157,7 @@ class PositionalEmbedding(nn.Module):
         self.register_buffer("inv_freq", 1 / (10000 ** (torch.arange(0.0, d, 2.0) / d)))
 
     def forward(self, pos_seq):  # (T,) -> (1, T, d): [sin | cos] concatenated
-        ang = pos_seq[:, None] @ self.inv_freq[None, :]
+        ang = pos_seq[:, None].to(self.inv_freq.dtype) @ self.inv_freq[None, :]
         return torch.cat([ang.sin(), ang.cos()], dim=1)[None]
 
 
@@ -145,7 +188,7 @@ class VarianceConvolutionLayer(nn.Module):
     def __init__(self, cin, cout, k, dropout, depthwise):
         super().__init__()
         conv = _Model(cin, cout, k) if depthwise else nn.Conv1d(cin, cout, k, padding=(k - 1) // 2)
-        self.layers = nn.Sequential(_Transpose(conv), nn.ReLU(), nn.LayerNorm(cout), nn.Dropout(dropout))
+        self.layers = nn.Sequential(_Transpose(conv), nn.ReLU(), nn.LayerNorm(cout), MaskedDropout(dropout))
 
     def forward(self, x):
         return self.layers(x)
@@ -353,6 +396,7 @@ class PostNet(nn.Module):
     def __init__(self, n_mel=80, dim=512, k=5, n=5):
         super().__init__()
         self.dropout_p = 0.5  # hard-coded in the reference; tests set 0 for determinism
+        self.drop_factors = None  # injected masks, one (B, C, T) factor per layer (tests only)
         chans = [n_mel] + [dim] * (n - 1) + [n_mel]
         self.convolutions = nn.ModuleList(
             nn.Sequential(_ConvNorm(chans[i], chans[i + 1], k, "tanh" if i < n - 1 else "linear"),
@@ -366,7 +410,10 @@ class PostNet(nn.Module):
             x = c(x)
             if i < len(self.convolutions) - 1:
                 x = torch.tanh(x)
-            x = F.dropout(x, self.dropout_p, self.training)
+            if self.drop_factors is not None and self.training:
+                x = x * self.drop_factors[i]
+            else:
+                x = F.dropout(x, self.dropout_p, self.training)
         return x.transpose(1, 2)
 
 
@@ -467,7 +514,7 @@ def fastspeech2_loss(config, output, batch, current_epoch: int) -> dict:
         c = getattr(m.variance_predictors, name)
         mask = src_mask if c.level.value == "phone" else tgt_mask
         losses[name] = fn[c.loss.value](output[f"{name}_prediction"] * mask, tgt * mask) * w
-    log_d = torch.log(output["duration_target"].float() + 1) * src_mask
+    log_d = torch.log(output["duration_target"].to(output["duration_prediction"].dtype) + 1) * src_mask
     losses["duration"] = fn[m.variance_predictors.duration.loss.value](
         output["duration_prediction"] * src_mask, log_d) * t.duration_loss_weight
     tm = tgt_mask.unsqueeze(2)

@@ -1,0 +1,71 @@
+"""Exports the HIP kernels' dropout masks and injects them into the CPU oracle (test infrastructure).
+
+The kernels never store a mask: every dropout site draws ``keep = hash(seed(site, step), element index) >= p * 2^32``
+(``csrc/common.h``) on the fly, in the forward kernel and again in the backward kernel, the element index being the
+linear index of the site's tensor in its natural layout ([B*T, C] rows for GEMM epilogues / BatchNorm+activation /
+elementwise kernels, [B, H, T, T] for the attention probabilities).  ``fs2hip_axpby`` applied to a vector of ones with a
+site's ``Drop`` record writes exactly those factors (0 or 1/(1-p)) -- the same device function, the same seed and the
+same device-resident step counter -- so ``site_factors`` is the debug export of a site's mask, and
+``inject`` puts each one into the oracle's matching ``MaskedDropout`` / attention / PostNet site in that site's layout.
+A dropout-ON train step can then be compared element by element with the usual tolerances.
+"""
+from __future__ import annotations
+
+import torch
+
+from fastspeech2_lightning_amd import hip as H
+
+
+def site_factors(model, p: float, site: int, *shape) -> torch.Tensor:
+    """The factors the kernels apply at dropout site ``site`` at the model's CURRENT device step, as a CPU tensor."""
+    drop = model.env.drop(p, site)
+    n = 1
+    for s in shape:
+        n *= s
+    if drop.p <= 0:
+        return torch.ones(*shape)
+    ones = torch.ones(n, device=model.device_, dtype=torch.float32)
+    return H.axpby(ones, None, 1.0, 0.0, drop).view(*shape).cpu()
+
+
+def _conformer(model, stack, ostack, cfg, B, T):
+    p, heads, D, Fd = cfg.dropout, cfg.heads, cfg.input_dim, cfg.feedforward_dim
+    for layer, olayer in zip(stack.layers, ostack.conformer_layers):
+        tb = lambda t: t.permute(1, 0, 2).contiguous()  # (B, T, C) -> the oracle's (T, B, C)  # noqa: E731
+        for ffn, offn in ((layer.ffn1, olayer.ffn1), (layer.ffn2, olayer.ffn2)):
+            offn.sequential[3].factor = tb(site_factors(model, p, ffn.s1, B, T, Fd))
+            offn.sequential[5].factor = tb(site_factors(model, p, ffn.s2, B, T, D))
+        olayer.attn_prob_factor = site_factors(model, p, layer.attn.sa, B, heads, T, T) if p > 0 else None
+        olayer.self_attn_dropout.factor = tb(site_factors(model, p, layer.attn.so, B, T, D))
+        # conv module: the oracle's Sequential runs on (B, D, T)
+        olayer.conv_module.sequential[6].factor = site_factors(model, p, layer.conv.site, B, T, D).permute(0, 2, 1).contiguous()
+
+
+def inject(model, oracle, B: int, Ts: int, Tm: int) -> dict:
+    """Gives every dropout site of ``oracle`` the mask the HIP model draws at its current step.  Returns
+    {site name: keep fraction} for the sites that are on."""
+    m = model.config.model
+    _conformer(model, model.encoder, oracle.encoder, m.encoder, B, Ts)
+    _conformer(model, model.decoder, oracle.decoder, m.decoder, B, Tm)
+    va, ova = model.variance_adaptor, oracle.variance_adaptor
+    seen = {}
+    for name in ("energy", "pitch", "duration"):
+        c = getattr(m.variance_predictors, name)
+        T = Tm if (name != "duration" and c.level.value == "frame") else Ts
+        pred, opred = getattr(va, f"{name}_predictor"), getattr(ova, f"{name}_predictor")
+        for L, ol in zip(pred.layers, opred.conv):
+            f = site_factors(model, c.dropout, L["site"], B, T, c.input_dim)
+            ol.layers[3].factor = f
+            seen[f"{name}.{L['site']}"] = float((f > 0).float().mean())
+    if model.postnet is not None:
+        facs = []
+        for (w, b, bn, site) in model.postnet.convs:
+            cout = model.store.p(b).numel()
+            f = site_factors(model, model.postnet.dropout_p, site, B, Tm, cout)
+            facs.append(f.permute(0, 2, 1).contiguous())
+            seen[f"postnet.{site}"] = float((f > 0).float().mean())
+        oracle.postnet.drop_factors = facs if model.postnet.dropout_p > 0 else None
+    for i, ol in enumerate(oracle.decoder.conformer_layers):
+        if ol.attn_prob_factor is not None:
+            seen[f"decoder.{i}.attn_prob"] = float((ol.attn_prob_factor > 0).float().mean())
+    return seen

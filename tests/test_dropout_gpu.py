@@ -1,0 +1,129 @@
+"""The benchmarked configuration has dropout ON (Conformer 0.2 incl. attention probabilities, predictors 0.5,
+PostNet 0.5 -- ``bench.py``).  These tests verify that configuration end to end: the kernels' stateless masks are
+exported (``tests/dropout_masks.py``), injected into the CPU oracle's dropout sites, and a whole train step (forward,
+every loss term, every parameter gradient) is compared at the tolerances of the dropout-off tests: loss terms 1e-4
+relative, gradients 2e-3 of each tensor's max.  A second step after ``optimizer.step()`` checks that the device step
+counter advances the masks and that forward and backward kernels of a step still agree on them."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from fastspeech2_lightning_amd.config import FastSpeech2Config, Stats
+from oracle import cases as C
+from oracle import fs2_oracle as O
+from tests import dropout_masks as DM
+
+pytestmark = pytest.mark.gpu
+
+
+def default_width_config(p_conformer, p_predictor, layers=4):
+    conf = dict(layers=layers, dropout=p_conformer)
+    vp = dict(dropout=p_predictor)
+    return FastSpeech2Config(
+        model=dict(encoder=conf, decoder=conf, learn_alignment=False,
+                   variance_predictors=dict(energy=vp, pitch=vp, duration=vp)),
+        text=dict(symbols=dict(letters=[f"s{i}" for i in range(40)])))
+
+
+def compare_step(model, oracle, batch, tag):
+    B, Ts, Tm = batch["text"].shape[0], batch["text"].shape[1], batch["mel"].shape[1]
+    seen = DM.inject(model, oracle, B, Ts, Tm)
+    oracle.zero_grad()
+    ref = oracle(batch)
+    ref_losses = oracle.loss(ref, batch, 0)
+    ref_losses["total"].backward()
+    total = model.training_step(batch)
+    out = model.last_output
+    for k in ("output", "postnet_output", "duration_prediction", "pitch_prediction", "energy_prediction"):
+        a, b = out[k].cpu(), ref[k].detach()
+        assert float((a - b).abs().max()) < 1e-4 * max(1.0, float(b.abs().max())), (tag, k)
+    for k, v in model.last_losses.items():
+        assert abs(float(v) - float(ref_losses[k])) < 1e-4 * max(1.0, abs(float(ref_losses[k]))), (tag, k)
+    got = model.store.grad_state_dict()
+    gmax = max(float(p.grad.abs().max()) for p in oracle.parameters() if p.grad is not None)
+    worst = ("", 0.0)
+    for k, p in oracle.named_parameters():
+        if p.grad is None:
+            continue
+        scale = max(float(p.grad.abs().max()), 1e-4 * gmax)
+        r = float((got[k].cpu() - p.grad).abs().max()) / scale
+        if r > worst[1]:
+            worst = (k, r)
+    assert worst[1] < 2e-3, (tag, worst)
+    return seen, float(total)
+
+
+@pytest.mark.parametrize("p_conf,p_pred,p_post,layers", [
+    (0.2, 0.5, 0.5, 4),   # the benchmark's setting: every site on, default model (4+4 layers, D=256, F=1024)
+    (0.0, 0.5, 0.0, 1),   # predictor sites alone (a mismatch localises)
+    (0.0, 0.0, 0.5, 1),   # PostNet's BatchNorm + tanh + dropout alone
+    (0.2, 0.0, 0.0, 1),   # Conformer sites alone: GEMM epilogues, attention probabilities, residual branches
+])
+def test_train_step_with_dropout_on_matches_oracle_with_the_same_masks(p_conf, p_pred, p_post, layers):
+    from fastspeech2_lightning_amd.model import FastSpeech2
+    config = default_width_config(p_conf, p_pred, layers)
+    batch = O.synthetic_batch(B=4, ts_lo=20, ts_hi=40, n_symbols=41, n_mels=80, seed=7, dur_hi=6)
+    model = FastSpeech2(config, Stats(**C.STATS), seed=99)
+    oracle = O.FastSpeech2Oracle(config, Stats(**C.STATS), n_symbols=41)
+    sd = O.seeded_state_dict(oracle.state_dict())
+    oracle.load_state_dict(sd)
+    model.load_state_dict(sd)
+    model.train(); oracle.train()
+    model.postnet.dropout_p = oracle.postnet.dropout_p = p_post
+    opt = model.configure_optimizers()[0][0]
+    seen0, loss0 = compare_step(model, oracle, batch, "step 0")
+    # the masks are really on, with the right keep fraction
+    for name, keep in seen0.items():
+        p = p_pred if name.split(".")[0] in ("energy", "pitch", "duration") else (p_post if name.startswith("postnet") else p_conf)
+        if p > 0:
+            assert abs(keep - (1 - p)) < 0.05, (name, keep)
+    if p_conf > 0:
+        f0 = oracle.decoder.conformer_layers[0].ffn1.sequential[3].factor.clone()
+        a0 = oracle.decoder.conformer_layers[0].attn_prob_factor.clone()
+    # second step: the optimizer advances the device step counter, the masks change, forward and backward still agree
+    opt.step()
+    torch.cuda.synchronize()
+    assert opt.record()["step"] == 1
+    oracle.load_state_dict(model.state_dict())
+    seen1, loss1 = compare_step(model, oracle, batch, "step 1")
+    if p_conf > 0:
+        f1 = oracle.decoder.conformer_layers[0].ffn1.sequential[3].factor
+        a1 = oracle.decoder.conformer_layers[0].attn_prob_factor
+        assert 0.2 < float(((f0 > 0) != (f1 > 0)).float().mean()) < 0.45   # 2 p (1-p) = 0.32 for independent masks
+        assert 0.2 < float(((a0 > 0) != (a1 > 0)).float().mean()) < 0.45
+    assert loss0 != loss1
+
+
+@pytest.mark.parametrize("act,C_,p", [("tanh", 512, 0.5), (None, 80, 0.5), ("silu", 256, 0.2)])
+def test_batchnorm_activation_dropout_fwd_bwd(act, C_, p):
+    """``bn_act_fwd`` / ``bn_act_bwd`` with dropout (PostNet: BatchNorm -> tanh -> F.dropout(0.5),
+    fs2/layers.py:204-212) against autograd with the kernel's own mask: out = act(bn(y)) * factor."""
+    from fastspeech2_lightning_amd import hip as H
+    M = 1500
+    g0 = torch.Generator().manual_seed(3)
+    y = (torch.randn(M, C_, generator=g0) * 2 + 0.5).requires_grad_(True)
+    g = (1 + 0.1 * torch.randn(C_, generator=g0)).requires_grad_(True)
+    b = torch.randn(C_, generator=g0).requires_grad_(True)
+    step = H.new_step_state("cuda")
+    step[0] = 5
+    drop = H.Drop(p, 0xABCDEF12345, step)
+    factor = H.axpby(torch.ones(M * C_, device="cuda"), None, 1.0, 0.0, drop).view(M, C_).cpu()
+    assert abs(float((factor > 0).float().mean()) - (1 - p)) < 0.02
+    assert torch.all((factor == 0) | ((factor - 1 / (1 - p)).abs() < 1e-6))
+    f = {"silu": F.silu, "tanh": torch.tanh, None: lambda t: t}[act]
+    ref = f(F.batch_norm(y, None, None, g, b, training=True, eps=1e-5)) * factor
+    stats = H.bn_finalize(H.colstats(y.detach().cuda()), g.detach().cuda(), b.detach().cuda(), None, None)
+    out = H.bn_act_fwd(y.detach().cuda(), stats, act, drop)
+    assert torch.equal(out.cpu() == 0, ref == 0) or float(((out.cpu() == 0) != (ref == 0)).float().mean()) < 1e-5
+    assert float((out.cpu() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+    dout = torch.randn(M, C_, generator=g0)
+    ref.backward(dout)
+    dg, db = torch.empty(C_, device="cuda"), torch.empty(C_, device="cuda")
+    dy = H.bn_act_bwd(dout.cuda(), y.detach().cuda(), stats, dg, db, act, drop)
+    for name, a, r in (("dy", dy, y.grad), ("dgamma", dg, g.grad), ("dbeta", db, b.grad)):
+        assert float((a.cpu() - r).abs().max()) < 1e-4 * max(1.0, float(r.abs().max())), name
+    # another step value gives another mask
+    step[0] = 6
+    factor2 = H.axpby(torch.ones(M * C_, device="cuda"), None, 1.0, 0.0, drop).view(M, C_).cpu()
+    assert 0.5 * 2 * p * (1 - p) < float(((factor > 0) != (factor2 > 0)).float().mean()) < 1.5 * 2 * p * (1 - p)
