@@ -3,6 +3,10 @@
 
     python bench.py --gpus N --steps K --warmup W
 
+With N > 1 and no launcher environment (WORLD_SIZE unset) this process starts the N ranks itself -- before it makes
+any GPU call -- and only relays their output; under ``python -m torch.distributed.run --nproc-per-node N`` each
+process is one rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).  One rank per GPU over RCCL.
+
 One "step" = forward + all losses + backward + gradient exchange (N > 1) + clip + fused AdamW on one
 synthetic LJSpeech-shaped batch of 32 utterances per GPU (BASELINE.json configs[1]: fp32, batch 32,
 ~100-128 phonemes, 80 x ~600 mel), dropout ON as in training, inputs resident in HBM before the
@@ -106,11 +110,48 @@ def cpu_baseline(config, batch, sample_B=32, iters=2):
                       f"1 warm-up + {iters} timed fwd+loss+bwd+clip+AdamW steps, fp32, {dt:.2f} s/step"}
 
 
+def kernel_source_hash() -> str:
+    """Hash of the kernel sources: profiles measured with rocprofv3 (HBM traffic) are stamped with it, and a stamp that
+    no longer matches the tree means the figure is stale (it is then reported as null, with the reason)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted((REPO / "fastspeech2_lightning_amd" / "csrc").glob("*")):
+        if f.suffix in (".hip", ".h"):
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def spawn_ranks(n: int) -> int:
+    """``python bench.py --gpus N`` without a launcher: start N copies of this script, one per GPU, with the rendezvous
+    environment torch.distributed.run would give them.  Runs BEFORE this process touches the GPU (it never does) and
+    never replaces a running process: children are ordinary subprocesses, rank 0's stdout (the JSON line) is relayed."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(c) for c in codes)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=200,
+                    help="timed steps (default 200 = ~4 s: long enough for clocks and the driver's activity sampler)")
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rendezvous + collectives only, no model (what the CPU-box test of the N > 1 launch path runs)")
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a hipGraph (single stream: the side stream for weight-gradient work is "
@@ -132,16 +173,29 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # FS2_BENCH_BACKEND=gloo rehearses the N > 1 control flow on a box with fewer GPUs than ranks (ranks then
     # share devices; RCCL itself refuses duplicate devices).  The driver's runs use RCCL ("nccl").
     backend = os.environ.get("FS2_BENCH_BACKEND", "nccl")
+    import torch.distributed as dist
+    if args.dry_run:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist.init_process_group("gloo" if backend != "nccl" or not torch.cuda.is_available() else backend)
+            t = torch.tensor([float(rank + 1)])
+            dist.all_reduce(t)
+            dist.barrier()
+            assert float(t) == world * (world + 1) / 2
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup}), flush=True)
+        return
     if backend != "nccl":
         local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
-    import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -177,7 +231,7 @@ def main():
     if world > 1 or force_sync:
         sync = GradSync(model.store, force=force_sync)
         sync.broadcast_parameters(0)
-        model.grad_sync = sync
+        model.data_parallel(sync, rank)
         opt.grad_scale = sync.grad_scale
     dev_batch = model.prepare_batch(batch)  # inputs resident in HBM before the timed region
     frames = int(batch["mel_lens"].sum())
@@ -281,11 +335,20 @@ def main():
         ms = raw_ms - ov * len(prof)
         flops = sum(q[2] for q in prof)
         achieved = flops / (ms * 1e-3) / 1e12
-        traffic, traffic_src = None, None
-        tfile = REPO / "profiles" / "r01_gemm_traffic.json"
-        if tfile.exists():  # HBM-side bytes per launch from the two rocprofv3 --pmc passes (tools/pmc_traffic.py)
-            traffic = round(json.loads(tfile.read_text())["hbm_bytes_per_launch"])
-            traffic_src = "profiles/r01_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled)"
+        # HBM-side bytes per launch come from two separate rocprofv3 --pmc passes over this same command
+        # (tools/pmc_traffic.py): they cannot be collected from inside the process, so the committed figure carries
+        # the hash of the kernel sources it was measured on and is only reported while that hash matches the tree
+        traffic, traffic_src = None, "no profiles/*gemm_traffic.json for this tree"
+        for tfile in sorted((REPO / "profiles").glob("r*_gemm_traffic.json"), reverse=True):
+            t = json.loads(tfile.read_text())
+            if t.get("kernel_source_hash") == kernel_source_hash():
+                traffic = round(t["hbm_bytes_per_launch"])
+                traffic_src = (f"profiles/{tfile.name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled; "
+                               f"kernel sources {t['kernel_source_hash']})")
+                break
+            traffic_src = (f"profiles/{tfile.name} is stale: measured on kernel sources "
+                           f"{t.get('kernel_source_hash', 'unstamped')}, tree is {kernel_source_hash()}")
+            break
         bf16 = args.precision == "bf16-mixed"
         if bf16:
             # operands and results stay fp32 in HBM, so at the bf16 MFMA rate these GEMMs sit below the ridge point

@@ -338,11 +338,16 @@ __global__ void sum_slots_kernel(const float* __restrict__ x, int n, float* __re
 }
 
 // fs2/variance_adaptor.py:360-366: clamp(round(exp(logd) - 1) * control, min=0).int(); torch.round is
-// round-half-to-even = rintf; .int() truncates
+// round-half-to-even = rintf; .int() truncates.  The integer result flips where exp(x) - 1 lands on k + 0.5, i.e.
+// where the fp32 exponential itself is exactly k + 1.5: a 1-ulp difference between two fp32 exp implementations
+// (this chip's expf and the host's vectorised one are both "<= 1 ulp", not the same function) would change a
+// duration there.  The exponential is therefore taken in double and rounded once -- the correctly rounded fp32
+// value, which is what the host's exp returns everywhere it is not off by its allowed ulp.
 __global__ void duration_round_kernel(const float* __restrict__ logd, float control, int* __restrict__ out, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float v = rintf(expf(logd[i]) - 1.f) * control;
+  const float e = (float)exp((double)logd[i]);
+  const float v = rintf(e - 1.f) * control;
   out[i] = (int)fmaxf(v, 0.f);
 }
 

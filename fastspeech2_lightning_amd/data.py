@@ -18,7 +18,6 @@ from typing import Iterable, Iterator, Optional
 
 import numpy as np
 import torch
-from torch.nn.utils.rnn import pad_sequence
 
 SEP = "--"
 
@@ -82,33 +81,47 @@ class FeatureDataset(torch.utils.data.Dataset):
         }
 
 
-def collate(items: list[dict], learn_alignment: bool = True) -> dict:
-    """reference ``FastSpeech2DataModule.collate_method``: list-of-dicts -> dict of padded tensors / lists."""
-    data = {k: [d[k] for d in items] for k in items[0]}
-    text_lens = torch.IntTensor([t.size(0) for t in data["text"]])
-    max_text = max(text_lens)
-    if data["mel"][0] is not None:
-        mel_lens = torch.IntTensor([m.size(0) for m in data["mel"]])
-        max_mel = max(mel_lens)
-    else:
-        mel_lens, max_mel = None, 1_000_000
-    for key in data:
-        if isinstance(data[key][0], np.ndarray):
-            data[key] = [torch.tensor(x) for x in data[key]]
-        if torch.is_tensor(data[key][0]):
+def _padded(seqs: list, shape_tail_max: tuple, pin: bool) -> torch.Tensor:
+    """One zero-initialised [B, *max extents] buffer (pinned when the prefetcher asked for it) with every sequence
+    written into its top-left corner -- the batch tensor is built in the memory the H2D copy will read."""
+    first = seqs[0]
+    out = torch.zeros((len(seqs),) + shape_tail_max, dtype=first.dtype, pin_memory=pin)
+    for row, seq in zip(out, seqs):
+        row[tuple(slice(0, n) for n in seq.shape)] = seq
+    return out
+
+
+def collate(items: list[dict], learn_alignment: bool = True, pin_memory: bool = False) -> dict:
+    """Batch contract of the reference's ``FastSpeech2DataModule.collate_method`` (fs2/dataset.py:257-293), produced
+    column by column: every key of the items becomes a list; tensor / ndarray columns become one zero-padded tensor
+    (ragged in time -- and, for the attention prior of a learned-alignment model, in tokens too: it is padded to
+    (max_mel_len, max_src_len) even when no utterance reaches both); int columns become int32 vectors; anything else
+    (names, raw text, None placeholders) stays a list.  ``src_lens`` / ``mel_lens`` are int32, the two maxima are
+    0-dim int32 tensors, and a batch without mels (inference) gets ``mel_lens = None, max_mel_len = 1_000_000``.
+    ``pin_memory``: allocate the padded tensors in pinned host memory (``DevicePrefetcher`` copies from them)."""
+    columns = {key: [item[key] for item in items] for key in items[0]}
+    src_lens = torch.tensor([len(t) for t in columns["text"]], dtype=torch.int32)
+    has_mel = columns["mel"][0] is not None
+    mel_lens = torch.tensor([len(m) for m in columns["mel"]], dtype=torch.int32) if has_mel else None
+    max_src = src_lens.max()
+    max_mel = mel_lens.max() if has_mel else 1_000_000
+    batch = {}
+    for key, col in columns.items():
+        head = col[0]
+        if isinstance(head, np.ndarray):
+            col, head = [torch.from_numpy(np.ascontiguousarray(x)) for x in col], torch.from_numpy(head)
+        if torch.is_tensor(head):
             if key == "duration" and learn_alignment:
-                # the attention prior is padded in both the frame and the token dimension
-                padded = torch.zeros(len(text_lens), max_mel, max_text)
-                for i, dur in enumerate(data[key]):
-                    padded[i, : dur.size(0), : dur.size(1)] = dur
-                data[key] = padded
+                extents = (int(max_mel), int(max_src))
             else:
-                data[key] = pad_sequence(data[key], batch_first=True, padding_value=0)
-        if isinstance(data[key][0], int):
-            data[key] = torch.IntTensor(data[key])
-    data["src_lens"], data["max_src_len"] = text_lens, max_text
-    data["mel_lens"], data["max_mel_len"] = mel_lens, max_mel
-    return data
+                extents = tuple(max(x.shape[d] for x in col) for d in range(head.dim()))
+            batch[key] = _padded(col, extents, pin_memory)
+        elif isinstance(head, int) and not isinstance(head, bool):
+            batch[key] = torch.tensor(col, dtype=torch.int32)
+        else:
+            batch[key] = col
+    batch.update(src_lens=src_lens, max_src_len=max_src, mel_lens=mel_lens, max_mel_len=max_mel)
+    return batch
 
 
 class DevicePrefetcher:

@@ -147,6 +147,11 @@ def _chk(t: torch.Tensor, dtype=torch.float32, name="tensor"):
         raise TypeError(f"fs2hip: {name} must be a tensor")
     if not t.is_cuda:
         raise RuntimeError(f"fs2hip: {name} must live in GPU memory (got {t.device}); there is no CPU path")
+    if t.device.index != _current_device():
+        # launches go to the CURRENT device's stream and scratch buffers: a tensor of another GPU would be a
+        # cross-device pointer inside a kernel, i.e. a memory fault
+        raise RuntimeError(f"fs2hip: {name} lives on cuda:{t.device.index} but the current device is "
+                           f"cuda:{_current_device()}; run under torch.cuda.device(...) of the tensors' GPU")
     if t.dtype != dtype:
         raise TypeError(f"fs2hip: {name} must be {dtype}, got {t.dtype}")
     if not t.is_contiguous():
@@ -562,6 +567,22 @@ def flush_grad_reductions():
         _ok(lib().fs2hip_reduce_rows_multi(jobs, len(batch), _stream()), "reduce_rows_multi")
         del _PENDING_REDUCTIONS[:len(batch)]
     return used
+
+
+def segment_colsum(x, out):
+    """out[b, :] = sum over t of x[b, t, :] -- the gradient of per-utterance vectors that were broadcast over time
+    (GST style vector, speaker / language embeddings).  One job per utterance, ``REDUCE_MAX_JOBS`` jobs per launch."""
+    _chk(x, name="x"); _chk(out, name="out")
+    B, T, D = x.shape
+    _req(out.shape == (B, D), "segment_colsum: bad output shape")
+    for b0 in range(0, B, REDUCE_MAX_JOBS):
+        nb = min(REDUCE_MAX_JOBS, B - b0)
+        jobs = (ReduceJob * nb)()
+        for i, j in enumerate(jobs):
+            j.src, j.out0, j.out1 = x.data_ptr() + 4 * (b0 + i) * T * D, out.data_ptr() + 4 * (b0 + i) * D, None
+            j.stride, j.rows, j.n, j.n0 = D, T, D, D
+        _ok(lib().fs2hip_reduce_rows_multi(jobs, nb, _stream()), "reduce_rows_multi")
+    return out
 
 
 def colsum_grad(x, out):

@@ -195,6 +195,10 @@ class FastSpeech2Loss:
         self.model = model
 
     def __call__(self, output, batch, current_epoch=0, frozen_components=None):
+        with torch.cuda.device(self.model.device_):
+            return self._loss(output, batch, current_epoch)
+
+    def _loss(self, output, batch, current_epoch=0):
         m = self.model
         m.env.join()  # variance predictors run on the side stream during a training forward
         cfg, t = m.config.model, m.config.training
@@ -282,6 +286,7 @@ class FastSpeech2(_Base):
         m = config.model
         d = m.encoder.input_dim
         self.step_state = H.new_step_state(self.device_)
+        self._seed = int(seed)
         self.env = M.Env(self.step_state, seed)
         S = self.store = P.ParamStore()
         self.padding_idx = self.text_processor.encode_text(self.text_processor._pad_symbol)[0]
@@ -334,6 +339,14 @@ class FastSpeech2(_Base):
         self.env.training = False
 
     # ---- helpers ------------------------------------------------------------------------------------
+    def data_parallel(self, sync, rank: int):
+        """Joins a data-parallel job: ``sync`` (``parallel.GradSync``) exchanges the gradient buckets during the
+        backward pass, and the rank enters the DROPOUT seed (not the initialisation seed: every rank builds the same
+        weights, rank 0's are broadcast anyway) so that ranks draw independent masks, as N processes each seeding
+        their own generator do under Lightning DDP."""
+        self.grad_sync = sync
+        self.env.seed = self._seed + 1_000_003 * int(rank)
+
     def _init_text_embedding(self, t):
         torch.nn.init.normal_(t)
         t[self.padding_idx].zero_()
@@ -412,6 +425,10 @@ class FastSpeech2(_Base):
 
     # ---- forward (fs2/model.py:153-268) -------------------------------------------------------------
     def forward(self, batch, control=None, inference=False):
+        with torch.cuda.device(self.device_):  # kernels launch on the current device: it must be the model's
+            return self._forward(batch, control, inference)
+
+    def _forward(self, batch, control=None, inference=False):
         H.set_precision(self.precision)
         control = control or InferenceControl()
         if "duration_control" in batch and batch["duration_control"] and batch["duration_control"][0]:
@@ -496,6 +513,10 @@ class FastSpeech2(_Base):
     # ---- backward -----------------------------------------------------------------------------------
     def backward(self):
         """Fills ``store.grad`` with d(total loss)/d(parameters) for the last training forward + loss."""
+        with torch.cuda.device(self.device_):
+            return self._backward()
+
+    def _backward(self):
         if self._ctx is None or self._loss_grads is None:
             raise RuntimeError("backward() needs a training-mode forward() and loss() first")
         H.set_precision(self.precision)
@@ -550,12 +571,9 @@ class FastSpeech2(_Base):
             sync.bucket_ready(bucket)
 
     def _rowsum(self, d):
-        """[B, T, D] -> [B, D]: gradient of a per-utterance vector that was broadcast over time."""
+        """[B, T, D] -> [B, D]: gradient of a per-utterance vector that was broadcast over time (one launch)."""
         B, T, D = d.shape
-        summed = torch.empty(B, D, device=d.device, dtype=torch.float32)
-        for b in range(B):  # config-5 path; one column-sum per utterance
-            H.colsum(d[b], summed[b])
-        return summed
+        return H.segment_colsum(d, torch.empty(B, D, device=d.device, dtype=torch.float32))
 
     def _rowvec_embedding_bwd(self, name, ids, d):
         H.embedding_bwd(ids, self._rowsum(d), self.store.g(name))

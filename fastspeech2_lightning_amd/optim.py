@@ -27,10 +27,11 @@ class FusedAdamWNoam:
     def step(self):
         """One optimizer step: schedule advance, clip coefficient, parameter update (3 launches + 1 finish)."""
         S = self.store
-        H.step_advance(self.state, self.lr, self.warmup_steps, self.betas[0], self.betas[1])
-        H.grad_clip_coef(S.grad, self.max_grad_norm, self.grad_scale, self.state)
-        H.adamw_step(S.flat, S.grad, S.adam_m, S.adam_v, self.state, self.betas[0], self.betas[1], self.eps,
-                     self.weight_decay)
+        with torch.cuda.device(S.flat.device):
+            H.step_advance(self.state, self.lr, self.warmup_steps, self.betas[0], self.betas[1])
+            H.grad_clip_coef(S.grad, self.max_grad_norm, self.grad_scale, self.state)
+            H.adamw_step(S.flat, S.grad, S.adam_m, S.adam_v, self.state, self.betas[0], self.betas[1], self.eps,
+                         self.weight_decay)
 
     def zero_grad(self, set_to_none=False):
         pass  # every gradient element is overwritten by the next backward pass

@@ -24,20 +24,31 @@ class GradSync:
         self.store, self.group, self.force = store, process_group, force
         self.world = world_size if world_size is not None else dist.get_world_size(process_group)
         self.ranges = store.bucket_ranges()
-        self._work = []
+        self.by_id = store.bucket_map()  # bucket id -> (start, end), None for an id without parameters
+        self._work, self._done = [], set()
 
     def bucket_ready(self, bucket: int):
         """Called by ``FastSpeech2.backward`` right after the last gradient kernel of ``bucket``."""
-        if (self.world == 1 and not self.force) or bucket >= len(self.ranges):
+        if bucket not in self.by_id:
+            raise KeyError(f"GradSync: unknown gradient bucket {bucket} (the store has {sorted(self.by_id)})")
+        if bucket in self._done:
+            raise RuntimeError(f"GradSync: bucket {bucket} handed over twice in one step")
+        self._done.add(bucket)
+        if (self.world == 1 and not self.force) or self.by_id[bucket] is None:
             return
-        s, e = self.ranges[bucket]
+        s, e = self.by_id[bucket]
         self._work.append(dist.all_reduce(self.store.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait(self):
-        """Makes the current stream wait for every outstanding bucket (call before the optimizer)."""
+        """Makes the current stream wait for every outstanding bucket (call before the optimizer).  Raises when a
+        bucket that holds parameters was never handed over this step: its gradient would silently stay local."""
+        missing = [b for b, r in self.by_id.items() if r is not None and b not in self._done]
+        if missing:
+            raise RuntimeError(f"GradSync: buckets {missing} were not exchanged in this step")
         for w in self._work:
             w.wait()
         self._work.clear()
+        self._done.clear()
 
     def broadcast_parameters(self, src: int = 0):
         """Rank ``src``'s weights and BatchNorm buffers to every rank (start of training)."""

@@ -193,6 +193,13 @@ class ParamStore:
             out[e.bucket] = (min(s, e.offset), max(t, end))
         return [out[k] for k in sorted(out)]
 
+    def bucket_map(self):
+        """{bucket id: (start, end) or None} for every id handed out by ``next_bucket`` (None: the bucket holds no
+        parameter, e.g. a model built without one of its optional blocks)."""
+        ids = sorted({e.bucket for e in self.entries.values()})
+        ranges = dict(zip(ids, self.bucket_ranges()))
+        return {b: ranges.get(b) for b in range(self._bucket + 1)}
+
     @property
     def num_trainable(self):
         return sum(e.numel for e in self.entries.values())

@@ -112,3 +112,37 @@ def test_rccl_call_path_with_one_rank():
     p.join(120)
     assert p.exitcode == 0
     assert err < 1e-6, err
+
+
+def test_bench_gpus_2_starts_its_own_ranks_and_reports_the_whole_job():
+    """The driver's command, ``python bench.py --gpus 2 ...``, with no launcher environment, on the one-GPU box:
+    the two ranks share the device (gloo -- RCCL refuses duplicate devices), every bucket is exchanged, and rank 0's
+    line carries the whole job's frames (2 x the per-rank batch)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    bench = Path(__file__).resolve().parent.parent / "bench.py"
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(FS2_BENCH_BACKEND="gloo", FS2_GEMM_TUNE="0")
+    r = subprocess.run([sys.executable, str(bench), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4",
+                        "--no-roofline", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["config"]["parallelism"] == "dp2"
+    assert line["config"]["global_batch"] == 8 and line["value"] > 0
+    assert line["config"]["real_frames_per_step"] % 2 == 0  # both ranks' frames (same structure on every rank)
+
+
+def test_tensor_on_another_device_is_refused_before_any_launch(monkeypatch):
+    """launches go to the current device's stream and scratch; a tensor of another GPU must raise on the
+    host.  One-GPU box: the 'other' device is simulated by moving the binding's notion of the current device."""
+    from fastspeech2_lightning_amd import hip as H
+    x = torch.ones(1024, device="cuda:0")
+    H.axpby(x, None, 2.0, 0.0)  # fine on its own device
+    monkeypatch.setattr(H, "_current_device", lambda: 1)
+    with pytest.raises(RuntimeError, match="current device"):
+        H.axpby(x, None, 2.0, 0.0)
+    with pytest.raises(RuntimeError, match="current device"):
+        H.layernorm_fwd(torch.ones(4, 256, device="cuda:0"), torch.ones(256, device="cuda:0"), torch.zeros(256, device="cuda:0"))

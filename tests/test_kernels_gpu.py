@@ -308,6 +308,37 @@ def test_duration_round_half_to_even(H, golden_dir):
     assert torch.equal(H.duration_round(logd.cuda(), 1.7).cpu(), ref)
 
 
+@pytest.mark.parametrize("control", [1.0, 1.7])
+def test_duration_round_dense_sweep_around_every_tie(H, control):
+    """Integer output, bit-exact where it can flip: for every k in 0..399 the 129 floats around log(k + 1.5) (where
+    exp(x) - 1 crosses k + 0.5; 51 600 inputs, ~90 of them exact ties) plus 200 000 random log-durations.  The
+    reference is the reference's own expression on the CPU, ``clamp(round(exp(x) - 1) * control, min=0).int()``
+    (fs2/variance_adaptor.py:360-366).  torch's CPU fp32 ``exp`` is a <= 1 ulp routine (it differs from the correctly
+    rounded value on ~1 % of these inputs): where it IS correctly rounded the kernel must agree bit for bit, and
+    where it is not, the kernel must give the answer of the correctly rounded exponential (float64 exp, rounded
+    once)."""
+    ks = np.arange(0, 400)
+    x0 = np.log(ks + 1.5).astype(np.float32)
+    xs = [x0.copy()]
+    up, dn = x0.copy(), x0.copy()
+    for _ in range(64):
+        up = np.nextafter(up, np.float32(np.inf)).astype(np.float32)
+        dn = np.nextafter(dn, np.float32(-np.inf)).astype(np.float32)
+        xs += [up.copy(), dn.copy()]
+    g = torch.Generator().manual_seed(0)
+    x = torch.cat([torch.from_numpy(np.concatenate(xs)), torch.rand(200000, generator=g) * 7 - 1])
+    e32, e64 = torch.exp(x), torch.exp(x.double()).float()
+    ref32 = torch.clamp(torch.round(e32 - 1) * control, min=0).int()
+    ref64 = torch.clamp(torch.round(e64 - 1) * control, min=0).int()
+    assert int(((e64 - 1) % 1 == 0.5).sum()) > 50  # the sweep does contain exact ties
+    got = H.duration_round(x.cuda(), control).cpu()
+    assert torch.equal(got, ref64)
+    same = e32 == e64
+    assert torch.equal(got[same], ref32[same])
+    # (on the hosts seen so far the two references agree everywhere: report it if that ever changes)
+    assert int((ref32 != ref64).sum()) <= 8, int((ref32 != ref64).sum())
+
+
 @pytest.mark.parametrize("B,Hh,Ww,Cin,Cout", [(2, 37, 80, 1, 32), (3, 19, 40, 32, 32), (2, 10, 5, 64, 128), (1, 3, 2, 128, 128),
                                                (2, 8, 6, 6, 10)])
 def test_conv2d_stride2_fwd_bwd(H, B, Hh, Ww, Cin, Cout):

@@ -102,3 +102,48 @@ def test_weak_scaling_batches_share_the_structure_and_differ_in_content():
     assert a["mel"].shape == b["mel"].shape and a["text"].shape == b["text"].shape
     assert not torch.equal(a["text"], b["text"]) and not torch.equal(a["mel"], b["mel"])
     assert torch.equal(a["text"] != 0, b["text"] != 0)  # padding positions are structure too
+
+
+def test_gradsync_bucket_ids_are_ids_not_positions():
+    """A bucket id that holds no parameter (an optional block that was not built) must not shift the slices of the
+    later ids; an unknown id raises; a step that forgets a bucket raises at ``wait()`` instead of silently keeping a
+    local gradient."""
+    S = P.ParamStore()
+    S.add("a.weight", (8, 4), "id", P.init_normal)
+    S.next_bucket()          # bucket 1: nothing declared (e.g. no GST / speaker block)
+    S.next_bucket()
+    S.add("c.weight", (16,), "id", P.init_normal)
+    S.finalize("cpu", seed=0)
+    m = S.bucket_map()
+    assert set(m) == {0, 1, 2} and m[1] is None and m[0][0] == 0 and m[2][1] == S.total and m[0][1] == m[2][0]
+    sync = GradSync(S, world_size=1)
+    sync.bucket_ready(2)
+    sync.bucket_ready(1)
+    with pytest.raises(KeyError):
+        sync.bucket_ready(7)
+    with pytest.raises(RuntimeError, match=r"\[0\]"):
+        sync.wait()          # bucket 0 was never handed over
+    sync._done.clear()
+    for b in (2, 1, 0):
+        sync.bucket_ready(b)
+    with pytest.raises(RuntimeError, match="twice"):
+        sync.bucket_ready(0)
+    sync.wait()
+
+
+def test_bench_launches_its_own_ranks_for_gpus_n():
+    """``python bench.py --gpus 2`` with no launcher environment: the parent must start the two ranks itself (before
+    any GPU call) and relay rank 0's JSON line.  ``--dry-run`` stops after rendezvous + a collective, so this runs on
+    the CPU box; ``tests/test_ddp_gpu.py`` runs the same entry with the model on the GPU box."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    bench = Path(__file__).resolve().parent.parent / "bench.py"
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["FS2_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, str(bench), "--gpus", "2", "--dry-run", "--steps", "5"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line == {"dry_run": True, "n_gpus": 2, "steps": 5, "warmup": 3}
