@@ -24,10 +24,12 @@ def deterministic_gemm_tiles(request):
     from fastspeech2_lightning_amd import hip
     saved = hip.GEMM_TUNE, dict(hip._TILE_CACHE)
     tuned = request.node.get_closest_marker("tuned_tiles") is not None
+    hip.set_precision("32-true")  # (a model built with precision="bf16-mixed" switches the binding's mode)
     hip.GEMM_TUNE = tuned
     if not tuned:
         hip._TILE_CACHE.clear()
     yield
+    hip.set_precision("32-true")
     hip.GEMM_TUNE = saved[0]
     hip._TILE_CACHE.clear()
     hip._TILE_CACHE.update(saved[1])
