@@ -1,0 +1,383 @@
+"""``fs2l train`` -- the training entry of the feature-prediction path (reference ``fs2/cli/train.py:9-41``,
+``fs2/cli/cli.py:46-54``; the Trainer the reference borrows from the parent toolkit's ``train_base_command`` is a
+Lightning ``Trainer(gradient_clip_val=1.0, monitor="validation/total_loss", max_epochs, max_steps, ...)``).
+
+    fs2l train CONFIG.yaml [-c training.batch_size=8 ...] [--devices N] [--resume last.ckpt]
+
+What it does, in the reference's order: load the YAML/JSON config (+ ``-c key=value`` overrides), read
+``<preprocessing.save_dir>/stats.json``, build the speaker / language look-up tables from the two filelists, build the
+model (``lang2id``, ``speaker2id``, ``stats``), then train: ``FeatureDataset -> DataLoader(collate, pinned) ->
+DevicePrefetcher -> training_step -> [bucketed gradient exchange] -> fused clip + AdamW + Noam``, validate on
+``validation/total_loss``, write ``last.ckpt`` / ``best.ckpt`` in Lightning's layout (weights under the reference's
+keys, optimizer state in ``torch.optim.AdamW``'s format) and resume from one.
+
+MI355X-first: one process per GPU (``--devices N`` starts the ranks itself before any GPU call, or run under
+``torch.distributed.run``), RCCL gradient buckets overlapped with the backward pass, no host synchronisation inside
+a step -- losses are copied out once every ``--log-every`` steps.
+"""
+from __future__ import annotations
+
+import argparse
+import csv
+import json
+import os
+import sys
+import time
+from pathlib import Path
+from typing import Optional
+
+import torch
+
+MONITOR = "validation/total_loss"  # fs2/cli/train.py:37
+GRADIENT_CLIP_VAL = 1.0            # fs2/cli/train.py:38
+
+
+# --------------------------------------------------------------------------------------------------------------
+# configuration and file plumbing (host only: exercised by the CPU tests)
+# --------------------------------------------------------------------------------------------------------------
+def apply_overrides(raw: dict, overrides: list) -> dict:
+    """``-c training.batch_size=8``: dotted path into the config dict, value parsed as JSON when it parses."""
+    for item in overrides or []:
+        if "=" not in item:
+            raise SystemExit(f"-c expects key=value, got {item!r}")
+        key, value = item.split("=", 1)
+        try:
+            value = json.loads(value)
+        except json.JSONDecodeError:
+            pass
+        node = raw
+        parts = key.split(".")
+        for p in parts[:-1]:
+            node = node.setdefault(p, {})
+            if not isinstance(node, dict):
+                raise SystemExit(f"-c {key}: {p!r} is not a section")
+        node[parts[-1]] = value
+    return raw
+
+
+def load_config(path, overrides=None):
+    from .config import FastSpeech2Config, _load_json_or_yaml
+    path = Path(path)
+    raw = apply_overrides(_load_json_or_yaml(path), overrides)
+    return FastSpeech2Config.model_validate(raw, context={"config_path": path})
+
+
+def read_filelist(path) -> list:
+    """The preprocessor's pipe-separated filelist with a header row (``basename|language|speaker|characters|
+    character_tokens|phones|phone_tokens|...``); rows become the entry dicts ``FeatureDataset`` takes."""
+    with open(path, encoding="utf8", newline="") as f:
+        rows = list(csv.DictReader(f, delimiter="|", quoting=csv.QUOTE_NONE))
+    if not rows or "basename" not in rows[0]:
+        raise ValueError(f"{path}: not a '|'-separated filelist with a 'basename' column")
+    return rows
+
+
+def lookup_tables(*filelists) -> tuple:
+    """(lang2id, speaker2id) over the given filelists: names sorted, ids dense (the parent toolkit's
+    ``lookuptables_from_config`` builds them from the training and validation filelists)."""
+    langs = sorted({r.get("language") or "default" for fl in filelists for r in fl})
+    speakers = sorted({r.get("speaker") or "default" for fl in filelists for r in fl})
+    return {n: i for i, n in enumerate(langs)}, {n: i for i, n in enumerate(speakers)}
+
+
+def filter_entries(entries: list, config) -> list:
+    """Rows that carry the text representation the model trains on (the reference's
+    ``filter_dataset_based_on_target_text_representation_level``)."""
+    from .config import TargetTrainingTextRepresentationLevel as L
+    key = "character_tokens" if config.model.target_text_representation_level == L.characters else "phone_tokens"
+    kept = [e for e in entries if e.get(key)]
+    if not kept:
+        raise ValueError(f"no filelist row has a {key!r} column value")
+    return kept
+
+
+def run_dir(config, args) -> Path:
+    lg = getattr(config.training, "logger", None)
+    get = (lambda k, d: (lg.get(k, d) if isinstance(lg, dict) else getattr(lg, k, d))) if lg is not None else (lambda k, d: d)
+    base = Path(args.output_dir) if args.output_dir else Path(get("save_dir", "logs_and_checkpoints")) / str(get("name", "FeaturePredictionExperiment")) / str(get("version", "base"))
+    return base
+
+
+def build_parser() -> argparse.ArgumentParser:
+    ap = argparse.ArgumentParser(prog="fs2l", description="MI355X-native FastSpeech2 feature-prediction path")
+    sub = ap.add_subparsers(dest="command", required=True)
+    tr = sub.add_parser("train", help="Train your Text-to-Spec model")
+    tr.add_argument("config_file", type=Path)
+    tr.add_argument("-c", "--config-args", action="append", default=[], metavar="KEY=VALUE")
+    tr.add_argument("-d", "--devices", default="auto", help="GPUs on this node: a count or 'auto' (all visible)")
+    tr.add_argument("--precision", default="32-true", choices=["32-true", "bf16-mixed"])
+    tr.add_argument("--resume", type=Path, default=None, help="checkpoint to resume from (default: <run dir>/checkpoints/last.ckpt when present)")
+    tr.add_argument("--output-dir", type=Path, default=None, help="run directory (default: training.logger.save_dir/name/version)")
+    tr.add_argument("--max-steps", type=int, default=None, help="overrides training.max_steps")
+    tr.add_argument("--max-epochs", type=int, default=None, help="overrides training.max_epochs")
+    tr.add_argument("--val-every", type=int, default=None, help="validate every N optimizer steps (default: once per epoch)")
+    tr.add_argument("--ckpt-every", type=int, default=None, help="write last.ckpt every N optimizer steps (default: once per epoch)")
+    tr.add_argument("--log-every", type=int, default=50)
+    tr.add_argument("--seed", type=int, default=1234)
+    tr.add_argument("--dry-run", action="store_true", help="resolve config, filelists, look-up tables and the run directory, print the plan, touch no GPU")
+    return ap
+
+
+def plan(args) -> dict:
+    """Everything ``train`` needs that does not involve the GPU."""
+    config = load_config(args.config_file, args.config_args)
+    t = config.training
+    if not t.training_filelist or not t.validation_filelist:
+        raise SystemExit("training.training_filelist and training.validation_filelist must be set")
+    base = args.config_file.parent
+
+    def resolve(p):
+        p = Path(p)
+        return p if p.is_absolute() else (base / p)
+
+    config.preprocessing.save_dir = str(resolve(config.preprocessing.save_dir))
+    train_rows = filter_entries(read_filelist(resolve(t.training_filelist)), config)
+    val_rows = filter_entries(read_filelist(resolve(t.validation_filelist)), config)
+    lang2id, speaker2id = lookup_tables(train_rows, val_rows)
+    stats_path = Path(config.preprocessing.save_dir) / "stats.json"
+    with open(stats_path, encoding="utf8") as f:
+        stats = json.load(f)
+    out = run_dir(config, args)
+    if not out.is_absolute():
+        out = base / out
+    ckpt_dir = out / "checkpoints"
+    resume = args.resume if args.resume else (ckpt_dir / "last.ckpt" if (ckpt_dir / "last.ckpt").exists() else None)
+    return dict(config=config, stats=stats, lang2id=lang2id, speaker2id=speaker2id, train_rows=train_rows,
+                val_rows=val_rows, run_dir=out, ckpt_dir=ckpt_dir, resume=resume,
+                max_steps=args.max_steps if args.max_steps is not None else t.max_steps,
+                max_epochs=args.max_epochs if args.max_epochs is not None else t.max_epochs)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# the loop (one rank)
+# --------------------------------------------------------------------------------------------------------------
+class Trainer:
+    def __init__(self, args, p: dict, rank: int, world: int, local_rank: int):
+        from . import hip as H
+        from .config import Stats
+        from .data import FeatureDataset
+        from .model import FastSpeech2
+        from .parallel import GradSync
+
+        self.args, self.p, self.rank, self.world = args, p, rank, world
+        self.device = torch.device("cuda", local_rank)
+        torch.cuda.set_device(self.device)
+        config = p["config"]
+        self.global_step, self.epoch = 0, 0
+        ckpt = None
+        if p["resume"] is not None:
+            self.model, ckpt = FastSpeech2.load_from_checkpoint(p["resume"], device=str(self.device),
+                                                                precision=args.precision, return_checkpoint=True)
+            self.model.config.training = config.training  # schedule / filelists / batch size are this run's
+            self.model.config.preprocessing.save_dir = config.preprocessing.save_dir
+        else:
+            self.model = FastSpeech2(config, Stats(**p["stats"]), p["lang2id"], p["speaker2id"], device=str(self.device),
+                                     seed=args.seed, precision=args.precision)
+            finetune = getattr(config.training, "finetune_checkpoint", None)
+            if finetune:  # weights only, fresh optimizer (Lightning: load_from_checkpoint + fit without ckpt_path)
+                sd = torch.load(finetune, map_location="cpu", weights_only=False)["state_dict"]
+                self.model.load_state_dict(sd)
+        self.model.train()
+        self.opt = self.model.configure_optimizers()[0][0]
+        self.opt.max_grad_norm = GRADIENT_CLIP_VAL
+        if ckpt is not None:
+            self.global_step, self.epoch = self.model.restore_training_state(ckpt, self.opt)
+            self.best = ckpt.get("fs2l_best_monitor", float("inf"))
+            self.batches_in_epoch = int(ckpt.get("fs2l_batches_in_epoch", 0))
+        else:
+            self.best, self.batches_in_epoch = float("inf"), 0
+        self.sync = None
+        if world > 1:
+            self.sync = GradSync(self.model.store)
+            self.sync.broadcast_parameters(0)
+            self.model.data_parallel(self.sync, rank)
+            self.opt.grad_scale = self.sync.grad_scale
+            # every rank must sum in the same order: rank 0's tuned GEMM tiles are adopted by all once it has them
+        cfg = self.model.config
+        self.train_set = FeatureDataset(p["train_rows"], cfg, self.model.lang2id, self.model.speaker2id)
+        self.val_set = FeatureDataset(p["val_rows"], cfg, self.model.lang2id, self.model.speaker2id)
+        self.H = H
+        self.metrics = None
+        if rank == 0:
+            p["ckpt_dir"].mkdir(parents=True, exist_ok=True)
+            self.metrics = open(p["run_dir"] / "metrics.jsonl", "a", encoding="utf8")
+
+    # ---- data ---------------------------------------------------------------------------------------------
+    def loader(self, dataset, shuffle: bool, epoch: int, workers: int, skip_batches: int = 0):
+        """Batches of one epoch in an order that depends only on (seed, epoch, world): a resumed run re-derives the
+        interrupted epoch's order and drops the ``skip_batches`` it had already trained on."""
+        from functools import partial
+
+        from .data import collate
+        cfg = self.model.config
+        if self.world > 1:
+            sampler = torch.utils.data.distributed.DistributedSampler(dataset, self.world, self.rank, shuffle=shuffle,
+                                                                      seed=self.args.seed, drop_last=False)
+            sampler.set_epoch(epoch)
+        elif shuffle:
+            sampler = torch.utils.data.RandomSampler(dataset, generator=torch.Generator().manual_seed(self.args.seed + epoch))
+        else:
+            sampler = torch.utils.data.SequentialSampler(dataset)
+        batches = list(torch.utils.data.BatchSampler(sampler, cfg.training.batch_size, drop_last=False))[skip_batches:]
+        return torch.utils.data.DataLoader(
+            dataset, batch_sampler=batches, num_workers=workers,
+            collate_fn=partial(collate, learn_alignment=cfg.model.learn_alignment, pin_memory=workers == 0))
+
+    def batches(self, dataset, shuffle, epoch, workers, skip_batches: int = 0):
+        from .data import DevicePrefetcher
+        return DevicePrefetcher(self.loader(dataset, shuffle, epoch, workers, skip_batches), self.model.prepare_batch,
+                                self.device)
+
+    # ---- one step -------------------------------------------------------------------------------------------
+    def step(self, batch):
+        self.model.current_epoch_ = self.epoch
+        self.model.training_step(batch)
+        if self.sync:
+            self.sync.wait()
+        self.opt.step()
+        self.global_step += 1
+        self.batches_in_epoch += 1
+
+    def log(self, record: dict):
+        record = dict(record, step=self.global_step, epoch=self.epoch, time=round(time.time(), 3))
+        if self.metrics:
+            self.metrics.write(json.dumps(record) + "\n")
+            self.metrics.flush()
+            print(json.dumps(record), flush=True)
+
+    def log_train(self):
+        slots = self.model._loss_slots.cpu()  # the one D2H copy per log interval
+        from .model import LOSS_KEYS
+        rec = {f"training/{k}_loss": float(slots[i]) for i, k in enumerate(LOSS_KEYS) if k in self.model.last_losses}
+        rec["training/total_loss"] = float(slots[len(LOSS_KEYS)])
+        r = self.opt.record()
+        rec.update(lr=r["lr"], grad_norm=r["grad_norm"])
+        self.log(rec)
+
+    def validate(self) -> float:
+        from .data import validate
+        cfg = self.model.config
+        means = validate(self.model, self.batches(self.val_set, False, 0, cfg.training.val_data_workers))
+        self.model.train()
+        self.log(means)
+        return means.get(MONITOR, float("inf"))
+
+    def save(self, name: str):
+        if self.rank != 0:
+            return
+        ckpt = self.model.checkpoint_dict(self.global_step, self.epoch, self.opt)
+        ckpt["fs2l_best_monitor"] = self.best
+        ckpt["fs2l_batches_in_epoch"] = self.batches_in_epoch
+        path = self.p["ckpt_dir"] / name
+        tmp = path.with_suffix(".tmp")
+        torch.save(ckpt, tmp)
+        os.replace(tmp, path)
+
+    def after_step(self):
+        a = self.args
+        if a.log_every and self.global_step % a.log_every == 0:
+            self.log_train()
+        if a.val_every and self.global_step % a.val_every == 0:
+            self.check_validation()
+        if a.ckpt_every and self.global_step % a.ckpt_every == 0:
+            self.save("last.ckpt")
+
+    def check_validation(self):
+        m = self.validate()
+        if m < self.best:
+            self.best = m
+            self.save("best.ckpt")
+
+    def fit(self):
+        p, cfg = self.p, self.model.config
+        max_steps, max_epochs = p["max_steps"], p["max_epochs"]
+        done = lambda: 0 <= max_steps <= self.global_step  # noqa: E731  (Lightning: max_steps = -1 means no limit)
+        from .data import DevicePrefetcher
+        while self.epoch < max_epochs and not done():
+            loader = self.loader(self.train_set, True, self.epoch, cfg.training.train_data_workers, self.batches_in_epoch)
+            epoch_batches = self.batches_in_epoch + len(loader)
+            for batch in DevicePrefetcher(loader, self.model.prepare_batch, self.device):
+                self.step(batch)
+                self.after_step()
+                if done():
+                    break
+            if self.batches_in_epoch >= epoch_batches:  # the epoch is complete (also when max_steps fell on its last batch)
+                self.epoch += 1
+                self.batches_in_epoch = 0
+                if not self.args.val_every:
+                    self.check_validation()
+                if not self.args.ckpt_every:
+                    self.save("last.ckpt")
+        torch.cuda.synchronize()
+        self.save("last.ckpt")
+        if self.metrics:
+            self.metrics.close()
+        return self.global_step
+
+
+def spawn_ranks(n: int, argv: list) -> int:
+    """``--devices N`` without a launcher: N child processes, one per GPU, started before this process makes any GPU
+    call (it never does); never an exec of a process that has touched the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-m", "fastspeech2_lightning_amd"] + argv, env=env))
+    return max(abs(p.wait()) for p in procs)
+
+
+def train(args, argv) -> int:
+    p = plan(args)
+    if args.dry_run:
+        print(json.dumps({
+            "config": str(args.config_file), "run_dir": str(p["run_dir"]), "resume": str(p["resume"]) if p["resume"] else None,
+            "train_utterances": len(p["train_rows"]), "validation_utterances": len(p["val_rows"]),
+            "lang2id": p["lang2id"], "speaker2id": p["speaker2id"], "batch_size": p["config"].training.batch_size,
+            "max_steps": p["max_steps"], "max_epochs": p["max_epochs"], "monitor": MONITOR,
+            "gradient_clip_val": GRADIENT_CLIP_VAL, "learn_alignment": p["config"].model.learn_alignment,
+            "stats": sorted(p["stats"])}))
+        return 0
+    world = int(os.environ.get("WORLD_SIZE", 0))
+    if not world:
+        n = torch.cuda.device_count() if args.devices == "auto" else int(args.devices)  # (device_count does not initialise the GPU)
+        if n > 1:
+            return spawn_ranks(n, argv)
+        world = 1
+    rank, local = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
+    backend = os.environ.get("FS2L_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(backend)
+    trainer = Trainer(args, p, rank, world, local)
+    steps = trainer.fit()
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"finished": True, "global_step": steps, "epoch": trainer.epoch, "best_" + MONITOR: trainer.best,
+                          "checkpoint": str(p["ckpt_dir"] / "last.ckpt")}), flush=True)
+    return 0
+
+
+def main(argv: Optional[list] = None) -> int:
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = build_parser().parse_args(argv)
+    if args.command == "train":
+        return train(args, argv)
+    return 2
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -639,12 +639,10 @@ class FastSpeech2(_Base):
             raise ValueError("There were breaking changes to the handling of phonological features in version 1.2; "
                              f"your model is version {version}.")
         if version < Version("1.2"):
-            # fs2/model.py:313-352 re-orders the embedding table of pre-1.2 checkpoints with the parent toolkit's
-            # symbol_sorter / get_symbols_from_checkpoint_symbol_dict, which are not part of the reference repository:
-            # refuse rather than load an embedding table whose row order may not match the symbol table.
-            raise NotImplementedError(
-                f"checkpoint version {version} < 1.2: its text embedding rows follow the old symbol order; upgrade it "
-                "with the reference toolkit (it rewrites text_input_layer.weight) and load the upgraded file")
+            # fs2/model.py:313-349: before 1.2 the embedding rows followed the old symbol order -- eight hard-coded
+            # initial symbols, then the checkpoint's own symbols sorted -- and are moved to this model's symbol table
+            remap_pre_1_2_text_embedding(checkpoint, self.text_processor.symbols,
+                                         tuple(self.store.entries["text_input_layer.weight"].ref_shape))
         return checkpoint
 
     def on_load_checkpoint(self, checkpoint):
@@ -653,19 +651,98 @@ class FastSpeech2(_Base):
         if checkpoint["hyper_parameters"].get("stats") is not None:
             self.stats = Stats(**checkpoint["hyper_parameters"]["stats"])
 
-    def save_checkpoint(self, path, global_step=0, epoch=0, optimizer=None):
-        ckpt = {"state_dict": {k: v.cpu() for k, v in self.state_dict().items()}, "global_step": global_step,
-                "epoch": epoch, "hyper_parameters": {}}
-        self.on_save_checkpoint(ckpt)
+    # ---- checkpoint files in the layout Lightning writes for the reference --------------------------------------
+    def reference_parameter_names(self) -> list:
+        """The reference's ``named_parameters()`` order: the state-dict order without buffers, with the frozen
+        ``pitch_bins`` / ``energy_bins`` (``nn.Parameter(requires_grad=False)``, fs2/variance_adaptor.py:117-148)
+        in their places.  ``torch.optim.AdamW(self.parameters())`` indexes its state by position in this list."""
+        frozen = ("variance_adaptor.pitch_bins", "variance_adaptor.energy_bins")
+        return [n for n in self.store.order_hint if n in self.store.entries or n in frozen]
+
+    def checkpoint_dict(self, global_step=0, epoch=0, optimizer=None) -> dict:
+        """What ``Trainer.save_checkpoint`` hands to ``on_save_checkpoint`` for the reference model, filled from this
+        model: weights under the reference's keys, ``hyper_parameters`` = the constructor arguments
+        (``save_hyperparameters``, fs2/model.py:69), optimizer / scheduler state in torch's own format."""
+        ckpt = {"epoch": int(epoch), "global_step": int(global_step), "pytorch-lightning_version": "2.6.1",
+                "state_dict": OrderedDict((k, v.cpu()) for k, v in self.state_dict().items()),
+                "hyper_parameters": {"lang2id": dict(self.lang2id), "speaker2id": dict(self.speaker2id)},
+                "loops": {}, "callbacks": {}}
         if optimizer is not None:
-            ckpt["fs2hip_optimizer"] = optimizer.state_dict()
-        torch.save(ckpt, path)
+            ckpt["optimizer_states"] = [optimizer.torch_state_dict(self.reference_parameter_names())]
+            ckpt["lr_schedulers"] = [optimizer.torch_scheduler_state_dict()]
+        self.on_save_checkpoint(ckpt)
+        return ckpt
+
+    def save_checkpoint(self, path, global_step=0, epoch=0, optimizer=None):
+        torch.save(self.checkpoint_dict(global_step, epoch, optimizer), path)
+
+    def restore_training_state(self, checkpoint: dict, optimizer) -> tuple:
+        """Resume: optimizer moments + step (from torch-format ``optimizer_states`` -- written by the reference through
+        Lightning or by ``save_checkpoint`` here), returns ``(global_step, epoch)``.  A checkpoint without optimizer
+        state (weights only) is refused: resuming from it would silently restart Adam and the warm-up."""
+        if not checkpoint.get("optimizer_states"):
+            raise RuntimeError("checkpoint holds no optimizer state: it can initialise weights (finetune) but not resume")
+        sched = (checkpoint.get("lr_schedulers") or [None])[0]
+        optimizer.load_torch_state_dict(checkpoint["optimizer_states"][0], self.reference_parameter_names(), sched)
+        self.current_epoch_ = int(checkpoint.get("epoch", 0))
+        return int(checkpoint.get("global_step", 0)), int(checkpoint.get("epoch", 0))
 
     @classmethod
-    def load_from_checkpoint(cls, path, device=None):
-        ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    def load_from_checkpoint(cls, path, device=None, precision="32-true", return_checkpoint=False):
+        ckpt = torch.load(path, map_location="cpu", weights_only=False) if not isinstance(path, dict) else path
         hp = ckpt["hyper_parameters"]
-        model = cls(hp["config"], hp.get("stats"), hp.get("lang2id"), hp.get("speaker2id"), device=device)
+        model = cls(hp["config"], hp.get("stats"), hp.get("lang2id"), hp.get("speaker2id"), device=device,
+                    precision=precision)
         model.on_load_checkpoint(ckpt)
         model.load_state_dict(ckpt["state_dict"])
-        return model
+        return (model, ckpt) if return_checkpoint else model
+
+
+OLD_HARDCODED_SYMBOLS = ("\x80", " ", "<EXCL>", "<QINT>", "<QUOTE>", "<BB>", "<SB>", "<EPS>")  # fs2/model.py:314-323
+
+
+def symbols_of_checkpoint(symbol_dict: dict) -> list:
+    """Every symbol of a checkpoint's ``config.text.symbols`` (restates the parent toolkit's
+    ``get_symbols_from_checkpoint_symbol_dict``, which is not part of the reference repository: string values are
+    one symbol, lists are taken element by element, nested dicts -- e.g. the punctuation categories -- recursively;
+    order of first appearance, duplicates dropped)."""
+    out = []
+
+    def walk(v):
+        if isinstance(v, str):
+            if v not in out:
+                out.append(v)
+        elif isinstance(v, dict):
+            for x in v.values():
+                walk(x)
+        elif isinstance(v, (list, tuple)):
+            for x in v:
+                walk(x)
+
+    walk(symbol_dict)
+    return out
+
+
+def old_symbol_order(symbols: list, hardcoded_initial_symbols=OLD_HARDCODED_SYMBOLS) -> list:
+    """The pre-1.2 embedding row order (restates ``symbol_sorter``): the hard-coded initial symbols, then the
+    remaining symbols sorted."""
+    head = list(hardcoded_initial_symbols)
+    return head + sorted(set(symbols) - set(head))
+
+
+def remap_pre_1_2_text_embedding(checkpoint: dict, model_symbols: list, weight_shape: tuple) -> None:
+    """fs2/model.py:324-349: row i of the old table belongs to ``old_order[i]``; it moves to that symbol's index in the
+    model's table (row 0 -- padding -- when the model does not know the symbol)."""
+    old = old_symbol_order(symbols_of_checkpoint(checkpoint["hyper_parameters"]["config"]["text"]["symbols"]))
+    if len(old) > len(model_symbols):
+        raise AssertionError("unable to update the embedding table automatically: the checkpoint has more symbols "
+                             "than the model (fs2/model.py:330-332)")
+    w_old = checkpoint["state_dict"]["text_input_layer.weight"]
+    if w_old.shape[0] != len(old):
+        raise ValueError(f"pre-1.2 checkpoint: embedding has {w_old.shape[0]} rows but its symbol table has {len(old)}")
+    idx = torch.tensor([model_symbols.index(c) if c in model_symbols else 0 for c in old], dtype=torch.long)
+    new = torch.zeros(weight_shape, dtype=w_old.dtype)
+    new[idx] = w_old
+    checkpoint["state_dict"]["text_input_layer.weight"] = new
+    print(f"checkpoint version < 1.2: text embedding rows moved to the current symbol order "
+          f"({len(old)} -> {len(model_symbols)} symbols)", file=sys.stderr)

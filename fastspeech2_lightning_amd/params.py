@@ -204,6 +204,18 @@ class ParamStore:
     def num_trainable(self):
         return sum(e.numel for e in self.entries.values())
 
+    # ---- any flat buffer of this layout <-> reference-shaped tensors (gradient, Adam moments) ----------------
+    def export_flat(self, base: torch.Tensor, name: str) -> torch.Tensor:
+        e = self.entries[name]
+        return _TO_REF[e.kind](self._view(base, name), e.ref_shape).contiguous().clone()
+
+    def import_flat(self, base: torch.Tensor, name: str, value: torch.Tensor) -> None:
+        e = self.entries[name]
+        if tuple(value.shape) != e.ref_shape:
+            raise RuntimeError(f"{name}: shape {tuple(value.shape)} != {e.ref_shape}")
+        with torch.no_grad():
+            self._view(base, name).copy_(_TO_NATIVE[e.kind](value.to(torch.float32)).to(base.device))
+
     # ---- reference-layout state dict ---------------------------------------------------------
     def state_dict(self) -> "OrderedDict[str, torch.Tensor]":
         sd = OrderedDict()
