@@ -353,9 +353,12 @@ class FastSpeech2(_Base):
 
     def _reorder_state_dict_keys(self):
         """state_dict() lists keys in the reference's module registration order."""
-        groups = ["text_input_layer.", "position_embedding.", "gst.", "encoder.", "variance_adaptor.duration_predictor.",
-                  "variance_adaptor.pitch_predictor.", "variance_adaptor.pitch_embedding.", "variance_adaptor.pitch_bins",
-                  "variance_adaptor.energy_predictor.", "variance_adaptor.energy_embedding.", "variance_adaptor.energy_bins",
+        # (a module's own parameters come before its children's: the frozen pitch_bins / energy_bins are
+        # nn.Parameters OF the VarianceAdaptor, fs2/variance_adaptor.py:117-148, so they lead its section)
+        groups = ["text_input_layer.", "position_embedding.", "gst.", "encoder.",
+                  "variance_adaptor.pitch_bins", "variance_adaptor.energy_bins", "variance_adaptor.duration_predictor.",
+                  "variance_adaptor.pitch_predictor.", "variance_adaptor.pitch_embedding.",
+                  "variance_adaptor.energy_predictor.", "variance_adaptor.energy_embedding.",
                   "variance_adaptor.attention.", "decoder.", "mel_linear.", "postnet.", "speaker_embedding.",
                   "language_embedding."]
         names = self.store.order_hint

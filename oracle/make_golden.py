@@ -291,6 +291,76 @@ def dump_data(out_dir: Path):
     print(f"data: {len(save)} arrays")
 
 
+CKPT_SEED = 31
+
+
+def ckpt_case():
+    """Config + batch of the checkpoint-interchange fixtures: the small model WITHOUT PostNet (the reference
+    hard-codes a 512-channel PostNet = 15 MB of weights; without it a full checkpoint with Adam moments is < 1 MB)."""
+    config = C.small_config(learn_alignment=False)
+    config.model.use_postnet = False
+    config.training.optimizer.learning_rate = 1e-2
+    config.training.optimizer.warmup_steps = 2
+    batch = O.synthetic_batch(B=3, ts_lo=6, ts_hi=12, n_symbols=C.N_SYMBOLS, n_mels=16, dur_hi=4, seed=CKPT_SEED)
+    return config, batch
+
+
+def reference_train_steps(ref, batch, n, opt=None, sched=None):
+    """n optimizer steps the way Lightning drives the reference: loss -> backward -> clip_grad_norm_(1.0)
+    (fs2/cli/train.py:38) -> AdamW.step -> NoamLR.step (interval "step", fs2/model.py:530-549)."""
+    if opt is None:
+        opt, scheds = ref.configure_optimizers()
+        opt, sched = opt[0], scheds[0]["scheduler"]
+    losses = []
+    for _ in range(n):
+        opt.zero_grad()
+        b = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        out = ref(b)
+        loss = ref.loss(out, b, 0)["total"]
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 1.0)
+        opt.step()
+        sched.step()
+        losses.append(float(loss))
+    return opt, sched, losses
+
+
+def dump_ckpt(out_dir: Path):
+    """A checkpoint WRITTEN BY THE REFERENCE: its own ``on_save_checkpoint`` over the dict Lightning's
+    ``Trainer.save_checkpoint`` assembles (weights, ``hyper_parameters`` = the constructor arguments, torch's own
+    optimizer / scheduler state dicts), after three training steps; plus what the checkpoint must reproduce."""
+    from fs2.model import FastSpeech2 as RefFastSpeech2
+
+    config, batch = ckpt_case()
+    torch.manual_seed(0)
+    ref = RefFastSpeech2(config, stats=STATS)
+    ref.load_state_dict(O.seeded_state_dict(ref.state_dict()))
+    ref.train()
+    opt, sched, losses = reference_train_steps(ref, batch, 3)
+    ckpt = {"epoch": 0, "global_step": 3, "pytorch-lightning_version": "2.6.1",
+            "state_dict": ref.state_dict(), "loops": {}, "callbacks": {},
+            "optimizer_states": [opt.state_dict()], "lr_schedulers": [sched.state_dict()],
+            "hyper_parameters": {"config": ref.config, "stats": ref.stats, "lang2id": ref.lang2id,
+                                 "speaker2id": ref.speaker2id}}
+    ref.on_save_checkpoint(ckpt)   # fs2/model.py:369-378
+    torch.save(ckpt, out_dir / "ref_written.ckpt")
+    save = {f"batch/{k}": _np(v) for k, v in batch.items()}
+    save["losses_1_3"] = np.asarray(losses)
+    ref.eval()
+    with torch.no_grad():
+        out = ref({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
+    for k in ("output", "duration_prediction", "pitch_prediction", "energy_prediction"):
+        save[f"eval/{k}"] = _np(out[k])
+    ref.train()
+    _, _, l4 = reference_train_steps(ref, batch, 1, opt, sched)
+    save["loss_4"] = np.asarray(l4[0])
+    for k, v in ref.state_dict().items():
+        if v.dtype.is_floating_point:
+            save[f"sd_after_4/{k}"] = _np(v)
+    np.savez_compressed(out_dir / "ckpt_interchange.npz", **save)
+    print(f"ckpt: losses {losses} then {l4[0]:.6f}; {len(ckpt['optimizer_states'][0]['state'])} parameters with state")
+
+
 def main():
     out_dir = REPO / "tests" / "golden"
     out_dir.mkdir(parents=True, exist_ok=True)
@@ -299,6 +369,8 @@ def main():
         dump_units(out_dir)
     if len(sys.argv) <= 1 or "data" in sys.argv[1:]:
         dump_data(out_dir)
+    if len(sys.argv) <= 1 or "ckpt" in sys.argv[1:]:
+        dump_ckpt(out_dir)
     only = set(sys.argv[1:])
     for name in C.CASES:
         if only and name not in only:
