@@ -8,6 +8,7 @@
 // (S^T = K Q^T, O^T = V^T P^T, ...) so that the owned row index sits on the MFMA column
 // (lane & 15): softmax statistics and rescales are then lane-local, and an accumulator tile is
 // directly the B operand of the next MFMA (any k-order is a valid reduction order for fp32).
+#include "attention2.h"
 #include "common.h"
 
 namespace {
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p, float* __rest
   for (int j = 0; j < NJ; ++j) oacc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float m = -INFINITY, l = 0.f;
   const int kend = min(T, len);
-  const unsigned long long rowidx = ((unsigned long long)(b * p.H + h) * T + q) * T;
+  const unsigned long long rowidx = ((unsigned long long)(b * p.H + h) * T + q) * (unsigned long long)(T + (T & 1));
   RowRegs<HD> kreg, vreg;
   fetch_rows<HD>(kreg, base, ld, D + h * HD, 0, T, tid);
   fetch_rows<HD>(vreg, base, ld, 2 * D + h * HD, 0, T, tid);
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(256, BF ? 2 : 1) void attn_bwd_dq_kernel(AttnP p, c
 #pragma unroll
   for (int j = 0; j < NJ; ++j) dq[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int kend = min(T, len);
-  const unsigned long long rowidx = ((unsigned long long)(b * p.H + h) * T + q) * T;
+  const unsigned long long rowidx = ((unsigned long long)(b * p.H + h) * T + q) * (unsigned long long)(T + (T & 1));
   RowRegs<HD> kreg, vreg;
   fetch_rows<HD>(kreg, base, ld, D + h * HD, 0, T, tid);
   fetch_rows<HD>(vreg, base, ld, 2 * D + h * HD, 0, T, tid);
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p, const float*
         for (int r = 0; r < 4; ++r) {
           int ql = 16 * qt + 4 * g + r;
           float pv = key_ok ? __expf(s2[u][r] - lse_s[ql]) : 0.f;
-          float f = fs2_drop_factor(drop, (headidx + (unsigned long long)(q0 + ql)) * T + (unsigned long long)key);
+          float f = fs2_drop_factor(drop, (headidx + (unsigned long long)(q0 + ql)) * (unsigned long long)(T + (T & 1)) + (unsigned long long)key);
           pd[u][r] = pv * f;
           ds[u][r] = pv * (dp2[u][r] * f - delta_s[ql]);
         }
@@ -509,6 +510,11 @@ extern "C" int fs2hip_attention_fwd(const float* qkv, const int* lens, float* o,
                                     int HD, float drop_p, unsigned long long drop_seed,
                                     const unsigned long long* drop_step, int operand_bf16, void* stream) {
   if (!attn_args_ok(qkv, B, T, H, HD) || ((uintptr_t)o % 16)) return FS2HIP_EINVAL;
+  static const bool old_only = getenv("FS2_ATTN_GEN1") != nullptr;  // measurement aid: first-generation kernels everywhere
+  if (!old_only && fs2_attn2_supported(HD, operand_bf16)) {
+    Attn2Args a2{qkv, lens, B, T, H, HD, 1.f / sqrtf((float)HD), fs2_make_drop(drop_p, drop_seed, drop_step), nullptr};
+    return fs2_attn2_fwd(a2, o, lse, (hipStream_t)stream);
+  }
   AttnP p{qkv, lens, B, T, H, 1.f / sqrtf((float)HD), fs2_make_drop(drop_p, drop_seed, drop_step)};
   dim3 grid((T + 63) / 64, H, B);
   ATTN_DISPATCH(HD, operand_bf16, (attn_fwd_kernel<HDc, BFc><<<grid, dim3(256), 0, (hipStream_t)stream>>>(p, o, lse)));

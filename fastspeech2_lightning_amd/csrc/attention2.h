@@ -1,0 +1,18 @@
+// Second-generation fp32 attention kernels for head dims 64 / 128 (the Conformer's 2 x 128): see attention2.hip.
+#pragma once
+#include "common.h"
+
+struct Attn2Args {
+  const float* qkv;   // [B*T][3*D]: q | k | v
+  const int* lens;    // [B] valid keys per utterance
+  int B, T, H, HD;
+  float scale;        // 1/sqrt(HD)
+  Fs2Drop drop;       // dropout on the attention probabilities, element index ((b*H + h)*T + q)*Tp + key, Tp = T rounded up to even
+  long long* stamps;  // diagnostic builds only (-DFS2_ATTN_STAMPS, tools/probes/attn2_probe.hip): per-phase cycle sums
+};
+
+// true when the second-generation kernels take the shape (fp32 operands, HD in {64, 128})
+bool fs2_attn2_supported(int HD, int operand_bf16);
+int fs2_attn2_fwd(const Attn2Args& a, float* o, float* lse, hipStream_t s);
+int fs2_attn2_bwd(const Attn2Args& a, const float* o, const float* dout, const float* lse, float* delta, float* dqkv,
+                  hipStream_t s);

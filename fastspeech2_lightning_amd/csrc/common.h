@@ -16,7 +16,11 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// ---- stateless dropout: keep iff hash(seed, idx) >= p * 2^32 ------------------------------
+// ---- stateless dropout: element idx keeps iff its 16-bit field of hash(seed, idx >> 1) >= p * 2^16 ----------
+// One 32-bit hash serves TWO neighbouring elements (even idx: low half, odd idx: high half): fp32 vector
+// instructions and fp32 MFMAs share the arithmetic on this chip (a vector instruction between two MFMAs is not
+// hidden, it is added), and the hash is most of the vector work of the attention kernels and GEMM epilogues.
+// The drop probability is p rounded to 1/65536.
 // 32-bit two-round multiply-xorshift mixer (the per-kernel 64-bit seed enters before the first and between the
 // two rounds, so that two dropout sites / steps are not index-permuted copies of one mask).  Integer
 // multiplies are quarter rate on CDNA: a 64-bit splitmix (12 of them per element) made the GEMM epilogues and
@@ -33,7 +37,7 @@ __device__ __forceinline__ uint32_t fs2_hash32(unsigned long long seed, unsigned
   return x;
 }
 struct Fs2Drop {
-  uint32_t thresh;  // drop iff hash < thresh
+  uint32_t thresh;  // drop iff the element's 16-bit hash field < thresh (0 .. 65536)
   float scale;      // 1/(1-p)
   unsigned long long seed;
   const unsigned long long* step;  // device-resident step counter mixed into the seed (may be null):
@@ -45,8 +49,8 @@ inline Fs2Drop fs2_make_drop(float p, unsigned long long seed, const unsigned lo
   d.on = p > 0.f;
   d.seed = seed;
   d.step = step;
-  double t = (double)p * 4294967296.0;
-  d.thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+  double t = (double)p * 65536.0 + 0.5;
+  d.thresh = t >= 65536.0 ? 65536u : (uint32_t)t;
   d.scale = p < 1.f ? 1.f / (1.f - p) : 0.f;
   return d;
 }
@@ -62,7 +66,8 @@ __device__ __forceinline__ Fs2Drop fs2_resolve_drop(Fs2Drop d) {
 }
 __device__ __forceinline__ float fs2_drop_factor(const Fs2Drop& d, unsigned long long idx) {
   if (!d.on) return 1.f;
-  return fs2_hash32(d.seed, idx) < d.thresh ? 0.f : d.scale;
+  const uint32_t h = fs2_hash32(d.seed, idx >> 1);
+  return ((idx & 1) ? (h >> 16) : (h & 0xffffu)) < d.thresh ? 0.f : d.scale;
 }
 
 // ---- activations ------------------------------------------------------------------------

@@ -6,7 +6,7 @@
  * reference call site(s) (file:line, relative to the reference checkout) whose
  * ATen ops it replaces.  INTEGRATION.md shows the ctypes binding.
  *
- * Dropout: keep-mask = hash(seed + *drop_step * c, element index) >= p * 2^32, regenerated
+ * Dropout: element i keeps iff its 16-bit field of hash(seed + *drop_step * c, i >> 1) >= p * 2^16, regenerated
  * (never stored) by the backward kernels; `drop_step` is a device-resident counter so that a
  * captured hipGraph draws a fresh mask on every replay.
  *

@@ -3,7 +3,7 @@
 The kernels never store a mask: every dropout site draws ``keep = hash(seed(site, step), element index) >= p * 2^32``
 (``csrc/common.h``) on the fly, in the forward kernel and again in the backward kernel, the element index being the
 linear index of the site's tensor in its natural layout ([B*T, C] rows for GEMM epilogues / BatchNorm+activation /
-elementwise kernels, [B, H, T, T] for the attention probabilities).  ``fs2hip_axpby`` applied to a vector of ones with a
+elementwise kernels, [B, H, T, Tp] for the attention probabilities, Tp = T rounded up to even).  ``fs2hip_axpby`` applied to a vector of ones with a
 site's ``Drop`` record writes exactly those factors (0 or 1/(1-p)) -- the same device function, the same seed and the
 same device-resident step counter -- so ``site_factors`` is the debug export of a site's mask, and
 ``inject`` puts each one into the oracle's matching ``MaskedDropout`` / attention / PostNet site in that site's layout.
@@ -35,7 +35,9 @@ def _conformer(model, stack, ostack, cfg, B, T):
         for ffn, offn in ((layer.ffn1, olayer.ffn1), (layer.ffn2, olayer.ffn2)):
             offn.sequential[3].factor = tb(site_factors(model, p, ffn.s1, B, T, Fd))
             offn.sequential[5].factor = tb(site_factors(model, p, ffn.s2, B, T, D))
-        olayer.attn_prob_factor = site_factors(model, p, layer.attn.sa, B, heads, T, T) if p > 0 else None
+        # (rows of the attention mask index are padded to an even length: one hash serves two neighbouring keys)
+        olayer.attn_prob_factor = (site_factors(model, p, layer.attn.sa, B, heads, T, T + (T & 1))[..., :T].contiguous()
+                                   if p > 0 else None)
         olayer.self_attn_dropout.factor = tb(site_factors(model, p, layer.attn.so, B, T, D))
         # conv module: the oracle's Sequential runs on (B, D, T)
         olayer.conv_module.sequential[6].factor = site_factors(model, p, layer.conv.site, B, T, D).permute(0, 2, 1).contiguous()

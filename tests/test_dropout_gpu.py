@@ -40,17 +40,28 @@ def compare_step(model, oracle, batch, tag):
         assert float((a - b).abs().max()) < 1e-4 * max(1.0, float(b.abs().max())), (tag, k)
     for k, v in model.last_losses.items():
         assert abs(float(v) - float(ref_losses[k])) < 1e-4 * max(1.0, abs(float(ref_losses[k]))), (tag, k)
+    # gradients: tensors downstream of the predictors' ReLUs (encoder, variance adaptor, text embedding) can differ by
+    # a flipped ReLU between any two fp32 summation orders (tests/test_fullsize_gpu.py measures it on the oracle alone):
+    # there the group is held in relative L2 and single tensors loosely; everything else element-wise at 2e-3
     got = model.store.grad_state_dict()
     gmax = max(float(p.grad.abs().max()) for p in oracle.parameters() if p.grad is not None)
-    worst = ("", 0.0)
+    worst, relu_worst, num, den = ("", 0.0), ("", 0.0), 0.0, 0.0
     for k, p in oracle.named_parameters():
         if p.grad is None:
             continue
-        scale = max(float(p.grad.abs().max()), 1e-4 * gmax)
-        r = float((got[k].cpu() - p.grad).abs().max()) / scale
-        if r > worst[1]:
-            worst = (k, r)
+        d = got[k].cpu() - p.grad
+        if float(p.grad.abs().max()) < 1e-4 * gmax:
+            # true gradient exactly zero (a bias in front of a BatchNorm): rounding residue on both sides
+            assert float(d.abs().max()) < 2e-2 * 1e-4 * gmax, (tag, k)
+            continue
+        r = float(d.abs().max()) / float(p.grad.abs().max())
+        if k.startswith(("encoder.", "variance_adaptor.", "text_input_layer.")):
+            num, den = num + float(d.pow(2).sum()), den + float(p.grad.pow(2).sum())
+            relu_worst = max(relu_worst, (k, r), key=lambda kr: kr[1])
+        else:
+            worst = max(worst, (k, r), key=lambda kr: kr[1])
     assert worst[1] < 2e-3, (tag, worst)
+    assert relu_worst[1] < 5e-2 and (num / max(den, 1e-30)) ** 0.5 < 5e-3, (tag, relu_worst, (num / max(den, 1e-30)) ** 0.5)
     return seen, float(total)
 
 

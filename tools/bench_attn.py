@@ -1,22 +1,42 @@
-"""Attention forward / backward at the decoder's shape (B=32, T=648, H=2, HD=128), dropout on (GPU only)."""
+"""Attention forward / backward at the decoder's shape (B=32, T=648, H=2, HD=128) (GPU only).
+usage: python tools/bench_attn.py [ragged|full] [drop_p]   -- `full`: every utterance 648 keys (no tail effects)"""
 import sys
 from pathlib import Path
+
 import torch
+
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from fastspeech2_lightning_amd import hip as H  # noqa: E402
-from tools.bench_gemm import timeit  # noqa: E402
 
+
+def timeit(fn, n=20):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / n * 1e-3
+
+
+mode = sys.argv[1] if len(sys.argv) > 1 else "ragged"
+p = float(sys.argv[2]) if len(sys.argv) > 2 else 0.2
 dev = "cuda"
-B, T, Hh, HD = 32, 648, 2, 128
+B, T, Hh, HD = 32, int(sys.argv[3]) if len(sys.argv) > 3 else 648, 2, 128
 D = Hh * HD
 g = torch.Generator().manual_seed(0)
-lens = torch.randint(430, 649, (B,), generator=g).int().to(dev)
+lens = torch.randint(int(T * 0.66), T + 1, (B,), generator=g).int() if mode == "ragged" else torch.full((B,), T, dtype=torch.int32)
+lens = lens.to(dev)
 qkv = torch.randn(B * T, 3 * D, device=dev)
 dout = torch.randn(B * T, D, device=dev)
 step = torch.zeros(4, dtype=torch.int64, device=dev)
-drop = H.Drop(0.2, 777, step)
+drop = H.Drop(p, 777, step) if p > 0 else H.NO_DROP
 o, lse = H.attention_fwd(qkv, lens, B, T, Hh, drop)
 tf = timeit(lambda: H.attention_fwd(qkv, lens, B, T, Hh, drop), 20)
 tb = timeit(lambda: H.attention_bwd(qkv, lens, o, dout, lse, B, T, Hh, drop), 20)
 frac = float(lens.float().mean()) / T
-print(f"fwd {tf * 1e6:7.1f} us  bwd (delta+dQ+dK/dV) {tb * 1e6:7.1f} us  (mean len/T = {frac:.2f})")
+flop_fwd = 4.0 * B * Hh * T * float(lens.float().mean()) * HD  # two products over the valid keys
+print(f"{mode:6s} T={T} drop={p:.1f}: fwd {tf * 1e6:7.1f} us ({flop_fwd / tf / 1e12:5.1f} TF)  bwd (delta+dQ+dK/dV) {tb * 1e6:7.1f} us "
+      f"({3.5 * flop_fwd / tb / 1e12:5.1f} TF on 7 products)  (mean len/T = {frac:.2f})")
