@@ -529,6 +529,11 @@ extern "C" int fs2hip_attention_bwd(const float* qkv, const int* lens, const flo
   if (!attn_args_ok(qkv, B, T, H, HD) || ((uintptr_t)o % 16) || ((uintptr_t)dout % 16) || ((uintptr_t)dqkv % 16))
     return FS2HIP_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+  static const bool old_only = getenv("FS2_ATTN_GEN1") != nullptr;
+  if (!old_only && fs2_attn2_supported(HD, operand_bf16)) {
+    Attn2Args a2{qkv, lens, B, T, H, HD, 1.f / sqrtf((float)HD), fs2_make_drop(drop_p, drop_seed, drop_step), nullptr};
+    return fs2_attn2_bwd(a2, o, dout, lse, delta, dqkv, s);
+  }
   attn_delta_kernel<<<dim3((B * T + 3) / 4), dim3(256), 0, s>>>(dout, o, delta, B, T, H, HD);
   FS2_LAUNCH_CHECK();
   AttnP p{qkv, lens, B, T, H, 1.f / sqrtf((float)HD), fs2_make_drop(drop_p, drop_seed, drop_step)};

@@ -36,9 +36,54 @@ __device__ __forceinline__ void sfor(F&& f) {
   sfor_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
 }
 
+template <int OFF>
+__device__ __forceinline__ void lds_rd64(float2& v, unsigned addr) {
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void pin(float2& v) { asm volatile("" : "+v"(v)); }
+
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
+
+// The same MFMA with its accumulator pinned to AGPRs.  The backward kernels hold 64-128 accumulator registers that
+// no vector instruction ever touches next to ~200 registers of operands: left to itself the allocator parks and
+// unparks accumulators around every phase (v_accvgpr_read/write are vector instructions -- 200-350 of them per
+// tile, each one ADDED to the MFMA time).  The "a" constraint keeps them where they belong.  The two wait states
+// in front cover a vector write of an operand register in the instruction before (the hazard recogniser does not
+// see through inline asm).
+__device__ __forceinline__ void mfma32_agpr(f32x16& acc, float a, float b) {
+  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+// ... and with the accumulator pinned to VGPRs (results that vector instructions consume: S, dP); `first` starts
+// the chain from zero (inline constant: no 16-register clear)
+__device__ __forceinline__ void mfma32_vgpr_first(f32x16& acc, float a, float b) {
+  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma32_vgpr(f32x16& acc, float a, float b) {
+  asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+// ... and with the B operand (the wavefront's own row, which nothing but MFMAs ever reads) in an AGPR: the backward
+// kernels keep 128 such values; in VGPRs they pushed the allocator past 256 and into parking them around every use
+__device__ __forceinline__ void mfma32_vgpr_first_ob(f32x16& acc, float a, float b) {
+  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "a"(b));
+}
+__device__ __forceinline__ void mfma32_vgpr_ob(f32x16& acc, float a, float b) {
+  asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
+}
+// gives a value its home in an AGPR (defined by asm into the "a" class: later "a" uses need no copy)
+__device__ __forceinline__ float to_agpr(float v) {
+  float r;
+  asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(r) : "v"(v));
+  return r;
+}
+__device__ __forceinline__ f32x4 to_agpr(f32x4 v) {
+  f32x4 r;
+  r[0] = to_agpr(v[0]); r[1] = to_agpr(v[1]); r[2] = to_agpr(v[2]); r[3] = to_agpr(v[3]);
+  return r;
+}
+// before the first compiler-visible read of such an accumulator: the last MFMA's 16 passes have to retire
+__device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); }
 
 constexpr int KT = 32;  // keys (or queries) per LDS tile
 
@@ -123,12 +168,10 @@ struct NoHook {
 };
 
 // `hook(j)` runs after the four MFMAs of reduction group j (work that should hide under them: DMA issue)
-template <int HD, class Hook = NoHook>
+template <int HD, bool OWN_AGPR = false, class Hook = NoHook>
 __device__ __forceinline__ f32x16 dot_rows(const RowRd& rd, unsigned tile_base, const f32x4 (&own)[HD / 8], Hook&& hook = Hook()) {
   constexpr int NJ = HD / 8;
   f32x16 acc;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   f32x4 a[3];
   lds_rd128<0>(a[0], tile_base + rd.addr(0));
   lds_rd128<0>(a[1], tile_base + rd.addr(1));
@@ -143,12 +186,22 @@ __device__ __forceinline__ f32x16 dot_rows(const RowRd& rd, unsigned tile_base, 
       lds_wait<0>();
     }
     pin(a[j % 3]);
-    acc = mfma32(a[j % 3][0], own[j][0], acc);
-    acc = mfma32(a[j % 3][1], own[j][1], acc);
-    acc = mfma32(a[j % 3][2], own[j][2], acc);
-    acc = mfma32(a[j % 3][3], own[j][3], acc);
+    if constexpr (OWN_AGPR) {
+      if constexpr (j == 0) mfma32_vgpr_first_ob(acc, a[0][0], own[0][0]);
+      else mfma32_vgpr_ob(acc, a[j % 3][0], own[j][0]);
+      mfma32_vgpr_ob(acc, a[j % 3][1], own[j][1]);
+      mfma32_vgpr_ob(acc, a[j % 3][2], own[j][2]);
+      mfma32_vgpr_ob(acc, a[j % 3][3], own[j][3]);
+    } else {
+      if constexpr (j == 0) mfma32_vgpr_first(acc, a[0][0], own[0][0]);
+      else mfma32_vgpr(acc, a[j % 3][0], own[j][0]);
+      mfma32_vgpr(acc, a[j % 3][1], own[j][1]);
+      mfma32_vgpr(acc, a[j % 3][2], own[j][2]);
+      mfma32_vgpr(acc, a[j % 3][3], own[j][3]);
+    }
     hook(jc);
   });
+  mfma_drain();  // (the result is consumed by vector instructions right away)
   return acc;
 }
 
@@ -286,6 +339,38 @@ struct SoftmaxWeights {
   }
 };
 
+// Work order.  A (batch, head) unit is `nblk` workgroups (its row blocks) whose cost grows with the utterance's
+// length, and the lengths of a batch are ragged (0.66 .. 1 of the padded length): dealt in batch order, the long
+// utterances that happen to come last set the kernel's time (measured: +27 % against the same work at uniform
+// length).  Longest first instead: dispatch deals workgroup ids round-robin over the 8 XCDs, so workgroup id w is the
+// (w >> 3)-th workgroup of XCD (w & 7); unit number (w >> 3) / nblk * 8 + (w & 7) in order of DEcreasing length goes
+// there -- every XCD gets a long-to-short sequence of units, and the row blocks of a unit still share one XCD's L2.
+// Needs B <= 64 (one lane per utterance ranks them) and B * H a multiple of 8; otherwise plain XCD-contiguous order.
+__device__ __forceinline__ void work_unit(const Attn2Args& p, int nblk, int& blk, int& b, int& h) {
+  const int units = p.B * p.H;
+  if (p.B <= 64 && (units & 7) == 0) {
+    const int w = blockIdx.x, k = w >> 3;
+    blk = k % nblk;
+    const int u = (k / nblk) * 8 + (w & 7);  // rank of the unit; u / H = rank of the utterance
+    const int lane = threadIdx.x & 63;
+    const int mylen = lane < p.B ? p.lens[lane] : -1;
+    int rank = 0;
+    for (int j = 0; j < p.B; ++j) {
+      const int lj = __builtin_amdgcn_readlane(mylen, j);
+      rank += (lj > mylen || (lj == mylen && j < lane)) ? 1 : 0;
+    }
+    const unsigned long long hit = __builtin_amdgcn_ballot_w64(lane < p.B && rank == u / p.H);
+    b = __builtin_ctzll(hit);
+    h = u % p.H;
+  } else {
+    const int wid = fs2_xcd_remap(blockIdx.x, gridDim.x);
+    blk = wid % nblk;
+    const int bh = wid / nblk;
+    h = bh % p.H;
+    b = bh / p.H;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // forward.  Workgroup = 4 wavefronts = 2 row blocks (32 queries each) x 2 key groups: the key tiles of the sequence
 // are cut in two halves, each half has its own K / V tiles in LDS (staged by its two wavefronts) and its own online
@@ -309,12 +394,9 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(Attn2Args p, float* _
   // offsets -- is then provably wave-uniform; as a plain tid >> 6 the DMA's scalar offset compiled to a waterfall loop)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5, l32 = lane & 31;
   const int rb = wave & 1, kg = wave >> 1, gtid = tid & 127;
-  // XCD-aware order: the row blocks of one (batch, head) are consecutive work ids on ONE XCD, so that the K / V rows
-  // they all stream stay in that XCD's L2 (dealt round-robin they would be fetched by all eight)
-  const int nqb = (p.T + 63) / 64;
-  const int wid = fs2_xcd_remap(blockIdx.x, gridDim.x);
-  const int qb = wid % nqb, bh = wid / nqb;
-  const int h = bh % p.H, b = bh / p.H, T = p.T, D = p.H * HD, ld = 3 * D;
+  int qb, b, h;
+  work_unit(p, (p.T + 63) / 64, qb, b, h);
+  const int T = p.T, D = p.H * HD, ld = 3 * D;
   const int q = qb * 64 + rb * 32 + l32;
   const int len = p.lens[b];
   const int kend = min(T, len);
@@ -336,7 +418,11 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(Attn2Args p, float* _
   for (int j = 0; j < NJ; ++j) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (q < T) v = *reinterpret_cast<const f32x4*>(base + (long long)q * ld + h * HD + 8 * j + 4 * hi);
+#ifdef FS2_FWD_OWN_AGPR
+    qv[j] = to_agpr(v * (p.scale * 1.44269504088896f));
+#else
     qv[j] = v * (p.scale * 1.44269504088896f);  // scores in log2 units: the exponentials are bare v_exp_f32
+#endif
   }
   f32x16 oacc[NDB];
 #pragma unroll
@@ -360,7 +446,11 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(Attn2Args p, float* _
     STAMP(1)  // wait at X
     f32x16 s;
     if (act) {
+#ifdef FS2_FWD_OWN_AGPR
+      s = dot_rows<HD, true>(rd, ks, qv, [&](auto jc) {
+#else
       s = dot_rows<HD>(rd, ks, qv, [&](auto jc) {  // the V tile's DMA, piece by piece under the MFMAs
+#endif
         constexpr int it = decltype(jc)::value;
         if constexpr (it < TileDma<HD, 128>::NP) dma.template piece<it>(rv, Vt, key0, T, ld, rb);
       });
@@ -436,6 +526,387 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(Attn2Args p, float* _
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// backward.  Three launches: prep (per row and head: lse and delta = sum_d dO*O, pre-digested), dQ (own = queries,
+// tiles = keys), dK/dV (own = keys, tiles = queries).  Both gradient kernels use the forward's decomposition --
+// 4 wavefronts = 2 row blocks x 2 groups over the other sequence, partial results merged through LDS -- but with
+// double-buffered tiles and ONE barrier per tile: a tile is read from the start (S, dP) to the end (the step-major
+// gradient products) of its iteration, so the next tile's DMA goes into the other buffer, piece by piece under the
+// MFMAs of S and dP.  128 KB of LDS: one workgroup per CU; the accumulators live in AGPRs (512 registers per lane).
+// Vector work per element (it is ADDED to the MFMA time on this chip): subtract, v_exp, [hash], compare, select,
+// multiply, fma -- lse arrives as lse*log2(e) - log2(dropout scale) and delta as delta / (dropout scale), so that
+// p' = 2^(s - lse') is already the kept-element weight and dS = keep(p')*dP - p'*delta'.
+// ------------------------------------------------------------------------------------------------------------
+
+// aux[b][h][t] = {lse * log2e - log2(dscale), delta / dscale}, delta = sum over the head's columns of dO * O
+__global__ __launch_bounds__(256) void attn2_prep_kernel(const float* __restrict__ dout, const float* __restrict__ o,
+                                                         const float* __restrict__ lse, float2* __restrict__ aux, int B,
+                                                         int T, int H, int HD, float lg_dscale, float inv_dscale) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B * T) return;
+  const int D = H * HD, f4 = D / 4, per_head = HD / 4;
+  const int b = row / T, t = row % T;
+  for (int i0 = 0; i0 < f4; i0 += 64) {
+    const int i = i0 + lane;
+    float sm = 0.f;
+    if (i < f4) {
+      const float4 a = reinterpret_cast<const float4*>(dout + (long long)row * D)[i];
+      const float4 c = reinterpret_cast<const float4*>(o + (long long)row * D)[i];
+      sm = a.x * c.x + a.y * c.y + a.z * c.z + a.w * c.w;
+    }
+    for (int w = 1; w < per_head && w < 64; w <<= 1) sm += __shfl_xor(sm, w, 64);
+    if (i < f4 && (i % per_head) == 0) {
+      const long long k = ((long long)b * H + i / per_head) * T + t;
+      aux[k] = make_float2(lse[k] * 1.44269504088896f - lg_dscale, sm * inv_dscale);
+    }
+  }
+}
+
+// Stream of (one LDS operand read, one MFMA) pairs with the reads running LOOK pairs ahead: before MFMA i the
+// wavefront waits until at most LOOK - 1 reads are outstanding (read i has landed), after it issues read i + LOOK.
+// rd(ic, dst) issues read number i into dst; mf(ic, v) performs MFMA i with operand v.
+template <int N, int LOOK, class Rd, class Mf>
+__device__ __forceinline__ void read_mfma_stream(Rd&& rd, Mf&& mf) {
+  float v[2 * LOOK];
+  sfor<LOOK>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    if constexpr (i < N) rd(ic, v[i % (2 * LOOK)]);
+  });
+  sfor<N>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    constexpr int left = N - 1 - i;  // reads issued after read i so far
+    lds_wait<(left < LOOK - 1 ? left : LOOK - 1)>();
+    pin(v[i % (2 * LOOK)]);
+    mf(ic, v[i % (2 * LOOK)]);
+    if constexpr (i + LOOK < N) rd(std::integral_constant<int, i + LOOK>{}, v[(i + LOOK) % (2 * LOOK)]);
+  });
+}
+
+// dQ: own = 32 queries per wavefront (Q' = Q * scale * log2e and dO in registers), tiles = keys (K and V)
+template <int HD, bool DROP>
+__global__ __launch_bounds__(256, 1) void attn2_bwd_dq_kernel(Attn2Args p, const float* __restrict__ dout,
+                                                              const float2* __restrict__ aux, float* __restrict__ dqkv) {
+  constexpr int NJ = HD / 8, NDB = HD / 32, TILE = KT * HD, NP = TileDma<HD, 128>::NP;
+  __shared__ __attribute__((aligned(1024))) float smem[8 * TILE];  // [key group][stage][K | V]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5, l32 = lane & 31;
+  const int rb = wave & 1, kg = wave >> 1, gtid = tid & 127;
+  int qb, b, h;
+  work_unit(p, (p.T + 63) / 64, qb, b, h);
+  const int T = p.T, D = p.H * HD, ld = 3 * D;
+  const int q = qb * 64 + rb * 32 + l32;
+  const int len = p.lens[b];
+  const int kend = min(T, len);
+  const int nt = (kend + KT - 1) / KT, n0 = (nt + 1) / 2;
+  const int tile0 = kg ? n0 : 0, mine = kg ? nt - n0 : n0;
+  PairHash ph;
+  ph.setup(fs2_resolve_drop(p.drop));
+  const float* base = p.qkv + (long long)b * T * ld;
+  const __amdgpu_buffer_rsrc_t rk = make_rsrc(base + D + h * HD), rv = make_rsrc(base + 2 * D + h * HD);
+  TileDma<HD, 128> dma;
+  dma.setup(ld, gtid);
+  float* gbuf = smem + kg * 4 * TILE;
+  if (mine > 0) {
+    dma.issue(rk, gbuf, tile0 * KT, T, ld, rb);
+    dma.issue(rv, gbuf + TILE, tile0 * KT, T, ld, rb);
+  }
+  f32x4 qv[NJ], dov[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f}, w = {0.f, 0.f, 0.f, 0.f};
+    if (q < T) {
+      v = *reinterpret_cast<const f32x4*>(base + (long long)q * ld + h * HD + 8 * j + 4 * hi);
+      w = *reinterpret_cast<const f32x4*>(dout + ((long long)b * T + q) * D + h * HD + 8 * j + 4 * hi);
+    }
+    qv[j] = to_agpr(v * (p.scale * 1.44269504088896f));
+    dov[j] = to_agpr(w);
+  }
+  float2 ax = make_float2(INFINITY, 0.f);  // (rows past T: p = 2^(s - inf) = 0)
+  if (q < T) ax = aux[((long long)b * p.H + h) * T + q];
+  const float lse2 = ax.x, deltap = ax.y;
+  f32x16 dq[NDB];
+#pragma unroll
+  for (int d = 0; d < NDB; ++d)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dq[d][i] = 0.f;
+  const uint32_t rowidx = (uint32_t)(((unsigned long long)(b * p.H + h) * T + q) * (unsigned long long)(T + (T & 1)));
+  RowRd rd;
+  rd.setup<HD>(l32, hi);
+  ColRd cr;
+  cr.setup<HD>(l32, hi);
+  const unsigned g0 = lds_addr(gbuf);
+  STAMP_DECL;
+  for (int j = 0; j < n0; ++j) {
+    const int key0 = (tile0 + j) * KT;
+    const bool act = j < mine, actn = j + 1 < mine;
+    const int st = j & 1;
+    STAMP(0)
+    wait_vmcnt_barrier<0>();  // tile j landed for everybody, and everybody is done with tile j - 1 (the other stage)
+    STAMP(1)
+    if (!act) continue;
+    const unsigned kb = g0 + st * 2 * TILE * 4, vb = kb + TILE * 4;
+    float* nxt = gbuf + (st ^ 1) * 2 * TILE;
+    f32x16 s = dot_rows<HD, true>(rd, kb, qv, [&](auto jc) {
+      constexpr int it = decltype(jc)::value;
+      if constexpr (it < NP) {
+        if (actn) dma.template piece<it>(rk, nxt, key0 + KT, T, ld, rb);
+      }
+    });
+    STAMP(2)
+    f32x16 dp = dot_rows<HD, true>(rd, vb, dov, [&](auto jc) {
+      constexpr int it = decltype(jc)::value;
+      if constexpr (it < NP) {
+        if (actn) dma.template piece<it>(rv, nxt + TILE, key0 + KT, T, ld, rb);
+      }
+    });
+    STAMP(3)
+    if (key0 + KT > len) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (key0 + 8 * (i >> 2) + 4 * hi + (i & 3) >= len) s[i] = -INFINITY;
+    }
+    // dq^T[d][q] += sum_key K[key][d] * dS[key][q], step-major; dS of step t is made right before its MFMAs
+    const uint32_t pair0 = (rowidx + (uint32_t)(key0 + 4 * hi)) >> 1;
+    uint32_t hsh = 0;
+    float w = 0.f;
+    auto weight = [&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      const float pp = __builtin_amdgcn_exp2f(s[t] - lse2);
+      float pd = pp;
+      if constexpr (DROP) {
+        if constexpr ((t & 1) == 0) hsh = ph.hash(pair0 + (uint32_t)(4 * (t >> 2) + ((t & 3) >> 1)));
+        pd = ph.template keep<t & 1>(hsh) ? pp : 0.f;
+      }
+      return fmaf(-pp, deltap, pd * dp[t]);
+    };
+    w = weight(std::integral_constant<int, 0>{});
+    STAMP(4)
+    read_mfma_stream<16 * NDB, 8>(
+        [&](auto ic, float& dst) {
+          constexpr int i = decltype(ic)::value, t = i / NDB, db = i % NDB;
+          lds_rd32<col_off<HD, t, db>()>(dst, kb + cr.base[t & 3]);
+        },
+        [&](auto ic, float v) {
+          constexpr int i = decltype(ic)::value, t = i / NDB, db = i % NDB;
+          mfma32_agpr(dq[db], v, w);
+          if constexpr (db == NDB - 1 && t + 1 < 16) w = weight(std::integral_constant<int, t + 1>{});
+        });
+    STAMP(5)
+  }
+  STAMP_FLUSH(p.stamps, blockIdx.x)
+  mfma_drain();
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  // merge the two key groups: group 1 parks its partial dq, group 0 adds, scales and stores
+  float* park = smem + rb * NDB * 16 * 64;
+  if (kg == 1) {
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) park[(d * 16 + i) * 64 + lane] = dq[d][i];
+  }
+  __syncthreads();
+  if (kg == 0 && q < T) {
+    float* row = dqkv + ((long long)b * T + q) * ld + h * HD;
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (dq[d][4 * a + r] + park[(d * 16 + 4 * a + r) * 64 + lane]) * p.scale;
+        *reinterpret_cast<f32x4*>(row + 32 * d + 8 * a + 4 * hi) = v;
+      }
+  }
+}
+
+// dK, dV: own = 32 keys per wavefront (K' = K * scale * log2e and V in registers), tiles = queries (Q, dO rows and
+// their {lse', delta'} pairs)
+template <int HD, bool DROP>
+__global__ __launch_bounds__(256, 1) void attn2_bwd_dkv_kernel(Attn2Args p, const float* __restrict__ dout,
+                                                               const float2* __restrict__ aux, float* __restrict__ dqkv) {
+  constexpr int NJ = HD / 8, NDB = HD / 32, TILE = KT * HD, NP = TileDma<HD, 128>::NP, STAGE = 2 * TILE + 256;
+  __shared__ __attribute__((aligned(1024))) float smem[4 * STAGE];  // [query group][stage][Q | dO | aux (1 KB)]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5, l32 = lane & 31;
+  const int rb = wave & 1, qg = wave >> 1, gtid = tid & 127;
+  int kblk, b, h;
+  work_unit(p, (p.T + 63) / 64, kblk, b, h);
+  const int T = p.T, D = p.H * HD, ld = 3 * D;
+  const int key = kblk * 64 + rb * 32 + l32;
+  const int len = p.lens[b];
+  const float* base = p.qkv + (long long)b * T * ld;
+  float* krow = dqkv + ((long long)b * T + key) * ld + D + h * HD;
+  float* vrow = krow + D;
+  if (kblk * 64 >= len) {  // every key of this workgroup is padding: its gradients are zero
+    if (qg == 0 && key < T) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          *reinterpret_cast<f32x4*>(krow + 32 * d + 8 * a + 4 * hi) = z;
+          *reinterpret_cast<f32x4*>(vrow + 32 * d + 8 * a + 4 * hi) = z;
+        }
+    }
+    return;
+  }
+  const int nt = (T + KT - 1) / KT, n0 = (nt + 1) / 2;  // query tiles: every row of the padded sequence has a gradient
+  const int tile0 = qg ? n0 : 0, mine = qg ? nt - n0 : n0;
+  PairHash ph;
+  ph.setup(fs2_resolve_drop(p.drop));
+  const __amdgpu_buffer_rsrc_t rq = make_rsrc(base + h * HD), rdo = make_rsrc(dout + (long long)b * T * D + h * HD);
+  const __amdgpu_buffer_rsrc_t rax = make_rsrc(reinterpret_cast<const float*>(aux + ((long long)b * p.H + h) * T));
+  TileDma<HD, 128> dmaq, dmao;
+  dmaq.setup(ld, gtid);
+  dmao.setup(D, gtid);
+  float* gbuf = smem + qg * 2 * STAGE;
+  // the 32 {lse', delta'} pairs of a query tile: 16 pieces of 16 bytes, issued by the first 16 lanes of the row
+  // block-0 wavefront (the other lanes carry the out-of-range offset: zeros into the slack of the 1 KB slot)
+  auto issue_aux = [&](float* stage, int q0) {
+    if (rb == 0) {
+      const int piece = lane;  // 2 queries per piece
+      const bool ok = lane < 16 && q0 + 2 * piece < T;  // (T even or not: a piece past T-1 reads one pair too many -> aux is padded by the launcher)
+      blds16(rax, ok ? piece * 16 : FS2_OOB, q0 * 8, stage + 2 * TILE);
+    }
+  };
+  if (mine > 0) {
+    dmaq.issue(rq, gbuf, tile0 * KT, T, ld, rb);
+    dmao.issue(rdo, gbuf + TILE, tile0 * KT, T, D, rb);
+    issue_aux(gbuf, tile0 * KT);
+  }
+  f32x4 kv[NJ], vv[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f}, w = {0.f, 0.f, 0.f, 0.f};
+    if (key < T) {
+      v = *reinterpret_cast<const f32x4*>(base + (long long)key * ld + D + h * HD + 8 * j + 4 * hi);
+      w = *reinterpret_cast<const f32x4*>(base + (long long)key * ld + 2 * D + h * HD + 8 * j + 4 * hi);
+    }
+    kv[j] = to_agpr(v * (p.scale * 1.44269504088896f));
+    vv[j] = to_agpr(w);
+  }
+  f32x16 dk[NDB], dv[NDB];
+#pragma unroll
+  for (int d = 0; d < NDB; ++d)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      dk[d][i] = 0.f;
+      dv[d][i] = 0.f;
+    }
+  const bool key_ok = key < len;
+  const uint32_t Tp = (uint32_t)(T + (T & 1));
+  const uint32_t head0 = (uint32_t)((unsigned long long)(b * p.H + h) * T) * Tp;  // (wraps like the other kernels' 32-bit index)
+  const int sh16 = 16 * (key & 1);
+  RowRd rd;
+  rd.setup<HD>(l32, hi);
+  ColRd cr;
+  cr.setup<HD>(l32, hi);
+  const unsigned g0 = lds_addr(gbuf);
+  STAMP_DECL;
+  for (int j = 0; j < n0; ++j) {
+    const int q0 = (tile0 + j) * KT;
+    const bool act = j < mine, actn = j + 1 < mine;
+    const int st = j & 1;
+    STAMP(0)
+    wait_vmcnt_barrier<0>();
+    STAMP(1)
+    if (!act) continue;
+    const unsigned qb_ = g0 + st * STAGE * 4, ob = qb_ + TILE * 4, ab = ob + TILE * 4;
+    float* nxt = gbuf + (st ^ 1) * STAGE;
+    const unsigned ab_hi = ab + 4 * hi * 8;  // {lse', delta'} of tile row 8a + 4hi + r: broadcast ds_read_b64 at (8a + r) * 8
+    if (actn) issue_aux(nxt, q0 + KT);
+    f32x16 s = dot_rows<HD, true>(rd, qb_, kv, [&](auto jc) {
+      constexpr int it = decltype(jc)::value;
+      if constexpr (it < NP) {
+        if (actn) dmaq.template piece<it>(rq, nxt, q0 + KT, T, ld, rb);
+      }
+    });
+    STAMP(2)
+    f32x16 dp = dot_rows<HD, true>(rd, ob, vv, [&](auto jc) {
+      constexpr int it = decltype(jc)::value;
+      if constexpr (it < NP) {
+        if (actn) dmao.template piece<it>(rdo, nxt + TILE, q0 + KT, T, D, rb);
+      }
+    });
+    STAMP(3)
+    const uint32_t rowkey = head0 + (uint32_t)(q0 + 4 * hi) * Tp + (uint32_t)key;  // element index of (row q0 + 4hi, own key)
+    float wv = 0.f, wk = 0.f;
+    float2 axs[2];  // the pairs of steps t and t + 1 (two in flight: a pair is read a whole step before its use)
+    auto aux_read = [&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      lds_rd64<(8 * (t >> 2) + (t & 3)) * 8>(axs[t & 1], ab_hi);
+    };
+    auto weights = [&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      pin(axs[t & 1]);
+      const float pp = key_ok ? __builtin_amdgcn_exp2f(s[t] - axs[t & 1].x) : 0.f;
+      float pd = pp;
+      if constexpr (DROP) {
+        const uint32_t idx = rowkey + (uint32_t)(8 * (t >> 2) + (t & 3)) * Tp;
+        const uint32_t hh = ph.hash(idx >> 1);
+        pd = ((hh >> sh16) & 0xffffu) >= ph.thresh ? pp : 0.f;
+      }
+      wv = pd;
+      wk = fmaf(-pp, axs[t & 1].y, pd * dp[t]);
+    };
+    aux_read(std::integral_constant<int, 0>{});
+    aux_read(std::integral_constant<int, 1>{});
+    lds_wait<1>();
+    weights(std::integral_constant<int, 0>{});
+    float wv_c = wv, wk_c = wk;
+    STAMP(4)
+    // per step 2 NDB MFMAs: dv^T[d][key] += dO[q][d] * pd[q][key], dk^T[d][key] += Q[q][d] * dS[q][key].  The aux pair
+    // of step t + 2 is read behind the last MFMA of step t: by the time weights(t + 2) runs, the stream's own waits
+    // (at most 7 younger reads outstanding before every MFMA) have long covered it.
+    read_mfma_stream<32 * NDB, 8>(
+        [&](auto ic, float& dst) {
+          constexpr int i = decltype(ic)::value, t = i / (2 * NDB), u = i % (2 * NDB), db = u % NDB;
+          lds_rd32<col_off<HD, t, db>()>(dst, (u < NDB ? ob : qb_) + cr.base[t & 3]);
+        },
+        [&](auto ic, float v) {
+          constexpr int i = decltype(ic)::value, t = i / (2 * NDB), u = i % (2 * NDB), db = u % NDB;
+          if constexpr (u < NDB) mfma32_agpr(dv[db], v, wv_c);
+          else mfma32_agpr(dk[db], v, wk_c);
+          if constexpr (u == 2 * NDB - 1 && t + 1 < 16) {
+            weights(std::integral_constant<int, t + 1>{});
+            wv_c = wv;
+            wk_c = wk;
+            if constexpr (t + 2 < 16) aux_read(std::integral_constant<int, t + 2>{});
+          }
+        });
+    STAMP(5)
+  }
+  STAMP_FLUSH(p.stamps, blockIdx.x)
+  mfma_drain();
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  float* park = smem + rb * 2 * NDB * 16 * 64;
+  static_assert(2 * 2 * NDB * 16 * 64 <= 4 * STAGE, "parking area");
+  if (qg == 1) {
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        park[(d * 16 + i) * 64 + lane] = dk[d][i];
+        park[((NDB + d) * 16 + i) * 64 + lane] = dv[d][i];
+      }
+  }
+  __syncthreads();
+  if (qg == 0 && key < T) {
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        f32x4 gk, gv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          gk[r] = (dk[d][4 * a + r] + park[(d * 16 + 4 * a + r) * 64 + lane]) * p.scale;
+          gv[r] = dv[d][4 * a + r] + park[((NDB + d) * 16 + 4 * a + r) * 64 + lane];
+        }
+        *reinterpret_cast<f32x4*>(krow + 32 * d + 8 * a + 4 * hi) = gk;
+        *reinterpret_cast<f32x4*>(vrow + 32 * d + 8 * a + 4 * hi) = gv;
+      }
+  }
+}
+
 }  // namespace
 
 bool fs2_attn2_supported(int HD, int operand_bf16) { return !operand_bf16 && (HD == 64 || HD == 128); }
@@ -453,3 +924,44 @@ int fs2_attn2_fwd(const Attn2Args& a, float* o, float* lse, hipStream_t s) {
   FS2_LAUNCH_CHECK();
   return 0;
 }
+
+// `delta` is the caller's [B][H][T] scratch of the first-generation interface; the second generation needs a
+// {lse', delta'} pair per row and head plus one pair of slack, so it is only used when the caller passes `aux`.
+int fs2_attn2_bwd(const Attn2Args& a, const float* o, const float* dout, const float* lse, float* aux, float* dqkv,
+                  hipStream_t s) {
+  if ((double)a.B * a.H * a.T * (a.T + 1) >= 4294967296.0) return FS2HIP_EINVAL;
+  const float dscale = a.drop.on ? a.drop.scale : 1.f;
+  attn2_prep_kernel<<<dim3((a.B * a.T + 3) / 4), dim3(256), 0, s>>>(dout, o, lse, reinterpret_cast<float2*>(aux), a.B, a.T,
+                                                                     a.H, a.HD, log2f(dscale), 1.f / dscale);
+  FS2_LAUNCH_CHECK();
+  dim3 grid(((a.T + 63) / 64) * a.H * a.B);
+  const float2* ax = reinterpret_cast<const float2*>(aux);
+#define FS2_ATTN2_BWD(HD_, DROP_)                                                        \
+  attn2_bwd_dq_kernel<HD_, DROP_><<<grid, dim3(256), 0, s>>>(a, dout, ax, dqkv);         \
+  FS2_LAUNCH_CHECK();                                                                    \
+  attn2_bwd_dkv_kernel<HD_, DROP_><<<grid, dim3(256), 0, s>>>(a, dout, ax, dqkv);
+  if (a.HD == 128) {
+    if (a.drop.on) { FS2_ATTN2_BWD(128, true) } else { FS2_ATTN2_BWD(128, false) }
+  } else {
+    if (a.drop.on) { FS2_ATTN2_BWD(64, true) } else { FS2_ATTN2_BWD(64, false) }
+  }
+#undef FS2_ATTN2_BWD
+  FS2_LAUNCH_CHECK();
+  return 0;
+}
+
+#ifdef FS2_ATTN_STAMPS
+// diagnostic build: one of the two gradient kernels alone (which = 0: dQ, 1: dK/dV), HD = 128, after a prep launch
+int fs2_attn2_bwd_one(const Attn2Args& a, const float* dout, const float* aux, float* dqkv, int which, hipStream_t s) {
+  dim3 grid(((a.T + 63) / 64) * a.H * a.B);
+  const float2* ax = reinterpret_cast<const float2*>(aux);
+  if (which == 0) {
+    if (a.drop.on) attn2_bwd_dq_kernel<128, true><<<grid, dim3(256), 0, s>>>(a, dout, ax, dqkv);
+    else attn2_bwd_dq_kernel<128, false><<<grid, dim3(256), 0, s>>>(a, dout, ax, dqkv);
+  } else {
+    if (a.drop.on) attn2_bwd_dkv_kernel<128, true><<<grid, dim3(256), 0, s>>>(a, dout, ax, dqkv);
+    else attn2_bwd_dkv_kernel<128, false><<<grid, dim3(256), 0, s>>>(a, dout, ax, dqkv);
+  }
+  return 0;
+}
+#endif

@@ -662,7 +662,7 @@ def attention_bwd(qkv, lens, o, dout, lse, B, T, H, drop: Drop = NO_DROP):
     _req(_rows(qkv) == B * T and o.numel() == B * T * D and dout.numel() == B * T * D and lse.numel() == B * H * T
          and lens.numel() == B, "attention_bwd: shape mismatch")
     dqkv = torch.empty_like(qkv)
-    delta = torch.empty_like(lse)
+    delta = torch.empty(2 * lse.numel() + 4, device=lse.device, dtype=torch.float32)  # scratch: see fs2hip.h
     _ok(lib().fs2hip_attention_bwd(_p(qkv), _p(lens), _p(o), _p(dout), _p(lse), _p(delta), _p(dqkv), B, T, H, D // H,
                                    drop.p, drop.seed, drop.step_ptr, int(GEMM_BF16), _stream()), "attention_bwd")
     return dqkv

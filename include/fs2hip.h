@@ -140,14 +140,16 @@ int fs2hip_layernorm_bwd(const float* dy, const float* x, const float* gamma, co
                          float* dgamma, float* dbeta, int M, int C, void* stream);
 
 /* ------------------------------------------------------------------------------------
- * Multi-head self-attention with key-padding mask (flash style; fp32 MFMA 16x16x4).
+ * Multi-head self-attention with key-padding mask (flash style; fp32 MFMA: v_mfma_f32_32x32x2_f32 for
+ * head dims 64 / 128 -- attention2.hip -- and 16x16x4 for head dims 16 / 32).
  * Replaces nn.MultiheadAttention's scaled-dot-product core inside torchaudio's
  * ConformerLayer (call sites fs2/model.py:193, :241).
  *   qkv  [B*T][3*H*HD]  in_proj output (q | k | v);  lens [B] int32 (keys >= lens[b] masked)
  *   o    [B*T][H*HD];   lse [B][H][T] (log-sum-exp per query, saved for the backward)
  *   dropout acts on the normalised probabilities (attention dropout), mask regenerated
  *   from (seed, b, h, q, k) in the backward.  HD in {16, 32, 64, 128}.
- * bwd: delta [B][H][T] scratch; dqkv [B*T][3*H*HD] fully written.
+ * bwd: delta = scratch of 2*B*H*T + 4 floats ({lse', delta'} pairs per row and head); dqkv [B*T][3*H*HD]
+ *      fully written.
  * operand_bf16 = 1 ("bf16-mixed"): the operands of all five products (Q, K, V, dO, P, dS) are rounded to bf16 for
  *   v_mfma_f32_16x16x32_bf16; scores, softmax statistics, accumulators and outputs stay fp32.
  * ------------------------------------------------------------------------------------ */

@@ -27,9 +27,14 @@ dev = "cuda"
 B, T, Hh, HD = 32, int(sys.argv[3]) if len(sys.argv) > 3 else 648, 2, 128
 D = Hh * HD
 g = torch.Generator().manual_seed(0)
-lens = torch.randint(int(T * 0.66), T + 1, (B,), generator=g).int() if mode == "ragged" else torch.full((B,), T, dtype=torch.int32)
+if mode == "ragged":
+    lens = torch.randint(int(T * 0.66), T + 1, (B,), generator=g).int()
+elif mode.startswith("len"):
+    lens = torch.full((B,), int(mode[3:]), dtype=torch.int32)
+else:
+    lens = torch.full((B,), T, dtype=torch.int32)
 lens = lens.to(dev)
-qkv = torch.randn(B * T, 3 * D, device=dev)
+qkv = torch.randn(B * T, 3 * D, device=dev) if "FS2_UNIFORM" not in __import__("os").environ else torch.rand(B * T, 3 * D, device=dev) * 2 - 1
 dout = torch.randn(B * T, D, device=dev)
 step = torch.zeros(4, dtype=torch.int64, device=dev)
 drop = H.Drop(p, 777, step) if p > 0 else H.NO_DROP
