@@ -161,7 +161,7 @@ def main():
                     help="second tuner stage: try the next-best GEMM tiles inside the step (+6 s of warm-up; measured gain 0.4 %%)")
     ap.add_argument("--gst", action="store_true",
                     help="BASELINE.json configs[4] shape in fp32: multi-speaker (16) + GST style encoder, mel up to ~1200 frames")
-    ap.add_argument("--precision", default="32-true", choices=["32-true", "bf16-mixed"],
+    ap.add_argument("--precision", default="32-true", choices=["32-true", "32-split", "bf16-mixed"],
                     help="bf16-mixed = BASELINE.json configs[2] (use with --batch 64): GEMM operands rounded to bf16 for the bf16 "
                          "MFMA, fp32 accumulation / parameters / activations.  The headline metric is quoted on 32-true")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -20,7 +20,7 @@
 #include "gemm2_core.h"
 namespace {
 
-template <int BM, int BN, bool AKC, bool BKC, int NST, int TAPS, bool BF>
+template <int BM, int BN, bool AKC, bool BKC, int NST, int TAPS, int BF>
 __global__ __launch_bounds__(256) void gemm2_kernel(GemmP p) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int A_TILE = BM * BK2, B_TILE = BN * BK2, STAGE = A_TILE + B_TILE;
@@ -109,8 +109,9 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmP p) {
 // fp32 or bf16-operand instance of one kernel shape
 #define FS2_GO(AKC_, BKC_, TAPS_)                                                          \
   do {                                                                                     \
-    if (a.operand_bf16) gemm2_kernel<BM, BN, AKC_, BKC_, NST, TAPS_, true><<<grid, block, 0, s>>>(p);  \
-    else gemm2_kernel<BM, BN, AKC_, BKC_, NST, TAPS_, false><<<grid, block, 0, s>>>(p);    \
+    if (a.operand_bf16 == 2) gemm2_kernel<BM, BN, AKC_, BKC_, NST, TAPS_, 2><<<grid, block, 0, s>>>(p);  \
+    else if (a.operand_bf16) gemm2_kernel<BM, BN, AKC_, BKC_, NST, TAPS_, 1><<<grid, block, 0, s>>>(p);  \
+    else gemm2_kernel<BM, BN, AKC_, BKC_, NST, TAPS_, 0><<<grid, block, 0, s>>>(p);        \
   } while (0)
 
 template <int BM, int BN, int NST, bool GENERIC_TOO>

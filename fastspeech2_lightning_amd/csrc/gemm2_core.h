@@ -411,10 +411,109 @@ __device__ __forceinline__ void compute_ktile_bf16(f32x16 (&acc)[BM / 64][BN / 6
 #undef FS2_PAIR
 }
 
-template <bool BF, int BM, int BN, bool AKC, bool BKC>
+// "32-split" operands (Fs2GemmArgs.operand_bf16 == 2): fp32 accuracy on the bf16 matrix pipe.  Every operand value is
+// cut -- exactly, by truncation -- into three bf16 planes x = x0 + x1 + x2 (8 + 8 + 8 = the 24 significant bits of an
+// fp32), and a product a*b is taken as the six partial products a_i*b_j with i + j <= 2, each one EXACT in the
+// MFMA's fp32 accumulation (8 x 8 significant bits), smallest first.  What is dropped (a1*b2, a2*b1, a2*b2) is below
+// 2^-24 |a||b|, i.e. below the rounding of the fp32 product itself: the result meets the fp32 kernels' error bound
+// (tests/test_gemm_split_gpu.py holds it to the same tolerance, against float64).  Cost: six v_mfma_f32_32x32x16_bf16
+// (8 passes each) per sixteen reduction steps instead of eight v_mfma_f32_32x32x2_f32 (16 passes each) -- 48 pipe
+// cycles instead of 128 per 32x32x16 block -- plus 5.5 vector instructions per operand value for the cut, which run
+// beside the bf16 MFMAs (unlike fp32 MFMAs, they do not share the vector ALUs).  Same fp32 LDS images, same reads.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
+  const unsigned ua = __builtin_bit_cast(unsigned, a), ub = __builtin_bit_cast(unsigned, b);
+  p0 = __builtin_amdgcn_perm(ub, ua, 0x07060302u);  // {hi16(b), hi16(a)}: two truncated bf16
+  const float ra = a - __builtin_bit_cast(float, ua & 0xffff0000u), rb = b - __builtin_bit_cast(float, ub & 0xffff0000u);
+  const unsigned va = __builtin_bit_cast(unsigned, ra), vb = __builtin_bit_cast(unsigned, rb);
+  p1 = __builtin_amdgcn_perm(vb, va, 0x07060302u);
+  const float sa = ra - __builtin_bit_cast(float, va & 0xffff0000u), sb = rb - __builtin_bit_cast(float, vb & 0xffff0000u);
+  p2 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, sb), __builtin_bit_cast(unsigned, sa), 0x07060302u);
+}
+
+struct Planes {
+  bf16x8 p[3];
+};
+template <int T, bool KC>
+__device__ __forceinline__ Planes frag_split3(const Frag<T, KC>& lo, const Frag<T, KC>& hi, int i) {
+  u32x4 q0, q1, q2;
+  unsigned a0, a1, a2;
+  split_pair(lo.get(i, 0), lo.get(i, 1), a0, a1, a2); q0[0] = a0; q1[0] = a1; q2[0] = a2;
+  split_pair(lo.get(i, 2), lo.get(i, 3), a0, a1, a2); q0[1] = a0; q1[1] = a1; q2[1] = a2;
+  split_pair(hi.get(i, 0), hi.get(i, 1), a0, a1, a2); q0[2] = a0; q1[2] = a1; q2[2] = a2;
+  split_pair(hi.get(i, 2), hi.get(i, 3), a0, a1, a2); q0[3] = a0; q1[3] = a1; q2[3] = a2;
+  Planes r;
+  r.p[0] = __builtin_bit_cast(bf16x8, q0);
+  r.p[1] = __builtin_bit_cast(bf16x8, q1);
+  r.p[2] = __builtin_bit_cast(bf16x8, q2);
+  return r;
+}
+
+template <int BM, int BN, bool AKC, bool BKC>
+__device__ __forceinline__ void compute_ktile_split(f32x16 (&acc)[BM / 64][BN / 64], const RdAddr<BM, AKC>& rda,
+                                                    const RdAddr<BN, BKC>& rdb, unsigned sa, unsigned sb) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  Frag<TM, AKC> fa[4];
+  Frag<TN, BKC> fb[4];
+  constexpr int RD = Frag<TM, AKC>::READS + Frag<TN, BKC>::READS;
+  frag_read<0, BM>(fa[0], rda, sa);
+  frag_read<0, BN>(fb[0], rdb, sb);
+  frag_read<1, BM>(fa[1], rda, sa);
+  frag_read<1, BN>(fb[1], rdb, sb);
+  frag_read<2, BM>(fa[2], rda, sa);
+  frag_read<2, BN>(fb[2], rdb, sb);
+  frag_read<3, BM>(fa[3], rda, sa);
+  frag_read<3, BN>(fb[3], rdb, sb);
+  lds_wait<0>();
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    fa[g].pin_all();
+    fb[g].pin_all();
+  }
+  // The cut of the second half of the K-tile is issued between the MFMAs of the first half (the bf16 matrix pipe
+  // and the vector ALUs run side by side, but a wavefront issues in order: a block of 170 vector instructions in
+  // front of 24 MFMAs leaves the pipe idle for its whole length).  7 vector instructions per 32-cycle MFMA.
+  Planes ua[2][TM], ub[2][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) ua[0][i] = frag_split3(fa[0], fa[1], i);
+#pragma unroll
+  for (int jn = 0; jn < TN; ++jn) ub[0][jn] = frag_split3(fb[0], fb[1], jn);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) ua[1][i] = frag_split3(fa[2], fa[3], i);
+#pragma unroll
+  for (int jn = 0; jn < TN; ++jn) ub[1][jn] = frag_split3(fb[2], fb[3], jn);
+#pragma unroll
+  for (int P = 0; P < 2; ++P)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn) {
+        f32x16 c = acc[i][jn];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua[P][i].p[2], ub[P][jn].p[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua[P][i].p[0], ub[P][jn].p[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua[P][i].p[1], ub[P][jn].p[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua[P][i].p[1], ub[P][jn].p[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua[P][i].p[0], ub[P][jn].p[1], c, 0, 0, 0);
+        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua[P][i].p[0], ub[P][jn].p[0], c, 0, 0, 0);
+      }
+  // schedule: [cut of half 0] then 6 TM TN x {1 MFMA, 7 vector} (half 0's MFMAs over half 1's cut), then the rest
+  constexpr int CUT = 44 * (TM + TN);  // vector instructions of one half's cut
+  __builtin_amdgcn_sched_group_barrier(0x002, CUT, 0);
+#pragma unroll
+  for (int k = 0; k < 6 * TM * TN; ++k) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, (CUT + 6 * TM * TN - 1) / (6 * TM * TN), 0);
+  }
+  __builtin_amdgcn_sched_group_barrier(0x008, 6 * TM * TN, 0);
+}
+
+// BF: 0 = fp32 MFMA, 1 = operands rounded to bf16 ("bf16-mixed"), 2 = three-plane split ("32-split")
+template <int BF, int BM, int BN, bool AKC, bool BKC>
 __device__ __forceinline__ void compute_ktile_any(f32x16 (&acc)[BM / 64][BN / 64], const RdAddr<BM, AKC>& rda,
                                                   const RdAddr<BN, BKC>& rdb, unsigned sa, unsigned sb) {
-  if constexpr (BF) compute_ktile_bf16<BM, BN, AKC, BKC>(acc, rda, rdb, sa, sb);
+  if constexpr (BF == 2) compute_ktile_split<BM, BN, AKC, BKC>(acc, rda, rdb, sa, sb);
+  else if constexpr (BF == 1) compute_ktile_bf16<BM, BN, AKC, BKC>(acc, rda, rdb, sa, sb);
   else compute_ktile<BM, BN, AKC, BKC>(acc, rda, rdb, sa, sb);
 }
 

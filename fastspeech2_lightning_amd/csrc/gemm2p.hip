@@ -68,7 +68,7 @@ __device__ __forceinline__ Unit decode_unit(const GemmP& p, const Hybrid& hy, in
   return q;
 }
 
-template <int BM, int BN, bool AKC, bool BKC, int TAPS, bool BF>
+template <int BM, int BN, bool AKC, bool BKC, int TAPS, int BF>
 __global__ __launch_bounds__(256) void gemm2p_kernel(GemmP p, Hybrid hy, int nunits, int tiles) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int A_TILE = BM * BK2, B_TILE = BN * BK2, STAGE = A_TILE + B_TILE;
@@ -193,8 +193,9 @@ __global__ __launch_bounds__(256) void tail_fixup_epi_kernel(GemmP p, Hybrid hy)
 
 #define FS2_GO(AKC_, BKC_, TAPS_)                                                                             \
   do {                                                                                                        \
-    if (a.operand_bf16) gemm2p_kernel<BM, BN, AKC_, BKC_, TAPS_, true><<<grid, block, 0, s>>>(p, hy, nunits, tiles);  \
-    else gemm2p_kernel<BM, BN, AKC_, BKC_, TAPS_, false><<<grid, block, 0, s>>>(p, hy, nunits, tiles);        \
+    if (a.operand_bf16 == 2) gemm2p_kernel<BM, BN, AKC_, BKC_, TAPS_, 2><<<grid, block, 0, s>>>(p, hy, nunits, tiles);  \
+    else if (a.operand_bf16) gemm2p_kernel<BM, BN, AKC_, BKC_, TAPS_, 1><<<grid, block, 0, s>>>(p, hy, nunits, tiles);  \
+    else gemm2p_kernel<BM, BN, AKC_, BKC_, TAPS_, 0><<<grid, block, 0, s>>>(p, hy, nunits, tiles);            \
   } while (0)
 
 template <int BM, int BN, int WG_PER_CU, bool SPLIT_TAIL>

@@ -231,8 +231,11 @@ GEMM_PROFILE = None
 GEMM_TUNE = os.environ.get("FS2_GEMM_TUNE", "1") != "0"
 #: "bf16-mixed": every algorithmic GEMM rounds its operands to bf16 in registers (v_mfma_f32_32x32x16_bf16, fp32
 #: accumulate / epilogue / storage).  Set through ``set_precision``; the fp32 path is the parity path and the default.
-GEMM_BF16 = False
-PRECISIONS = {"32-true": False, "32": False, "fp32": False, "bf16-mixed": True, "bf16": True}
+#: "32-split": fp32 accuracy on the bf16 matrix pipe -- every operand value is cut exactly into three bf16 planes in
+#: registers and a product is the six partial products that matter, accumulated in fp32 (csrc/gemm2_core.h); the
+#: GEMM family only (attention stays on the fp32 MFMA), same error bound as "32-true" (tests/test_gemm_split_gpu.py).
+GEMM_BF16 = 0
+PRECISIONS = {"32-true": 0, "32": 0, "fp32": 0, "bf16-mixed": 1, "bf16": 1, "32-split": 2}
 
 
 def set_precision(precision) -> None:
@@ -244,7 +247,7 @@ def set_precision(precision) -> None:
 
 
 def get_precision() -> str:
-    return "bf16-mixed" if GEMM_BF16 else "32-true"
+    return {0: "32-true", 1: "bf16-mixed", 2: "32-split"}[int(GEMM_BF16)]
 
 
 GEMM_TILES = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)  # 1-3: register-staged BK=16 core; 4-9: direct-to-LDS BK=32 core;
@@ -401,7 +404,7 @@ def _gemm(_algorithmic=True, **kw):
     if not a.workspace:  # scratch for the split-tail tiles (13-15): at most one slab of partial sums per workgroup slot
         ws = _workspace(HYBRID_WS_FLOATS, _current_device())
         a.workspace, a.workspace_floats = _p(ws), ws.numel()
-    a.operand_bf16 = 1 if (GEMM_BF16 and _algorithmic) else 0
+    a.operand_bf16 = int(GEMM_BF16) if _algorithmic else 0
     a.tile = _tune_tile(a)
     if GEMM_PROFILE is None or not _algorithmic:  # (the one-hot embedding GEMM's flops are not algorithmic)
         _launch_gemm(a)
@@ -650,7 +653,7 @@ def attention_fwd(qkv, lens, B, T, H, drop: Drop = NO_DROP):
     o = torch.empty(B, T, D, device=qkv.device, dtype=torch.float32)
     lse = torch.empty(B, H, T, device=qkv.device, dtype=torch.float32)
     _ok(lib().fs2hip_attention_fwd(_p(qkv), _p(lens), _p(o), _p(lse), B, T, H, D // H, drop.p, drop.seed,
-                                   drop.step_ptr, int(GEMM_BF16), _stream()), "attention_fwd")
+                                   drop.step_ptr, int(GEMM_BF16 == 1), _stream()), "attention_fwd")
     return o, lse
 
 
@@ -664,7 +667,7 @@ def attention_bwd(qkv, lens, o, dout, lse, B, T, H, drop: Drop = NO_DROP):
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(2 * lse.numel() + 4, device=lse.device, dtype=torch.float32)  # scratch: see fs2hip.h
     _ok(lib().fs2hip_attention_bwd(_p(qkv), _p(lens), _p(o), _p(dout), _p(lse), _p(delta), _p(dqkv), B, T, H, D // H,
-                                   drop.p, drop.seed, drop.step_ptr, int(GEMM_BF16), _stream()), "attention_bwd")
+                                   drop.p, drop.seed, drop.step_ptr, int(GEMM_BF16 == 1), _stream()), "attention_bwd")
     return dqkv
 
 

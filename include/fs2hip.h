@@ -97,7 +97,11 @@ typedef struct {
   long long workspace_floats; /* capacity of `workspace` */
   int operand_bf16; /* 0: fp32 MFMA (the default, the parity path).  1: "bf16-mixed" -- A and B stay fp32 in memory and
                        in LDS, are rounded to bf16 (RNE) in registers and multiplied with v_mfma_f32_32x32x16_bf16;
-                       accumulation, bias/epilogue and C stay fp32.  Only the direct-to-LDS cores (tile >= 4) carry it;
+                       accumulation, bias/epilogue and C stay fp32.  2: "32-split" -- fp32 accuracy on the bf16 pipe:
+                       every operand value is cut exactly into three bf16 planes in registers (x = x0 + x1 + x2) and a
+                       product is the six partial products a_i b_j with i + j <= 2, accumulated in fp32, smallest first
+                       (what is dropped is below the rounding of the fp32 product): the error bound of mode 0 at
+                       2.7x its matrix-pipe rate.  Only the direct-to-LDS cores (tile >= 4) carry modes 1 and 2;
                        shapes those cores refuse run in fp32 */
 } Fs2GemmArgs;
 
