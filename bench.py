@@ -165,6 +165,7 @@ def main():
                     help="bf16-mixed = BASELINE.json configs[2] (use with --batch 64): GEMM operands rounded to bf16 for the bf16 "
                          "MFMA, fp32 accumulation / parameters / activations.  The headline metric is quoted on 32-true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-split-line", action="store_true", help="skip the secondary 32-split measurement")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--learn-alignment", action="store_true",
                     help="reference default config: jointly learned alignment (aligner + MAS + CTC/bin losses)")
@@ -365,17 +366,43 @@ def main():
                         "gemm_ms_per_step": round(ms, 3), "event_pair_overhead_us": round(ov * 1e3, 2),
                         "gemm_ms_per_step_raw_events": round(raw_ms, 3)}
         else:
+            split_main = args.precision == "32-split"
+            # 32-split: six bf16 MFMA products per algorithmic product -> the pipe's ceiling for fp32-accurate flops
+            peak = round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1) if split_main else PEAK_FP32_MFMA_TFLOPS
             roofline = {
-                    "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": round(sum(q[6] for q in prof) / len(prof)),
-                    "kernel": "gemm2_kernel / gemm2p_kernel / gemm_kernel family (fp32 v_mfma_f32_32x32x2_f32), tile autotuned per shape",
+                    "kernel": ("gemm2_kernel / gemm2p_kernel family, 32-split instances (6 x v_mfma_f32_32x32x16_bf16 per 32x32x16 block; "
+                               "peak = dense bf16 MFMA peak / 6)" if split_main else
+                               "gemm2_kernel / gemm2p_kernel / gemm_kernel family (fp32 v_mfma_f32_32x32x2_f32), tile autotuned per shape"),
                     "launches_per_step": len(prof),
                     "avg_launch_us": round(ms * 1e3 / len(prof), 2), "flops_per_launch": round(flops / len(prof)),
                     "gemm_ms_per_step": round(ms, 3), "event_pair_overhead_us": round(ov * 1e3, 2),
                     "gemm_ms_per_step_raw_events": round(raw_ms, 3)}
 
     log("roofline pass done")
+    # The same step with precision "32-split" (fp32-accurate GEMMs on the bf16 matrix pipe, tests/test_gemm_split_gpu.py):
+    # reported beside the headline, never as it -- `value` above is the exact fp32 MFMA path.
+    split = None
+    if args.precision == "32-true" and world == 1 and not args.no_split_line and graph is None:
+        model.precision = "32-split"
+        for _ in range(2):
+            step()  # (tunes the tiles of the split instances)
+        torch.cuda.synchronize()
+        n_split = max(20, args.steps // 4)
+        t1 = time.perf_counter()
+        for _ in range(n_split):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / n_split
+        model.precision = "32-true"
+        split = {"precision": "32-split", "ms_per_step": round(dt * 1e3, 3), "value": round(frames / dt, 1), "unit": "mel-frames/s",
+                 "steps": n_split,
+                 "note": "every GEMM operand cut exactly into three bf16 planes in registers, six partial products per "
+                         "product on v_mfma_f32_32x32x16_bf16, fp32 accumulation: the fp32 kernels' error bound (same parity "
+                         "tests, same tolerances); attention, normalisations, losses and the optimizer unchanged"}
+        log(f"32-split: {dt * 1e3:.2f} ms/step")
     cpu = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         cpu = cpu_baseline(config, batch)
@@ -388,9 +415,10 @@ def main():
             "value": round(frames_all * args.steps / elapsed, 1), "unit": "mel-frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "32-true" else "bf16 MFMA operands, f32 accumulate / parameters / activations",
+            "dtype": {"32-true": "f32", "32-split": "f32 (GEMM products from three exact bf16 planes per operand, f32 accumulate)",
+                      "bf16-mixed": "bf16 MFMA operands, f32 accumulate / parameters / activations"}[args.precision],
             "data": "synthetic",
-            "config": {"workload": ("BASELINE.json configs[1]: fp32 train step, batch=32/GPU" if args.precision == "32-true" else
+            "config": {"workload": (f"BASELINE.json configs[1]: fp32 train step, batch={args.batch}/GPU" if args.precision != "bf16-mixed" else
                                     f"BASELINE.json configs[2]: bf16-mixed train step, batch={args.batch}/GPU") + ", LJSpeech-shaped synthetic "
                                    "(96-128 phonemes, 80 x ~600 mel), learn_alignment=" + str(args.learn_alignment) + ", dropout on"
                                    + (" [--gst: multi-speaker + GST, mel up to ~1200 frames (configs[4] shape, fp32)]" if args.gst else ""),
@@ -401,7 +429,7 @@ def main():
             "per_gpu_value": round(frames_all * args.steps / elapsed / world, 1),
             "padded_frames_per_s": round(padded_all * args.steps / elapsed, 1),
             "loss_total": round(losses.get("total", float("nan")), 5),
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "split_fp32": split,
         }
         # whole-step view (SURVEY.md 8d closed form, padded shapes, backward = 2 x forward): algorithmic FLOPs of the
         # step / step time against the fp32 MFMA peak -- beside the dominant kernel's own roofline above
@@ -412,7 +440,7 @@ def main():
             f_step += 3.0 * Bq * (Ts_p * 868352 + Tm_p * (115200 + 240 * Ts_p))
         tf = f_step / (ms_per_step * 1e-3) / 1e12
         line["whole_step"] = {"algorithmic_tflop_per_step_per_gpu": round(f_step / 1e12, 4), "achieved_tflops_per_gpu": round(tf, 2)}
-        if args.precision == "32-true":
+        if args.precision != "bf16-mixed":
             line["whole_step"]["frac_of_fp32_mfma_peak"] = round(tf / PEAK_FP32_MFMA_TFLOPS, 4)
         else:  # (attention and everything outside the GEMM family still computes in fp32)
             line["whole_step"]["frac_of_bf16_mfma_peak"] = round(tf / PEAK_BF16_MFMA_TFLOPS, 4)

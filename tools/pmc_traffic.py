@@ -13,6 +13,9 @@ import csv
 import glob
 import json
 import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 
 
 def last_step(dirname, counter, n):
@@ -27,7 +30,9 @@ def main():
     fetch_dir, write_dir, n = sys.argv[1], sys.argv[2], int(sys.argv[3])
     fetch_kib, nf = last_step(fetch_dir, "FETCH_SIZE", n)
     write_kib, nw = last_step(write_dir, "WRITE_SIZE", n)
+    from bench import kernel_source_hash  # the figure is only valid for the kernel sources it was measured on
     out = {
+        "kernel_source_hash": kernel_source_hash(),
         "launches": nf,
         "fetch_bytes_per_launch_raw": fetch_kib * 1024 / nf,
         "fetch_bytes_per_launch_corrected": 2 * fetch_kib * 1024 / nf,
