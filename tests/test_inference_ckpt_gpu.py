@@ -74,8 +74,12 @@ def test_checkpoint_round_trip(tmp_path):
         model.on_load_checkpoint(bad)
     with pytest.raises(TypeError):
         model.on_load_checkpoint(dict(ckpt, model_info={"name": "HiFiGAN", "version": "1.0"}))
-    with pytest.raises(NotImplementedError):  # pre-1.2: the embedding rows follow the old symbol order (not silently loaded)
-        model.on_load_checkpoint(dict(ckpt, model_info={"name": "FastSpeech2", "version": "1.1"}))
+    # pre-1.2: the embedding rows follow the old symbol order (8 hard-coded symbols first) and are moved
+    # (fs2/model.py:313-349; tests/test_cli_cpu.py checks the row mapping); this model's table lacks the hard-coded
+    # symbols, so the old table is larger than the new one and the reference's own assertion fires
+    with pytest.raises(AssertionError, match="embedding table"):
+        model.on_load_checkpoint(dict(ckpt, model_info={"name": "FastSpeech2", "version": "1.1"},
+                                      state_dict=dict(ckpt["state_dict"])))
 
 
 @pytest.mark.parametrize("mode", ["token", "style_reference"])
