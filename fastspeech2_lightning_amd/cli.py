@@ -115,6 +115,13 @@ def build_parser() -> argparse.ArgumentParser:
     tr.add_argument("--log-every", type=int, default=50)
     tr.add_argument("--seed", type=int, default=1234)
     tr.add_argument("--dry-run", action="store_true", help="resolve config, filelists, look-up tables and the run directory, print the plan, touch no GPU")
+    bm = sub.add_parser("benchmark", help="Time the forward pass on one batch of the training filelist (reference fs2/cli/benchmark.py)")
+    bm.add_argument("config_file", type=Path)
+    bm.add_argument("-c", "--config-args", action="append", default=[], metavar="KEY=VALUE")
+    bm.add_argument("--benchmark-type", choices=["training", "inference"], default="training")
+    bm.add_argument("--warmup-reps", type=int, default=10)
+    bm.add_argument("--repetitions", type=int, default=300)
+    bm.add_argument("--precision", default="32-true", choices=["32-true", "32-split", "bf16-mixed"])
     return ap
 
 
@@ -371,11 +378,52 @@ def train(args, argv) -> int:
     return 0
 
 
+def benchmark(args) -> int:
+    """reference ``fs2/cli/benchmark.py:14-80``: the first ``training.batch_size`` items of the training filelist,
+    collated; ``warmup_reps`` untimed forward passes, then ``repetitions`` timed ones (HIP events, one sync each);
+    prints mean and standard deviation in ms.  ``training`` = teacher-forced forward (targets in the batch),
+    ``inference`` = ``forward(inference=True)``."""
+    import numpy as np
+
+    from .config import Stats
+    from .data import FeatureDataset, collate
+    from .model import FastSpeech2
+
+    args.output_dir = args.resume = None
+    args.max_steps = args.max_epochs = None
+    p = plan(args)
+    config = p["config"]
+    model = FastSpeech2(config, Stats(**p["stats"]), p["lang2id"], p["speaker2id"], precision=args.precision)
+    model.eval()
+    ds = FeatureDataset(p["train_rows"], config, p["lang2id"], p["speaker2id"])
+    n = min(config.training.batch_size, len(ds))
+    batch = model.prepare_batch(collate([ds[i] for i in range(n)], learn_alignment=config.model.learn_alignment))
+    inference = args.benchmark_type == "inference"
+    if inference:
+        batch = {k: v for k, v in batch.items() if k not in ("mel", "mel_lens", "pitch", "energy", "duration")}
+        batch.update(mel=None, mel_lens=None, duration=None, max_mel_len=config.model.max_length)
+    for _ in range(args.warmup_reps):
+        model(batch, inference=inference)
+    timings = np.zeros(args.repetitions)
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for rep in range(args.repetitions):
+        start.record()
+        model(batch, inference=inference)
+        end.record()
+        torch.cuda.synchronize()
+        timings[rep] = start.elapsed_time(end)
+    print(f"Average forward pass for {args.benchmark_type} duration after {args.repetitions} repetitions: "
+          f"{timings.mean()} ms Standard Deviation: {timings.std()}")
+    return 0
+
+
 def main(argv: Optional[list] = None) -> int:
     argv = list(sys.argv[1:] if argv is None else argv)
     args = build_parser().parse_args(argv)
     if args.command == "train":
         return train(args, argv)
+    if args.command == "benchmark":
+        return benchmark(args)
     return 2
 
 

@@ -58,3 +58,14 @@ def test_train_save_resume_reproduces_the_next_steps(tmp_path):
     with pytest.raises(RuntimeError, match="no optimizer state"):
         cli.main(["train", str(cfg), "--output-dir", str(tmp_path / "c"), "--resume", str(tmp_path / "weights_only.ckpt"),
                   "--max-steps", "13", "--devices", "1"])
+
+
+@pytest.mark.parametrize("kind", ["training", "inference"])
+def test_fs2l_benchmark_times_the_forward_pass(tmp_path, capsys, kind):
+    """``fs2l benchmark`` (reference fs2/cli/benchmark.py): forward-only timing on a batch of the training filelist."""
+    cfg = make_project(tmp_path, n_train=6, n_val=2, write_features=True)
+    assert cli.main(["benchmark", str(cfg), "--benchmark-type", kind, "--warmup-reps", "2", "--repetitions", "5"]) == 0
+    out = capsys.readouterr().out
+    assert f"Average forward pass for {kind} duration after 5 repetitions:" in out and "Standard Deviation" in out
+    ms = float(out.split("repetitions:")[1].split("ms")[0])
+    assert 0.0 < ms < 1000.0
