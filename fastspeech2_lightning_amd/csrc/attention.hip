@@ -512,12 +512,13 @@ extern "C" int fs2hip_attention_fwd(const float* qkv, const int* lens, float* o,
   if (!attn_args_ok(qkv, B, T, H, HD) || ((uintptr_t)o % 16)) return FS2HIP_EINVAL;
   static const bool old_only = getenv("FS2_ATTN_GEN1") != nullptr;  // measurement aid: first-generation kernels everywhere
   if (!old_only && fs2_attn2_supported(HD, operand_bf16)) {
-    Attn2Args a2{qkv, lens, B, T, H, HD, 1.f / sqrtf((float)HD), fs2_make_drop(drop_p, drop_seed, drop_step), nullptr};
+    Attn2Args a2{qkv, lens, B, T, H, HD, 1.f / sqrtf((float)HD), fs2_make_drop(drop_p, drop_seed, drop_step),
+                 operand_bf16 == 2 ? 3 : operand_bf16, nullptr};
     return fs2_attn2_fwd(a2, o, lse, (hipStream_t)stream);
   }
   AttnP p{qkv, lens, B, T, H, 1.f / sqrtf((float)HD), fs2_make_drop(drop_p, drop_seed, drop_step)};
   dim3 grid((T + 63) / 64, H, B);
-  ATTN_DISPATCH(HD, operand_bf16, (attn_fwd_kernel<HDc, BFc><<<grid, dim3(256), 0, (hipStream_t)stream>>>(p, o, lse)));
+  ATTN_DISPATCH(HD, operand_bf16 == 1, (attn_fwd_kernel<HDc, BFc><<<grid, dim3(256), 0, (hipStream_t)stream>>>(p, o, lse)));
   FS2_LAUNCH_CHECK();
   return 0;
 }
@@ -531,16 +532,17 @@ extern "C" int fs2hip_attention_bwd(const float* qkv, const int* lens, const flo
   hipStream_t s = (hipStream_t)stream;
   static const bool old_only = getenv("FS2_ATTN_GEN1") != nullptr;
   if (!old_only && fs2_attn2_supported(HD, operand_bf16)) {
-    Attn2Args a2{qkv, lens, B, T, H, HD, 1.f / sqrtf((float)HD), fs2_make_drop(drop_p, drop_seed, drop_step), nullptr};
+    Attn2Args a2{qkv, lens, B, T, H, HD, 1.f / sqrtf((float)HD), fs2_make_drop(drop_p, drop_seed, drop_step),
+                 operand_bf16 == 2 ? 3 : operand_bf16, nullptr};
     return fs2_attn2_bwd(a2, o, dout, lse, delta, dqkv, s);
   }
   attn_delta_kernel<<<dim3((B * T + 3) / 4), dim3(256), 0, s>>>(dout, o, delta, B, T, H, HD);
   FS2_LAUNCH_CHECK();
   AttnP p{qkv, lens, B, T, H, 1.f / sqrtf((float)HD), fs2_make_drop(drop_p, drop_seed, drop_step)};
   dim3 grid((T + 63) / 64, H, B);
-  ATTN_DISPATCH(HD, operand_bf16, (attn_bwd_dq_kernel<HDc, BFc><<<grid, dim3(256), 0, s>>>(p, dout, lse, delta, dqkv)));
+  ATTN_DISPATCH(HD, operand_bf16 == 1, (attn_bwd_dq_kernel<HDc, BFc><<<grid, dim3(256), 0, s>>>(p, dout, lse, delta, dqkv)));
   FS2_LAUNCH_CHECK();
-  ATTN_DISPATCH(HD, operand_bf16, (attn_bwd_dkv_kernel<HDc, BFc><<<grid, dim3(256), 0, s>>>(p, dout, lse, delta, dqkv)));
+  ATTN_DISPATCH(HD, operand_bf16 == 1, (attn_bwd_dkv_kernel<HDc, BFc><<<grid, dim3(256), 0, s>>>(p, dout, lse, delta, dqkv)));
   FS2_LAUNCH_CHECK();
   return 0;
 }

@@ -8,10 +8,11 @@ struct Attn2Args {
   int B, T, H, HD;
   float scale;        // 1/sqrt(HD)
   Fs2Drop drop;       // dropout on the attention probabilities, element index ((b*H + h)*T + q)*Tp + key, Tp = T rounded up to even
+  int planes;         // 0: fp32 MFMA.  1: operands rounded to bf16 ("bf16-mixed").  3: three exact bf16 planes ("32-split")
   long long* stamps;  // diagnostic builds only (-DFS2_ATTN_STAMPS, tools/probes/attn2_probe.hip): per-phase cycle sums
 };
 
-// true when the second-generation kernels take the shape (fp32 operands, HD in {64, 128})
+// true when the second-generation kernels take the shape (HD in {64, 128}; operand_bf16: 0 fp32, 1 bf16, 2 split)
 bool fs2_attn2_supported(int HD, int operand_bf16);
 int fs2_attn2_fwd(const Attn2Args& a, float* o, float* lse, hipStream_t s);
 int fs2_attn2_bwd(const Attn2Args& a, const float* o, const float* dout, const float* lse, float* delta, float* dqkv,

@@ -267,6 +267,143 @@ __device__ __forceinline__ void acc_cols_pipelined(const ColRd& cr, unsigned til
   });
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Operand modes on the bf16 matrix pipe (template parameter PL = number of bf16 planes per operand value):
+//   PL = 1  "bf16-mixed": values rounded to bf16 (RNE), one v_mfma_f32_32x32x16_bf16 per 16 reduction steps
+//   PL = 3  "32-split"  : values cut exactly into three bf16 planes, six partial products per product (gemm2_core.h)
+// Both take operands from the same fp32 LDS images as the fp32 kernels; the MFMA's C/D layout is the 32x32 one, so
+// everything downstream of an accumulator (softmax, masks, stores) is shared.  Unlike fp32 MFMAs these run BESIDE
+// the vector ALUs, so the softmax / dropout / cut arithmetic overlaps them instead of adding to them.
+// ------------------------------------------------------------------------------------------------------------
+template <int PL>
+struct Pl {
+  bf16x8 p[PL];
+};
+template <int PL>
+__device__ __forceinline__ Pl<PL> make_planes(const float (&x)[8]) {
+  Pl<PL> r;
+  if constexpr (PL == 1) {
+    const f32x8 v = {x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]};
+    r.p[0] = __builtin_convertvector(v, bf16x8);
+  } else {
+    u32x4 q0, q1, q2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      unsigned a0, a1, a2;
+      split_pair(x[2 * e], x[2 * e + 1], a0, a1, a2);
+      q0[e] = a0; q1[e] = a1; q2[e] = a2;
+    }
+    r.p[0] = __builtin_bit_cast(bf16x8, q0);
+    r.p[1] = __builtin_bit_cast(bf16x8, q1);
+    r.p[2] = __builtin_bit_cast(bf16x8, q2);
+  }
+  return r;
+}
+template <int PL>
+__device__ __forceinline__ Pl<PL> make_planes(const f32x4& lo, const f32x4& hi) {
+  const float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return make_planes<PL>(x);
+}
+template <int PL>
+__device__ __forceinline__ f32x16 mfma_planes(const Pl<PL>& a, const Pl<PL>& b, f32x16 c) {
+  if constexpr (PL == 1) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[0], c, 0, 0, 0);
+  } else {  // smallest partial products first
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[2], b.p[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[1], b.p[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[1], b.p[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[1], c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[0], c, 0, 0, 0);
+  }
+}
+
+// this lane's own row for the bf16 products: step s covers k = 16 s + 8 hi + 0..7; load(j4) returns the four values
+// k = 4 j4 .. 4 j4 + 3 of the row
+template <int HD, int PL, class Ld>
+__device__ __forceinline__ void own_planes(Pl<PL> (&own)[HD / 16], int hi, Ld&& load) {
+#pragma unroll
+  for (int s_ = 0; s_ < HD / 16; ++s_) own[s_] = make_planes<PL>(load(4 * s_ + 2 * hi), load(4 * s_ + 2 * hi + 1));
+}
+
+// acc^T[32 tile rows][32 own] = sum_k tile[row][k] * own[k] on the bf16 pipe: per 16 reduction steps two
+// ds_read_b128 (chunks 4s + 2hi, + 1 of the lane's tile row), the cut / rounding, and PL (PL + 1) / 2 ... MFMAs
+template <int HD, int PL, class Hook = NoHook>
+__device__ __forceinline__ f32x16 dot_rows_pl(int row, int hi, unsigned tile_base, const Pl<PL> (&own)[HD / 16], Hook&& hook = Hook()) {
+  constexpr int NS = HD / 16;
+  const unsigned base = tile_base + row * HD * 4, sw = (unsigned)(row & 15) << 4;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  f32x4 a[3][2];
+  auto rd = [&](int s_, f32x4 (&dst)[2]) {
+    lds_rd128<0>(dst[0], base + ((((unsigned)(4 * s_ + 2 * hi)) << 4) ^ sw));
+    lds_rd128<0>(dst[1], base + ((((unsigned)(4 * s_ + 2 * hi + 1)) << 4) ^ sw));
+  };
+  rd(0, a[0]);
+  if constexpr (NS > 1) rd(1, a[1]);
+  sfor<NS>([&](auto sc) {
+    constexpr int s_ = decltype(sc)::value;
+    if constexpr (s_ + 2 < NS) {
+      rd(s_ + 2, a[(s_ + 2) % 3]);
+      lds_wait<4>();
+    } else if constexpr (s_ + 1 < NS) {
+      lds_wait<2>();
+    } else {
+      lds_wait<0>();
+    }
+    pin(a[s_ % 3][0]);
+    pin(a[s_ % 3][1]);
+    acc = mfma_planes<PL>(make_planes<PL>(a[s_ % 3][0], a[s_ % 3][1]), own[s_], acc);
+    hook(sc);
+  });
+  return acc;
+}
+
+// acc[k]^T[d][own] += sum over the tile's 32 rows tile_k[row][d] * w_k[row][own] on the bf16 pipe, for NW (tile,
+// weight) sets at once (forward: P.V; dQ: K.dS; dK/dV: dO.P and Q.dS).  Two 16-row steps; the eight weights of a step
+// are S-layout registers 8 s .. 8 s + 7 (rows 16 s + 8 (e >> 2) + 4 hi + (e & 3)), made by weight(t, w[NW]) right
+// before; a tile operand is eight ds_read_b32 per d-block and step, read one MFMA group ahead.
+template <int HD, int PL, int NW, class Wf>
+__device__ __forceinline__ void acc_cols_pl(const ColRd& cr, const unsigned (&tile)[NW], f32x16 (&acc)[NW][HD / 32], Wf&& weight) {
+  constexpr int NDB = HD / 32, PER = NW * NDB, N = 2 * PER;
+  float v[2][8];
+  auto rd = [&](auto nc, float (&dst)[8]) {
+    constexpr int n = decltype(nc)::value, s_ = n / PER, k = (n % PER) / NDB, db = n % NDB;
+    sfor<8>([&](auto ec) {
+      constexpr int t = 8 * s_ + decltype(ec)::value;
+      lds_rd32<col_off<HD, t, db>()>(dst[decltype(ec)::value], tile[k] + cr.base[t & 3]);
+    });
+  };
+  rd(std::integral_constant<int, 0>{}, v[0]);
+  sfor<2>([&](auto sc) {
+    constexpr int s_ = decltype(sc)::value;
+    float w[NW][8];
+    sfor<8>([&](auto ec) {
+      constexpr int e = decltype(ec)::value;
+      float one[NW];
+      weight(std::integral_constant<int, 8 * s_ + e>{}, one);
+#pragma unroll
+      for (int k = 0; k < NW; ++k) w[k][e] = one[k];
+    });
+    Pl<PL> wp[NW];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) wp[k] = make_planes<PL>(w[k]);
+    sfor<PER>([&](auto uc) {
+      constexpr int u = decltype(uc)::value, n = s_ * PER + u, k = u / NDB, db = u % NDB;
+      if constexpr (n + 1 < N) {
+        rd(std::integral_constant<int, n + 1>{}, v[(n + 1) & 1]);
+        lds_wait<8>();
+      } else {
+        lds_wait<0>();
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pin(v[n & 1][e]);
+      acc[k][db] = mfma_planes<PL>(make_planes<PL>(v[n & 1]), wp[k], acc[k][db]);
+    });
+  });
+}
+
 // max / sum over the lane pair (l, l ^ 32) -- the two halves of a row's 32 keys -- with v_permlane32_swap (vector
 // pipe; ds_bpermute would be an LDS round trip in the one stretch of the tile that is not under MFMAs)
 __device__ __forceinline__ float pair_max(float x) {
@@ -383,7 +520,7 @@ __device__ __forceinline__ void work_unit(const Attn2Args& p, int nblk, int& blk
 // -> the next V tile's DMA starts and lands under K.Q^T + softmax) and barrier Y (start of P.V; everybody is done
 // with the K tile -> the next K tile's DMA starts and lands under P.V).
 // ------------------------------------------------------------------------------------------------------------
-template <int HD, bool DROP>
+template <int HD, bool DROP, int PL>
 __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(Attn2Args p, float* __restrict__ o, float* __restrict__ lse) {
   constexpr int NJ = HD / 8, NDB = HD / 32;
   // K tile, V tile of key group 0; then of group 1: 64 KB, two workgroups per CU.  (fp32 MFMAs and fp32 vector
@@ -413,18 +550,25 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(Attn2Args p, float* _
   float* Kt = smem + kg * 2 * KT * HD;
   float* Vt = Kt + KT * HD;
   dma.issue(rk, Kt, tile0 * KT, T, ld, rb);
-  f32x4 qv[NJ];
+  const float qscale = p.scale * 1.44269504088896f;  // scores in log2 units: the exponentials are bare v_exp_f32
+  f32x4 qv[PL == 0 ? NJ : 1];
+  Pl<(PL == 0 ? 1 : PL)> qp[HD / 16];
+  if constexpr (PL == 0) {
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (q < T) v = *reinterpret_cast<const f32x4*>(base + (long long)q * ld + h * HD + 8 * j + 4 * hi);
-#ifdef FS2_FWD_OWN_AGPR
-    qv[j] = to_agpr(v * (p.scale * 1.44269504088896f));
-#else
-    qv[j] = v * (p.scale * 1.44269504088896f);  // scores in log2 units: the exponentials are bare v_exp_f32
-#endif
+    for (int j = 0; j < NJ; ++j) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (q < T) v = *reinterpret_cast<const f32x4*>(base + (long long)q * ld + h * HD + 8 * j + 4 * hi);
+      qv[j] = v * qscale;
+    }
+  } else {
+    own_planes<HD, PL>(qp, hi, [&](int j4) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (q < T) v = *reinterpret_cast<const f32x4*>(base + (long long)q * ld + h * HD + 4 * j4);
+      return v * qscale;
+    });
   }
-  f32x16 oacc[NDB];
+  f32x16 oacc_[1][NDB];
+  auto& oacc = oacc_[0];
 #pragma unroll
   for (int d = 0; d < NDB; ++d)
 #pragma unroll
@@ -446,14 +590,12 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(Attn2Args p, float* _
     STAMP(1)  // wait at X
     f32x16 s;
     if (act) {
-#ifdef FS2_FWD_OWN_AGPR
-      s = dot_rows<HD, true>(rd, ks, qv, [&](auto jc) {
-#else
-      s = dot_rows<HD>(rd, ks, qv, [&](auto jc) {  // the V tile's DMA, piece by piece under the MFMAs
-#endif
+      auto vdma = [&](auto jc) {  // the V tile's DMA, piece by piece under the MFMAs
         constexpr int it = decltype(jc)::value;
         if constexpr (it < TileDma<HD, 128>::NP) dma.template piece<it>(rv, Vt, key0, T, ld, rb);
-      });
+      };
+      if constexpr (PL == 0) s = dot_rows<HD>(rd, ks, qv, vdma);
+      else s = dot_rows_pl<HD, PL>(l32, hi, ks, qp, vdma);
     }
     STAMP(2)  // K.Q^T
     float mnew = m, alpha = 1.f;
@@ -485,7 +627,8 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(Attn2Args p, float* _
       if (actn) dma.issue(rk, Kt, key0 + KT, T, ld, rb);
       STAMP(6)
       SoftmaxWeights<DROP> wt(s, mnew - lg_dscale, ph, (rowidx + (uint32_t)(key0 + 4 * hi)) >> 1);
-      acc_cols_pipelined<HD>(cr, vs, oacc, wt);
+      if constexpr (PL == 0) acc_cols_pipelined<HD>(cr, vs, oacc, wt);
+      else acc_cols_pl<HD, PL, 1>(cr, {vs}, oacc_, [&](auto tc, float (&w1)[1]) { w1[0] = wt.template weight<decltype(tc)::value>(); });
       l = l * alpha + pair_sum(wt.rs);  // (sum of the UNdropped probabilities, times the dropout scale)
       m = mnew;
     }
@@ -584,7 +727,7 @@ __device__ __forceinline__ void read_mfma_stream(Rd&& rd, Mf&& mf) {
 }
 
 // dQ: own = 32 queries per wavefront (Q' = Q * scale * log2e and dO in registers), tiles = keys (K and V)
-template <int HD, bool DROP>
+template <int HD, bool DROP, int PL>
 __global__ __launch_bounds__(256, 1) void attn2_bwd_dq_kernel(Attn2Args p, const float* __restrict__ dout,
                                                               const float2* __restrict__ aux, float* __restrict__ dqkv) {
   constexpr int NJ = HD / 8, NDB = HD / 32, TILE = KT * HD, NP = TileDma<HD, 128>::NP;
@@ -610,21 +753,37 @@ __global__ __launch_bounds__(256, 1) void attn2_bwd_dq_kernel(Attn2Args p, const
     dma.issue(rk, gbuf, tile0 * KT, T, ld, rb);
     dma.issue(rv, gbuf + TILE, tile0 * KT, T, ld, rb);
   }
-  f32x4 qv[NJ], dov[NJ];
+  const float qscale = p.scale * 1.44269504088896f;
+  f32x4 qv[PL == 0 ? NJ : 1], dov[PL == 0 ? NJ : 1];
+  Pl<(PL == 0 ? 1 : PL)> qp[HD / 16], dop[HD / 16];
+  if constexpr (PL == 0) {
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f}, w = {0.f, 0.f, 0.f, 0.f};
-    if (q < T) {
-      v = *reinterpret_cast<const f32x4*>(base + (long long)q * ld + h * HD + 8 * j + 4 * hi);
-      w = *reinterpret_cast<const f32x4*>(dout + ((long long)b * T + q) * D + h * HD + 8 * j + 4 * hi);
+    for (int j = 0; j < NJ; ++j) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f}, w = {0.f, 0.f, 0.f, 0.f};
+      if (q < T) {
+        v = *reinterpret_cast<const f32x4*>(base + (long long)q * ld + h * HD + 8 * j + 4 * hi);
+        w = *reinterpret_cast<const f32x4*>(dout + ((long long)b * T + q) * D + h * HD + 8 * j + 4 * hi);
+      }
+      qv[j] = to_agpr(v * qscale);
+      dov[j] = to_agpr(w);
     }
-    qv[j] = to_agpr(v * (p.scale * 1.44269504088896f));
-    dov[j] = to_agpr(w);
+  } else {
+    own_planes<HD, PL>(qp, hi, [&](int j4) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (q < T) v = *reinterpret_cast<const f32x4*>(base + (long long)q * ld + h * HD + 4 * j4);
+      return v * qscale;
+    });
+    own_planes<HD, PL>(dop, hi, [&](int j4) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (q < T) v = *reinterpret_cast<const f32x4*>(dout + ((long long)b * T + q) * D + h * HD + 4 * j4);
+      return v;
+    });
   }
   float2 ax = make_float2(INFINITY, 0.f);  // (rows past T: p = 2^(s - inf) = 0)
   if (q < T) ax = aux[((long long)b * p.H + h) * T + q];
   const float lse2 = ax.x, deltap = ax.y;
-  f32x16 dq[NDB];
+  f32x16 dq_[1][NDB];
+  auto& dq = dq_[0];
 #pragma unroll
   for (int d = 0; d < NDB; ++d)
 #pragma unroll
@@ -646,19 +805,24 @@ __global__ __launch_bounds__(256, 1) void attn2_bwd_dq_kernel(Attn2Args p, const
     if (!act) continue;
     const unsigned kb = g0 + st * 2 * TILE * 4, vb = kb + TILE * 4;
     float* nxt = gbuf + (st ^ 1) * 2 * TILE;
-    f32x16 s = dot_rows<HD, true>(rd, kb, qv, [&](auto jc) {
+    auto kdma = [&](auto jc) {
       constexpr int it = decltype(jc)::value;
       if constexpr (it < NP) {
         if (actn) dma.template piece<it>(rk, nxt, key0 + KT, T, ld, rb);
       }
-    });
-    STAMP(2)
-    f32x16 dp = dot_rows<HD, true>(rd, vb, dov, [&](auto jc) {
+    };
+    auto vdma = [&](auto jc) {
       constexpr int it = decltype(jc)::value;
       if constexpr (it < NP) {
         if (actn) dma.template piece<it>(rv, nxt + TILE, key0 + KT, T, ld, rb);
       }
-    });
+    };
+    f32x16 s, dp;
+    if constexpr (PL == 0) s = dot_rows<HD, true>(rd, kb, qv, kdma);
+    else s = dot_rows_pl<HD, PL>(l32, hi, kb, qp, kdma);
+    STAMP(2)
+    if constexpr (PL == 0) dp = dot_rows<HD, true>(rd, vb, dov, vdma);
+    else dp = dot_rows_pl<HD, PL>(l32, hi, vb, dop, vdma);
     STAMP(3)
     if (key0 + KT > len) {
 #pragma unroll
@@ -679,18 +843,23 @@ __global__ __launch_bounds__(256, 1) void attn2_bwd_dq_kernel(Attn2Args p, const
       }
       return fmaf(-pp, deltap, pd * dp[t]);
     };
-    w = weight(std::integral_constant<int, 0>{});
-    STAMP(4)
-    read_mfma_stream<16 * NDB, 8>(
-        [&](auto ic, float& dst) {
-          constexpr int i = decltype(ic)::value, t = i / NDB, db = i % NDB;
-          lds_rd32<col_off<HD, t, db>()>(dst, kb + cr.base[t & 3]);
-        },
-        [&](auto ic, float v) {
-          constexpr int i = decltype(ic)::value, t = i / NDB, db = i % NDB;
-          mfma32_agpr(dq[db], v, w);
-          if constexpr (db == NDB - 1 && t + 1 < 16) w = weight(std::integral_constant<int, t + 1>{});
-        });
+    if constexpr (PL == 0) {
+      w = weight(std::integral_constant<int, 0>{});
+      STAMP(4)
+      read_mfma_stream<16 * NDB, 8>(
+          [&](auto ic, float& dst) {
+            constexpr int i = decltype(ic)::value, t = i / NDB, db = i % NDB;
+            lds_rd32<col_off<HD, t, db>()>(dst, kb + cr.base[t & 3]);
+          },
+          [&](auto ic, float v) {
+            constexpr int i = decltype(ic)::value, t = i / NDB, db = i % NDB;
+            mfma32_agpr(dq[db], v, w);
+            if constexpr (db == NDB - 1 && t + 1 < 16) w = weight(std::integral_constant<int, t + 1>{});
+          });
+    } else {
+      STAMP(4)
+      acc_cols_pl<HD, PL, 1>(cr, {kb}, dq_, [&](auto tc, float (&w1)[1]) { w1[0] = weight(tc); });
+    }
     STAMP(5)
   }
   STAMP_FLUSH(p.stamps, blockIdx.x)
@@ -721,7 +890,7 @@ __global__ __launch_bounds__(256, 1) void attn2_bwd_dq_kernel(Attn2Args p, const
 
 // dK, dV: own = 32 keys per wavefront (K' = K * scale * log2e and V in registers), tiles = queries (Q, dO rows and
 // their {lse', delta'} pairs)
-template <int HD, bool DROP>
+template <int HD, bool DROP, int PL>
 __global__ __launch_bounds__(256, 1) void attn2_bwd_dkv_kernel(Attn2Args p, const float* __restrict__ dout,
                                                                const float2* __restrict__ aux, float* __restrict__ dqkv) {
   constexpr int NJ = HD / 8, NDB = HD / 32, TILE = KT * HD, NP = TileDma<HD, 128>::NP, STAGE = 2 * TILE + 256;
@@ -773,18 +942,35 @@ __global__ __launch_bounds__(256, 1) void attn2_bwd_dkv_kernel(Attn2Args p, cons
     dmao.issue(rdo, gbuf + TILE, tile0 * KT, T, D, rb);
     issue_aux(gbuf, tile0 * KT);
   }
-  f32x4 kv[NJ], vv[NJ];
+  const float kscale = p.scale * 1.44269504088896f;
+  f32x4 kv[PL == 0 ? NJ : 1], vv[PL == 0 ? NJ : 1];
+  Pl<(PL == 0 ? 1 : PL)> kp[HD / 16], vp[HD / 16];
+  if constexpr (PL == 0) {
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f}, w = {0.f, 0.f, 0.f, 0.f};
-    if (key < T) {
-      v = *reinterpret_cast<const f32x4*>(base + (long long)key * ld + D + h * HD + 8 * j + 4 * hi);
-      w = *reinterpret_cast<const f32x4*>(base + (long long)key * ld + 2 * D + h * HD + 8 * j + 4 * hi);
+    for (int j = 0; j < NJ; ++j) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f}, w = {0.f, 0.f, 0.f, 0.f};
+      if (key < T) {
+        v = *reinterpret_cast<const f32x4*>(base + (long long)key * ld + D + h * HD + 8 * j + 4 * hi);
+        w = *reinterpret_cast<const f32x4*>(base + (long long)key * ld + 2 * D + h * HD + 8 * j + 4 * hi);
+      }
+      kv[j] = to_agpr(v * kscale);
+      vv[j] = to_agpr(w);
     }
-    kv[j] = to_agpr(v * (p.scale * 1.44269504088896f));
-    vv[j] = to_agpr(w);
+  } else {
+    own_planes<HD, PL>(kp, hi, [&](int j4) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (key < T) v = *reinterpret_cast<const f32x4*>(base + (long long)key * ld + D + h * HD + 4 * j4);
+      return v * kscale;
+    });
+    own_planes<HD, PL>(vp, hi, [&](int j4) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (key < T) v = *reinterpret_cast<const f32x4*>(base + (long long)key * ld + 2 * D + h * HD + 4 * j4);
+      return v;
+    });
   }
-  f32x16 dk[NDB], dv[NDB];
+  f32x16 g_[2][NDB];  // [0]: dV, [1]: dK
+  auto& dv = g_[0];
+  auto& dk = g_[1];
 #pragma unroll
   for (int d = 0; d < NDB; ++d)
 #pragma unroll
@@ -814,19 +1000,24 @@ __global__ __launch_bounds__(256, 1) void attn2_bwd_dkv_kernel(Attn2Args p, cons
     float* nxt = gbuf + (st ^ 1) * STAGE;
     const unsigned ab_hi = ab + 4 * hi * 8;  // {lse', delta'} of tile row 8a + 4hi + r: broadcast ds_read_b64 at (8a + r) * 8
     if (actn) issue_aux(nxt, q0 + KT);
-    f32x16 s = dot_rows<HD, true>(rd, qb_, kv, [&](auto jc) {
+    auto qdma = [&](auto jc) {
       constexpr int it = decltype(jc)::value;
       if constexpr (it < NP) {
         if (actn) dmaq.template piece<it>(rq, nxt, q0 + KT, T, ld, rb);
       }
-    });
-    STAMP(2)
-    f32x16 dp = dot_rows<HD, true>(rd, ob, vv, [&](auto jc) {
+    };
+    auto odma = [&](auto jc) {
       constexpr int it = decltype(jc)::value;
       if constexpr (it < NP) {
         if (actn) dmao.template piece<it>(rdo, nxt + TILE, q0 + KT, T, D, rb);
       }
-    });
+    };
+    f32x16 s, dp;
+    if constexpr (PL == 0) s = dot_rows<HD, true>(rd, qb_, kv, qdma);
+    else s = dot_rows_pl<HD, PL>(l32, hi, qb_, kp, qdma);
+    STAMP(2)
+    if constexpr (PL == 0) dp = dot_rows<HD, true>(rd, ob, vv, odma);
+    else dp = dot_rows_pl<HD, PL>(l32, hi, ob, vp, odma);
     STAMP(3)
     const uint32_t rowkey = head0 + (uint32_t)(q0 + 4 * hi) * Tp + (uint32_t)key;  // element index of (row q0 + 4hi, own key)
     float wv = 0.f, wk = 0.f;
@@ -848,31 +1039,57 @@ __global__ __launch_bounds__(256, 1) void attn2_bwd_dkv_kernel(Attn2Args p, cons
       wv = pd;
       wk = fmaf(-pp, axs[t & 1].y, pd * dp[t]);
     };
-    aux_read(std::integral_constant<int, 0>{});
-    aux_read(std::integral_constant<int, 1>{});
-    lds_wait<1>();
-    weights(std::integral_constant<int, 0>{});
-    float wv_c = wv, wk_c = wk;
-    STAMP(4)
-    // per step 2 NDB MFMAs: dv^T[d][key] += dO[q][d] * pd[q][key], dk^T[d][key] += Q[q][d] * dS[q][key].  The aux pair
-    // of step t + 2 is read behind the last MFMA of step t: by the time weights(t + 2) runs, the stream's own waits
-    // (at most 7 younger reads outstanding before every MFMA) have long covered it.
-    read_mfma_stream<32 * NDB, 8>(
-        [&](auto ic, float& dst) {
-          constexpr int i = decltype(ic)::value, t = i / (2 * NDB), u = i % (2 * NDB), db = u % NDB;
-          lds_rd32<col_off<HD, t, db>()>(dst, (u < NDB ? ob : qb_) + cr.base[t & 3]);
-        },
-        [&](auto ic, float v) {
-          constexpr int i = decltype(ic)::value, t = i / (2 * NDB), u = i % (2 * NDB), db = u % NDB;
-          if constexpr (u < NDB) mfma32_agpr(dv[db], v, wv_c);
-          else mfma32_agpr(dk[db], v, wk_c);
-          if constexpr (u == 2 * NDB - 1 && t + 1 < 16) {
-            weights(std::integral_constant<int, t + 1>{});
-            wv_c = wv;
-            wk_c = wk;
-            if constexpr (t + 2 < 16) aux_read(std::integral_constant<int, t + 2>{});
-          }
-        });
+    if constexpr (PL == 0) {
+      aux_read(std::integral_constant<int, 0>{});
+      aux_read(std::integral_constant<int, 1>{});
+      lds_wait<1>();
+      weights(std::integral_constant<int, 0>{});
+      float wv_c = wv, wk_c = wk;
+      STAMP(4)
+      // per step 2 NDB MFMAs: dv^T[d][key] += dO[q][d] * pd[q][key], dk^T[d][key] += Q[q][d] * dS[q][key].  The aux pair
+      // of step t + 2 is read behind the last MFMA of step t: by the time weights(t + 2) runs, the stream's own waits
+      // (at most 7 younger reads outstanding before every MFMA) have long covered it.
+      read_mfma_stream<32 * NDB, 8>(
+          [&](auto ic, float& dst) {
+            constexpr int i = decltype(ic)::value, t = i / (2 * NDB), u = i % (2 * NDB), db = u % NDB;
+            lds_rd32<col_off<HD, t, db>()>(dst, (u < NDB ? ob : qb_) + cr.base[t & 3]);
+          },
+          [&](auto ic, float v) {
+            constexpr int i = decltype(ic)::value, t = i / (2 * NDB), u = i % (2 * NDB), db = u % NDB;
+            if constexpr (u < NDB) mfma32_agpr(dv[db], v, wv_c);
+            else mfma32_agpr(dk[db], v, wk_c);
+            if constexpr (u == 2 * NDB - 1 && t + 1 < 16) {
+              weights(std::integral_constant<int, t + 1>{});
+              wv_c = wv;
+              wk_c = wk;
+              if constexpr (t + 2 < 16) aux_read(std::integral_constant<int, t + 2>{});
+            }
+          });
+    } else {
+      // the eight {lse', delta'} pairs of a 16-row step are read (one wait) right before the step's weights
+      float2 axa[8];
+      STAMP(4)
+      acc_cols_pl<HD, PL, 2>(cr, {ob, qb_}, g_, [&](auto tc, float (&w2)[2]) {
+        constexpr int t = decltype(tc)::value;
+        if constexpr ((t & 7) == 0) {
+          sfor<8>([&](auto ec) {
+            constexpr int u = t + decltype(ec)::value;
+            lds_rd64<(8 * (u >> 2) + (u & 3)) * 8>(axa[u & 7], ab_hi);
+          });
+          lds_wait<0>();
+        }
+        pin(axa[t & 7]);
+        const float pp = key_ok ? __builtin_amdgcn_exp2f(s[t] - axa[t & 7].x) : 0.f;
+        float pd = pp;
+        if constexpr (DROP) {
+          const uint32_t idx = rowkey + (uint32_t)(8 * (t >> 2) + (t & 3)) * Tp;
+          const uint32_t hh = ph.hash(idx >> 1);
+          pd = ((hh >> sh16) & 0xffffu) >= ph.thresh ? pp : 0.f;
+        }
+        w2[0] = pd;
+        w2[1] = fmaf(-pp, axa[t & 7].y, pd * dp[t]);
+      });
+    }
     STAMP(5)
   }
   STAMP_FLUSH(p.stamps, blockIdx.x)
@@ -909,18 +1126,21 @@ __global__ __launch_bounds__(256, 1) void attn2_bwd_dkv_kernel(Attn2Args p, cons
 
 }  // namespace
 
-bool fs2_attn2_supported(int HD, int operand_bf16) { return !operand_bf16 && (HD == 64 || HD == 128); }
+bool fs2_attn2_supported(int HD, int operand_bf16) { return (operand_bf16 >= 0 && operand_bf16 <= 2) && (HD == 64 || HD == 128); }
 
 int fs2_attn2_fwd(const Attn2Args& a, float* o, float* lse, hipStream_t s) {
   if ((double)a.B * a.H * a.T * a.T >= 4294967296.0) return FS2HIP_EINVAL;  // 32-bit dropout element index
   dim3 grid(((a.T + 63) / 64) * a.H * a.B);
+#define FS2_ATTN2_FWD(HD_, DROP_)                                                                 \
+  if (a.planes == 3) attn2_fwd_kernel<HD_, DROP_, 3><<<grid, dim3(256), 0, s>>>(a, o, lse);         \
+  else if (a.planes == 1) attn2_fwd_kernel<HD_, DROP_, 1><<<grid, dim3(256), 0, s>>>(a, o, lse);    \
+  else attn2_fwd_kernel<HD_, DROP_, 0><<<grid, dim3(256), 0, s>>>(a, o, lse);
   if (a.HD == 128) {
-    if (a.drop.on) attn2_fwd_kernel<128, true><<<grid, dim3(256), 0, s>>>(a, o, lse);
-    else attn2_fwd_kernel<128, false><<<grid, dim3(256), 0, s>>>(a, o, lse);
+    if (a.drop.on) { FS2_ATTN2_FWD(128, true) } else { FS2_ATTN2_FWD(128, false) }
   } else {
-    if (a.drop.on) attn2_fwd_kernel<64, true><<<grid, dim3(256), 0, s>>>(a, o, lse);
-    else attn2_fwd_kernel<64, false><<<grid, dim3(256), 0, s>>>(a, o, lse);
+    if (a.drop.on) { FS2_ATTN2_FWD(64, true) } else { FS2_ATTN2_FWD(64, false) }
   }
+#undef FS2_ATTN2_FWD
   FS2_LAUNCH_CHECK();
   return 0;
 }
@@ -936,15 +1156,23 @@ int fs2_attn2_bwd(const Attn2Args& a, const float* o, const float* dout, const f
   FS2_LAUNCH_CHECK();
   dim3 grid(((a.T + 63) / 64) * a.H * a.B);
   const float2* ax = reinterpret_cast<const float2*>(aux);
-#define FS2_ATTN2_BWD(HD_, DROP_)                                                        \
-  attn2_bwd_dq_kernel<HD_, DROP_><<<grid, dim3(256), 0, s>>>(a, dout, ax, dqkv);         \
-  FS2_LAUNCH_CHECK();                                                                    \
-  attn2_bwd_dkv_kernel<HD_, DROP_><<<grid, dim3(256), 0, s>>>(a, dout, ax, dqkv);
+// "32-split": dQ on the bf16 pipe (237 vs 277 us at the decoder's shape), dK/dV stays on the fp32 MFMAs -- with one
+// wavefront per SIMD its cut arithmetic (two gradient tiles per step) is not hidden and the split version is slower
+// (430 vs 340 us).  "bf16-mixed": everything on the bf16 pipe.
+#define FS2_ATTN2_BWD_PL(HD_, DROP_, PQ_, PKV_)                                                \
+  attn2_bwd_dq_kernel<HD_, DROP_, PQ_><<<grid, dim3(256), 0, s>>>(a, dout, ax, dqkv);          \
+  FS2_LAUNCH_CHECK();                                                                          \
+  attn2_bwd_dkv_kernel<HD_, DROP_, PKV_><<<grid, dim3(256), 0, s>>>(a, dout, ax, dqkv);
+#define FS2_ATTN2_BWD(HD_, DROP_)                                     \
+  if (a.planes == 3) { FS2_ATTN2_BWD_PL(HD_, DROP_, 3, 0) }           \
+  else if (a.planes == 1) { FS2_ATTN2_BWD_PL(HD_, DROP_, 1, 1) }      \
+  else { FS2_ATTN2_BWD_PL(HD_, DROP_, 0, 0) }
   if (a.HD == 128) {
     if (a.drop.on) { FS2_ATTN2_BWD(128, true) } else { FS2_ATTN2_BWD(128, false) }
   } else {
     if (a.drop.on) { FS2_ATTN2_BWD(64, true) } else { FS2_ATTN2_BWD(64, false) }
   }
+#undef FS2_ATTN2_BWD_PL
 #undef FS2_ATTN2_BWD
   FS2_LAUNCH_CHECK();
   return 0;
@@ -955,13 +1183,16 @@ int fs2_attn2_bwd(const Attn2Args& a, const float* o, const float* dout, const f
 int fs2_attn2_bwd_one(const Attn2Args& a, const float* dout, const float* aux, float* dqkv, int which, hipStream_t s) {
   dim3 grid(((a.T + 63) / 64) * a.H * a.B);
   const float2* ax = reinterpret_cast<const float2*>(aux);
+#define FS2_ONE(K_, DROP_, P3_)                                                               \
+  if (a.planes == 3) K_<128, DROP_, P3_><<<grid, dim3(256), 0, s>>>(a, dout, ax, dqkv);         \
+  else if (a.planes == 1) K_<128, DROP_, 1><<<grid, dim3(256), 0, s>>>(a, dout, ax, dqkv);      \
+  else K_<128, DROP_, 0><<<grid, dim3(256), 0, s>>>(a, dout, ax, dqkv);
   if (which == 0) {
-    if (a.drop.on) attn2_bwd_dq_kernel<128, true><<<grid, dim3(256), 0, s>>>(a, dout, ax, dqkv);
-    else attn2_bwd_dq_kernel<128, false><<<grid, dim3(256), 0, s>>>(a, dout, ax, dqkv);
+    if (a.drop.on) { FS2_ONE(attn2_bwd_dq_kernel, true, 3) } else { FS2_ONE(attn2_bwd_dq_kernel, false, 3) }
   } else {
-    if (a.drop.on) attn2_bwd_dkv_kernel<128, true><<<grid, dim3(256), 0, s>>>(a, dout, ax, dqkv);
-    else attn2_bwd_dkv_kernel<128, false><<<grid, dim3(256), 0, s>>>(a, dout, ax, dqkv);
+    if (a.drop.on) { FS2_ONE(attn2_bwd_dkv_kernel, true, 0) } else { FS2_ONE(attn2_bwd_dkv_kernel, false, 0) }
   }
+#undef FS2_ONE
   return 0;
 }
 #endif

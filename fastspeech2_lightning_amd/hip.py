@@ -653,7 +653,7 @@ def attention_fwd(qkv, lens, B, T, H, drop: Drop = NO_DROP):
     o = torch.empty(B, T, D, device=qkv.device, dtype=torch.float32)
     lse = torch.empty(B, H, T, device=qkv.device, dtype=torch.float32)
     _ok(lib().fs2hip_attention_fwd(_p(qkv), _p(lens), _p(o), _p(lse), B, T, H, D // H, drop.p, drop.seed,
-                                   drop.step_ptr, int(GEMM_BF16 == 1), _stream()), "attention_fwd")
+                                   drop.step_ptr, int(GEMM_BF16), _stream()), "attention_fwd")
     return o, lse
 
 
@@ -667,7 +667,7 @@ def attention_bwd(qkv, lens, o, dout, lse, B, T, H, drop: Drop = NO_DROP):
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(2 * lse.numel() + 4, device=lse.device, dtype=torch.float32)  # scratch: see fs2hip.h
     _ok(lib().fs2hip_attention_bwd(_p(qkv), _p(lens), _p(o), _p(dout), _p(lse), _p(delta), _p(dqkv), B, T, H, D // H,
-                                   drop.p, drop.seed, drop.step_ptr, int(GEMM_BF16 == 1), _stream()), "attention_bwd")
+                                   drop.p, drop.seed, drop.step_ptr, int(GEMM_BF16), _stream()), "attention_bwd")
     return dqkv
 
 

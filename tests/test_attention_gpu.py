@@ -102,3 +102,61 @@ def test_attention_bf16_mixed(H, B, T, Hh, hd, lens):
     eg = (dqkv.cpu() - qr.grad).abs().max().item() / qr.grad.abs().max().item()
     assert eo < 1e-2 and el < 1e-2 and eg < 2e-2, (eo, el, eg)
     assert eo > 2e-5 or eg > 3e-5, "bf16 operands requested, fp32-exact result: the bf16 kernels did not run"
+
+
+@pytest.mark.parametrize("B,T,Hh,hd,lens", [
+    (2, 37, 2, 16, [37, 5]), (3, 130, 2, 128, [130, 64, 1]), (1, 200, 2, 64, [200]), (2, 648, 2, 128, [648, 500]),
+    (32, 648, 2, 128, [648, 430, 40] + [430 + 7 * i for i in range(29)]),
+])
+def test_attention_split(H, B, T, Hh, hd, lens):
+    """precision "32-split": Q.K^T, P.V and the dQ products on the bf16 pipe with operands cut into three exact bf16
+    planes (head dims 64 / 128; dK/dV and the small head dims stay on the fp32 MFMAs).  Same bounds as the fp32 kernels."""
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    D = Hh * hd
+    qkv = torch.randn(B, T, 3 * D, generator=g)
+    dout = torch.randn(B, T, D, generator=g)
+    lens_t = torch.tensor(lens, dtype=torch.int32)
+    qr = qkv.clone().requires_grad_(True)
+    ref, ref_lse = ref_attention(qr, lens_t, B, T, Hh)
+    ref.backward(dout)
+    saved = H.get_precision()
+    try:
+        H.set_precision("32-split")
+        o, lse = H.attention_fwd(qkv.cuda(), lens_t.cuda(), B, T, Hh)
+        dqkv = H.attention_bwd(qkv.cuda(), lens_t.cuda(), o, dout.cuda(), lse, B, T, Hh)
+    finally:
+        H.set_precision(saved)
+    assert (o.cpu() - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max().item())
+    assert (lse.cpu() - ref_lse).abs().max() < 2e-5 * max(1.0, ref_lse.abs().max().item())
+    scale = qr.grad.abs().max().item()
+    err = (dqkv.cpu() - qr.grad).abs().max().item()
+    assert err < 3e-5 * scale, f"dqkv err {err} scale {scale}"
+
+
+@pytest.mark.parametrize("precision,tol", [("32-split", 2e-5), ("bf16-mixed", 3e-2)])
+@pytest.mark.parametrize("T,hd", [(130, 128), (77, 64)])
+def test_attention_plane_modes_share_the_dropout_mask(H, precision, tol, T, hd):
+    """The bf16-pipe variants regenerate the same keep mask as the fp32 kernels (same element index, same pair hash):
+    with dropout on, their outputs and gradients stay within the mode's operand precision of the fp32 kernels'."""
+    B, Hh = 3, 2
+    D = Hh * hd
+    g = torch.Generator().manual_seed(T)
+    qkv = torch.randn(B, T, 3 * D, generator=g).cuda()
+    dout = torch.randn(B, T, D, generator=g).cuda()
+    lens = torch.tensor([T, T // 2, 3], dtype=torch.int32).cuda()
+    drop = H.Drop(0.2, 4242)
+    o0, lse0 = H.attention_fwd(qkv, lens, B, T, Hh, drop)
+    g0 = H.attention_bwd(qkv, lens, o0, dout, lse0, B, T, Hh, drop)
+    saved = H.get_precision()
+    try:
+        H.set_precision(precision)
+        o1, lse1 = H.attention_fwd(qkv, lens, B, T, Hh, drop)
+        g1 = H.attention_bwd(qkv, lens, o1, dout, lse1, B, T, Hh, drop)
+    finally:
+        H.set_precision(saved)
+    valid = (torch.arange(T, device="cuda")[None, :] < lens[:, None])[..., None]
+    eo = ((o1 - o0) * valid).abs().max().item() / o0.abs().max().item()
+    eg = ((g1 - g0).view(B, T, -1) * valid).abs().max().item() / g0.abs().max().item()
+    assert eo < tol and eg < tol, (eo, eg)
+    if precision == "bf16-mixed":
+        assert eo > 1e-4, "bf16 operands requested, fp32-exact result"

@@ -1,5 +1,6 @@
 """Attention forward / backward at the decoder's shape (B=32, T=648, H=2, HD=128) (GPU only).
-usage: python tools/bench_attn.py [ragged|full] [drop_p]   -- `full`: every utterance 648 keys (no tail effects)"""
+usage: python tools/bench_attn.py [ragged|full|lenN] [drop_p] [T] [precision]   -- `full`: every utterance T keys (no tail
+effects); precision 32-true | bf16-mixed | 32-split: prints the error against the 32-true kernels too"""
 import sys
 from pathlib import Path
 
@@ -38,7 +39,20 @@ qkv = torch.randn(B * T, 3 * D, device=dev) if "FS2_UNIFORM" not in __import__("
 dout = torch.randn(B * T, D, device=dev)
 step = torch.zeros(4, dtype=torch.int64, device=dev)
 drop = H.Drop(p, 777, step) if p > 0 else H.NO_DROP
+prec = sys.argv[4] if len(sys.argv) > 4 else "32-true"
+o0, lse0 = H.attention_fwd(qkv, lens, B, T, Hh, drop)
+g0 = H.attention_bwd(qkv, lens, o0, dout, lse0, B, T, Hh, drop)
+H.set_precision(prec)
 o, lse = H.attention_fwd(qkv, lens, B, T, Hh, drop)
+if prec != "32-true":
+    g1 = H.attention_bwd(qkv, lens, o, dout, lse, B, T, Hh, drop)
+    valid = (torch.arange(T, device=dev)[None, :] < lens[:, None])
+    rel = lambda a, b: float((a - b).norm() / b.norm())  # noqa: E731
+    mx = lambda a, b: float((a - b).abs().max())  # noqa: E731
+    om, o0m = o * valid[..., None], o0 * valid[..., None]
+    gm, g0m = g1.view(B, T, -1) * valid[..., None], g0.view(B, T, -1) * valid[..., None]
+    print(f"{prec} vs 32-true: o rel {rel(om, o0m):.2e} max {mx(om, o0m):.2e}; lse max {mx(lse * valid[:, None, :], lse0 * valid[:, None, :]):.2e}; "
+          f"dqkv rel {rel(gm, g0m):.2e} max {mx(gm, g0m):.2e} (|dqkv| max {float(g0m.abs().max()):.2e})")
 tf = timeit(lambda: H.attention_fwd(qkv, lens, B, T, Hh, drop), 20)
 tb = timeit(lambda: H.attention_bwd(qkv, lens, o, dout, lse, B, T, Hh, drop), 20)
 frac = float(lens.float().mean()) / T

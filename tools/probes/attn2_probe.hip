@@ -12,6 +12,7 @@ int main(int argc, char** argv) {
   const int B = 32, H = 2, HD = 128, D = H * HD;
   const int T = argc > 1 ? atoi(argv[1]) : 648, len = argc > 2 ? atoi(argv[2]) : T;
   const float pdrop = argc > 3 ? atof(argv[3]) : 0.f;
+  const int planes = argc > 4 ? atoi(argv[4]) : 0;
   std::vector<float> h((size_t)B * T * 3 * D);
   unsigned x = 12345;
   for (auto& v : h) { x = x * 1664525u + 1013904223u; v = ((x >> 8) & 0xffff) / 32768.f - 1.f; }
@@ -22,7 +23,7 @@ int main(int argc, char** argv) {
   (void)hipMalloc(&dl, B * 4); (void)hipMalloc(&st, nst * 8);
   (void)hipMemcpy(qkv, h.data(), h.size() * 4, hipMemcpyHostToDevice);
   (void)hipMemcpy(dl, lens.data(), B * 4, hipMemcpyHostToDevice);
-  Attn2Args a{qkv, dl, B, T, H, HD, 1.f / sqrtf((float)HD), fs2_make_drop(pdrop, 777), st};
+  Attn2Args a{qkv, dl, B, T, H, HD, 1.f / sqrtf((float)HD), fs2_make_drop(pdrop, 777), planes, st};
   for (int i = 0; i < 300; ++i) fs2_attn2_fwd(a, o, lse, 0);
   (void)hipDeviceSynchronize();
   (void)hipMemset(st, 0, nst * 8);
