@@ -65,33 +65,55 @@ __global__ __launch_bounds__(256) void colstats_wide_kernel(const float* __restr
   }
 }
 
-// fp64 sum over parts of partial[p][2][C] for 64 channels: lanes 0..15 split the parts
-__device__ __forceinline__ void reduce_parts(const float* __restrict__ partial, int nparts, int C, int c, int rl,
-                                             int lane, double (&red)[2][16][64], double& s1, double& s2) {
-  double a = 0.0, b = 0.0;
-  if (c < C)
-    for (int p = rl; p < nparts; p += 16) {
-      a += (double)partial[((long long)p * 2 + 0) * C + c];
-      b += (double)partial[((long long)p * 2 + 1) * C + c];
-    }
-  red[0][rl][lane] = a;
-  red[1][rl][lane] = b;
+// The finalize kernels: one 1024-thread workgroup per 16 channels, thread = (channel tid & 15, part lane tid >> 4):
+// 64 part lanes with four independent loads in flight each (these kernels are pure latency: a few hundred parts per
+// channel), fp64 sums merged in a fixed order -- the lane pairs of a wavefront, then the 16 wavefronts through LDS.
+constexpr int FIN_CH = 16, FIN_LANES = 64;
+// every thread gets the block's sum of v for its channel
+__device__ __forceinline__ double fin_sum(double v, double (&red)[16][FIN_CH]) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  const int ch = threadIdx.x & 15, w = threadIdx.x >> 6;
+  __syncthreads();  // (the previous call's readers are done with red)
+  if ((threadIdx.x & 63) < 16) red[w][ch] = v;
   __syncthreads();
-  s1 = 0.0;
-  s2 = 0.0;
-  if (rl == 0)
-    for (int l = 0; l < 16; ++l) {
-      s1 += red[0][l][lane];
-      s2 += red[1][l][lane];
+  double s = 0.0;
+#pragma unroll
+  for (int l = 0; l < 16; ++l) s += red[l][ch];
+  return s;
+}
+// sum over this thread's parts of f(p, partial[p][0][c], partial[p][1][c]) -> (a, b)
+template <class F>
+__device__ __forceinline__ void fin_parts(const float* __restrict__ partial, int nparts, int C, int c, F&& f, double& a,
+                                          double& b) {
+  a = 0.0;
+  b = 0.0;
+  if (c >= C) return;
+  int p = threadIdx.x >> 4;
+  for (; p + 3 * FIN_LANES < nparts; p += 4 * FIN_LANES) {
+    float u[4], v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      u[k] = partial[((long long)(p + k * FIN_LANES) * 2 + 0) * C + c];
+      v[k] = partial[((long long)(p + k * FIN_LANES) * 2 + 1) * C + c];
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) f(p + k * FIN_LANES, u[k], v[k], a, b);
+  }
+  float u[3], v[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    if (p + k * FIN_LANES < nparts) {
+      u[k] = partial[((long long)(p + k * FIN_LANES) * 2 + 0) * C + c];
+      v[k] = partial[((long long)(p + k * FIN_LANES) * 2 + 1) * C + c];
+    }
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    if (p + k * FIN_LANES < nparts) f(p + k * FIN_LANES, u[k], v[k], a, b);
 }
 
-// rows of part p: the parts tile groups of group_rows rows (one group = the whole matrix for colstats, one utterance
-// for the depthwise conv's fused statistics) in stripes of part_rows
-__device__ __forceinline__ int part_count(int p, int part_rows, int group_rows) {
-  const int ppg = (group_rows + part_rows - 1) / part_rows;
-  return min(part_rows, group_rows - (p % ppg) * part_rows);
-}
+// rows of part p (bn_finalize): the parts tile groups of group_rows rows (one group = the whole matrix for colstats,
+// one utterance for the depthwise conv's fused statistics) in stripes of part_rows
 
 // stats layout (per channel): [0]=scale (gamma*invstd) [1]=shift (beta-mean*scale) [2]=mean [3]=invstd
 // training: Chan's parallel merge of the per-part (n, mean, M2) in fp64 -- mean = sum n_p mean_p / N, then
@@ -102,36 +124,22 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
                                                             const float* __restrict__ beta, float* __restrict__ rmean,
                                                             float* __restrict__ rvar, float momentum, float eps,
                                                             int training, float* __restrict__ stats, int C) {
-  __shared__ double red[16][64];
-  __shared__ double mu_s[64];
-  const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
+  __shared__ double red[16][FIN_CH];
+  const int c = blockIdx.x * FIN_CH + (threadIdx.x & 15);
+  const bool writer = threadIdx.x < FIN_CH && c < C;
   float mean = 0.f, invstd = 0.f;
   if (training) {
-    double a = 0.0;
-    if (c < C)
-      for (int p = rl; p < nparts; p += 16)
-        a += (double)part_count(p, part_rows, group_rows) * (double)partial[((long long)p * 2 + 0) * C + c];
-    red[rl][lane] = a;
-    __syncthreads();
-    if (rl == 0) {
-      double s = 0.0;
-      for (int l = 0; l < 16; ++l) s += red[l][lane];
-      mu_s[lane] = s / (double)count;
-    }
-    __syncthreads();
-    const double mu = mu_s[lane];
-    a = 0.0;
-    if (c < C)
-      for (int p = rl; p < nparts; p += 16) {
-        const double d = (double)partial[((long long)p * 2 + 0) * C + c] - mu;
-        a += (double)partial[((long long)p * 2 + 1) * C + c] + (double)part_count(p, part_rows, group_rows) * d * d;
-      }
-    red[rl][lane] = a;
-    __syncthreads();
-    if (rl != 0 || c >= C) return;
-    double m2 = 0.0;
-    for (int l = 0; l < 16; ++l) m2 += red[l][lane];
+    const int ppg = (group_rows + part_rows - 1) / part_rows;
+    auto cnt = [&](int p) { return (double)min(part_rows, group_rows - (p % ppg) * part_rows); };
+    double a, b;
+    fin_parts(partial, nparts, C, c, [&](int p, float u, float, double& x, double&) { x += cnt(p) * (double)u; }, a, b);
+    const double mu = fin_sum(a, red) / (double)count;
+    fin_parts(partial, nparts, C, c, [&](int p, float u, float v, double& x, double&) {
+      const double d = (double)u - mu;
+      x += (double)v + cnt(p) * d * d;
+    }, a, b);
+    const double m2 = fin_sum(a, red);
+    if (!writer) return;
     double var = m2 / (double)count;
     if (var < 0.0) var = 0.0;
     mean = (float)mu;
@@ -142,7 +150,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
       rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
     }
   } else {
-    if (rl != 0 || c >= C) return;
+    if (!writer) return;
     mean = rmean[c];
     invstd = 1.f / sqrtf(rvar[c] + eps);
   }
@@ -220,12 +228,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nparts,
                                                                 long long count, float* __restrict__ dgamma,
                                                                 float* __restrict__ dbeta, float* __restrict__ coef, int C) {
-  __shared__ double red[2][16][64];
-  const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
-  double s1, s2;
-  reduce_parts(partial, nparts, C, c, rl, lane, red, s1, s2);
-  if (rl != 0 || c >= C) return;
+  __shared__ double red[16][FIN_CH];
+  const int c = blockIdx.x * FIN_CH + (threadIdx.x & 15);
+  double a, b;
+  fin_parts(partial, nparts, C, c, [&](int, float u, float v, double& x, double& y) { x += (double)u; y += (double)v; }, a, b);
+  const double s1 = fin_sum(a, red), s2 = fin_sum(b, red);
+  if (threadIdx.x >= FIN_CH || c >= C) return;
   dbeta[c] = (float)s1;
   dgamma[c] = (float)s2;
   coef[c] = (float)(s1 / (double)count);
@@ -291,7 +299,7 @@ extern "C" int fs2hip_bn_finalize(const float* partial, int nparts, long long co
     const long long ppg = (group_rows + part_rows - 1) / part_rows;
     if (ppg * (count / group_rows) != nparts) return FS2HIP_EINVAL;
   }
-  bn_finalize_kernel<<<dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream>>>(
+  bn_finalize_kernel<<<dim3((C + FIN_CH - 1) / FIN_CH), dim3(1024), 0, (hipStream_t)stream>>>(
       partial, nparts, count, part_rows, group_rows, gamma, beta, running_mean, running_var, momentum, eps, training,
       stats, C);
   FS2_LAUNCH_CHECK();
@@ -326,7 +334,7 @@ extern "C" int fs2hip_bn_act_bwd(const float* dout, const float* y, const float*
   const int nparts = fs2hip_colstats_parts(M);
   bn_bwd_reduce_kernel<<<dim3(nparts), dim3(256), 0, s>>>(dout, y, stats, M, C, act, drop, partial, wm);
   FS2_LAUNCH_CHECK();
-  bn_bwd_finalize_kernel<<<dim3((C + 63) / 64), dim3(1024), 0, s>>>(partial, nparts, (long long)M, dgamma, dbeta, coef, C);
+  bn_bwd_finalize_kernel<<<dim3((C + FIN_CH - 1) / FIN_CH), dim3(1024), 0, s>>>(partial, nparts, (long long)M, dgamma, dbeta, coef, C);
   FS2_LAUNCH_CHECK();
   const long long n4 = (long long)M * C / 4;
   long long blocks = (n4 + 255) / 256;

@@ -57,21 +57,28 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 
 // dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)) (+ dx_add);
 // partial[blk][0][C] = sum_rows dy*xhat, partial[blk][1][C] = sum_rows dy
-template <int NCH>
+// DZ: a second output dz = dz_scale * dropmask * dx (the gradient entering the sub-module below through its output
+// dropout and residual scale: what would otherwise be an axpby launch over dx) and partial[blk][2][C] = sum_rows dz
+// (the gradient of that sub-module's last bias: what would otherwise be a column-sum launch over dz)
+template <int NCH, bool DZ>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                       const float* __restrict__ gamma, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, const float* __restrict__ dx_add,
-                                                      float* __restrict__ dx, float* __restrict__ partial, int M, int C) {
-  __shared__ float red[4][2][LN_MAX_CH * 256];
+                                                      float* __restrict__ dx, float* __restrict__ partial, int M, int C,
+                                                      float* __restrict__ dz, float dz_scale, Fs2Drop drop_in) {
+  constexpr int NP = DZ ? 3 : 2;
+  __shared__ float red[4][NP][LN_MAX_CH * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c4 = C >> 2;
-  float4 g[NCH], dg[NCH], db[NCH];
+  const Fs2Drop drop = fs2_resolve_drop(drop_in);
+  float4 g[NCH], dg[NCH], db[NCH], dzs[DZ ? NCH : 1];
 #pragma unroll
   for (int j = 0; j < NCH; ++j) {
     int i = lane + 64 * j;
     g[j] = i < c4 ? reinterpret_cast<const float4*>(gamma)[i] : make_float4(0, 0, 0, 0);
     dg[j] = make_float4(0, 0, 0, 0);
     db[j] = make_float4(0, 0, 0, 0);
+    if constexpr (DZ) dzs[j] = make_float4(0, 0, 0, 0);
   }
   const int row0 = blockIdx.x * LN_BWD_ROWS;
   for (int rr = wave; rr < LN_BWD_ROWS; rr += 4) {
@@ -113,6 +120,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
           o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
         }
         reinterpret_cast<float4*>(dx + (long long)row * C)[i] = o;
+        if constexpr (DZ) {
+          const unsigned long long e = ((unsigned long long)row * C) + 4ull * i;  // element index in the [M, C] tensor
+          float4 z;
+          z.x = o.x * dz_scale * fs2_drop_factor(drop, e + 0);
+          z.y = o.y * dz_scale * fs2_drop_factor(drop, e + 1);
+          z.z = o.z * dz_scale * fs2_drop_factor(drop, e + 2);
+          z.w = o.w * dz_scale * fs2_drop_factor(drop, e + 3);
+          reinterpret_cast<float4*>(dz + (long long)row * C)[i] = z;
+          dzs[j].x += z.x; dzs[j].y += z.y; dzs[j].z += z.z; dzs[j].w += z.w;
+        }
       }
     }
   }
@@ -121,13 +138,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     int i = lane + 64 * j;
     reinterpret_cast<float4*>(&red[wave][0][0])[i] = dg[j];
     reinterpret_cast<float4*>(&red[wave][1][0])[i] = db[j];
+    if constexpr (DZ) reinterpret_cast<float4*>(&red[wave][2][0])[i] = dzs[j];
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
-    float a = red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c];
-    float b = red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c];
-    partial[((long long)blockIdx.x * 2 + 0) * C + c] = a;
-    partial[((long long)blockIdx.x * 2 + 1) * C + c] = b;
+#pragma unroll
+    for (int k = 0; k < NP; ++k)
+      partial[((long long)blockIdx.x * NP + k) * C + c] = red[0][k][c] + red[1][k][c] + red[2][k][c] + red[3][k][c];
   }
 }
 
@@ -160,13 +177,35 @@ extern "C" int fs2hip_layernorm_bwd(const float* dy, const float* x, const float
   const int nblk = fs2hip_layernorm_bwd_blocks(M);
   hipStream_t s = (hipStream_t)stream;
   const int nch = (C / 4 + 63) / 64;
+  const Fs2Drop nodrop = fs2_make_drop(0.f, 0);
   switch (nch) {
-    case 1: ln_bwd_kernel<1><<<dim3(nblk), dim3(256), 0, s>>>(dy, x, gamma, mean, rstd, dx_add, dx, partial, M, C); break;
-    case 2: ln_bwd_kernel<2><<<dim3(nblk), dim3(256), 0, s>>>(dy, x, gamma, mean, rstd, dx_add, dx, partial, M, C); break;
-    default: ln_bwd_kernel<4><<<dim3(nblk), dim3(256), 0, s>>>(dy, x, gamma, mean, rstd, dx_add, dx, partial, M, C); break;
+    case 1: ln_bwd_kernel<1, false><<<dim3(nblk), dim3(256), 0, s>>>(dy, x, gamma, mean, rstd, dx_add, dx, partial, M, C, nullptr, 0.f, nodrop); break;
+    case 2: ln_bwd_kernel<2, false><<<dim3(nblk), dim3(256), 0, s>>>(dy, x, gamma, mean, rstd, dx_add, dx, partial, M, C, nullptr, 0.f, nodrop); break;
+    default: ln_bwd_kernel<4, false><<<dim3(nblk), dim3(256), 0, s>>>(dy, x, gamma, mean, rstd, dx_add, dx, partial, M, C, nullptr, 0.f, nodrop); break;
   }
   FS2_LAUNCH_CHECK();
   // partial is [nblk][2][C]: columns [0, C) -> dgamma, [C, 2C) -> dbeta
   if (!dgamma && !dbeta) return 0;  // the caller finishes the partial sums with fs2hip_reduce_rows_multi
   return fs2_reduce_rows(partial, nblk, 2 * C, 2LL * C, dgamma, C, dbeta, s);
+}
+
+extern "C" int fs2hip_layernorm_bwd_dz(const float* dy, const float* x, const float* gamma, const float* mean,
+                                       const float* rstd, const float* dx_add, float* dx, float* dz, float dz_scale,
+                                       float drop_p, unsigned long long drop_seed, const unsigned long long* drop_step,
+                                       float* partial, int M, int C, void* stream) {
+  if (M <= 0 || C <= 0 || (C % 4) || C > LN_MAX_CH * 256 || !dz || !partial) return FS2HIP_EINVAL;
+  if (((uintptr_t)x % 16) || ((uintptr_t)dy % 16) || ((uintptr_t)dx % 16) || ((uintptr_t)dz % 16) || ((uintptr_t)gamma % 16))
+    return FS2HIP_EINVAL;
+  if (dx_add && ((uintptr_t)dx_add % 16)) return FS2HIP_EINVAL;
+  const int nblk = fs2hip_layernorm_bwd_blocks(M);
+  hipStream_t s = (hipStream_t)stream;
+  const Fs2Drop drop = fs2_make_drop(drop_p, drop_seed, drop_step);
+  const int nch = (C / 4 + 63) / 64;
+  switch (nch) {
+    case 1: ln_bwd_kernel<1, true><<<dim3(nblk), dim3(256), 0, s>>>(dy, x, gamma, mean, rstd, dx_add, dx, partial, M, C, dz, dz_scale, drop); break;
+    case 2: ln_bwd_kernel<2, true><<<dim3(nblk), dim3(256), 0, s>>>(dy, x, gamma, mean, rstd, dx_add, dx, partial, M, C, dz, dz_scale, drop); break;
+    default: ln_bwd_kernel<4, true><<<dim3(nblk), dim3(256), 0, s>>>(dy, x, gamma, mean, rstd, dx_add, dx, partial, M, C, dz, dz_scale, drop); break;
+  }
+  FS2_LAUNCH_CHECK();
+  return 0;  // partial is [nblk][3][C]; the caller finishes it with fs2hip_reduce_rows_multi
 }

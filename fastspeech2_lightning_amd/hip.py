@@ -57,6 +57,7 @@ SIGNATURES = {
     "fs2hip_layernorm_fwd": "ppppppiifp",
     "fs2hip_layernorm_bwd_blocks": "i",
     "fs2hip_layernorm_bwd": "ppppppppppiip",
+    "fs2hip_layernorm_bwd_dz": "ppppppppffQppiip",
     "fs2hip_attention_fwd": "ppppiiiifQpip",
     "fs2hip_attention_bwd": "pppppppiiiifQpip",
     "fs2hip_dwconv_blocks": "ii",
@@ -617,8 +618,11 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dx_add=None, defer=False):
-    """Returns dx (+ dx_add); writes dgamma/dbeta (``defer``: at the next ``flush_grad_reductions()``)."""
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dx_add=None, defer=False, dz_scale=None,
+                  dz_drop: Drop = NO_DROP, dz_colsum=None):
+    """Returns dx (+ dx_add); writes dgamma/dbeta (``defer``: at the next ``flush_grad_reductions()``).
+    With ``dz_scale``: returns (dx, dz), dz = dz_scale * dropmask(dz_drop) * dx, and ``dz_colsum`` receives dz's column
+    sums at the next ``flush_grad_reductions()`` (like dgamma/dbeta, which are then always deferred)."""
     for n, t in (("dy", dy), ("x", x), ("gamma", gamma), ("mean", mean), ("rstd", rstd), ("dgamma", dgamma),
                  ("dbeta", dbeta)):
         _chk(t, name=n)
@@ -630,6 +634,17 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dx_add=None, defer=Fa
         _req(dx_add.shape == x.shape, "layernorm_bwd: dx_add shape")
     dx = torch.empty_like(x)
     nblk = lib().fs2hip_layernorm_bwd_blocks(M)
+    if dz_scale is not None:
+        _chk(dz_colsum, name="dz_colsum")
+        _req(dz_colsum.numel() == Cc, "layernorm_bwd: dz_colsum size")
+        dz = torch.empty_like(x)
+        part = torch.empty(nblk * 3 * Cc, device=x.device, dtype=torch.float32)
+        _ok(lib().fs2hip_layernorm_bwd_dz(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx_add), _p(dx), _p(dz),
+                                          float(dz_scale), dz_drop.p, dz_drop.seed, dz_drop.step_ptr, _p(part), M, Cc,
+                                          _stream()), "layernorm_bwd_dz")
+        _defer_reduction(part, nblk, 2 * Cc, 3 * Cc, dgamma, Cc, dbeta)
+        _defer_reduction(part[2 * Cc:], nblk, Cc, 3 * Cc, dz_colsum, Cc, None)
+        return dx, dz
     if defer and nblk > 1:
         part = torch.empty(nblk * 2 * Cc, device=x.device, dtype=torch.float32)
         _ok(lib().fs2hip_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx_add), _p(dx), _p(part),

@@ -122,9 +122,15 @@ class LayerNorm:
         y, mean, rstd = H.layernorm_fwd(x, self.S.p(self.w), self.S.p(self.b))
         return y, (x, mean, rstd)
 
-    def bwd(self, dy, saved, dx_add=None):
+    def bwd(self, dy, saved, dx_add=None, nxt=None):
+        """``nxt`` = (scale, Drop, bias gradient) of the sub-module below (its ``dz_spec()``): returns (dx, dz) with
+        dz = scale * dropmask * dx made, and its column sums (that bias gradient) started, by the same kernel."""
         x, mean, rstd = saved
-        return H.layernorm_bwd(dy, x, self.S.p(self.w), mean, rstd, self.S.g(self.w), self.S.g(self.b), dx_add, defer=True)
+        if nxt is None:
+            return H.layernorm_bwd(dy, x, self.S.p(self.w), mean, rstd, self.S.g(self.w), self.S.g(self.b), dx_add, defer=True)
+        scale, drop, bias_grad = nxt
+        return H.layernorm_bwd(dy, x, self.S.p(self.w), mean, rstd, self.S.g(self.w), self.S.g(self.b), dx_add, defer=True,
+                               dz_scale=scale, dz_drop=drop, dz_colsum=bias_grad)
 
 
 class BatchNorm:
@@ -175,18 +181,28 @@ class FeedForward:
                          drop=env.drop(self.p, self.s2))
         return y, Ctx(ln=ln_saved, h=h, u=u, a=a)
 
-    def bwd(self, dy, c):
+    def dz_spec(self):
+        """(scale, Drop, bias gradient): what turns the gradient of this sub-module's output into the gradient dz of its
+        last Linear's output, and where dz's column sums go (``LayerNorm.bwd(nxt=...)`` of the sub-module above)."""
+        return 0.5, self.env.drop(self.p, self.s2), self.S.g(self.b2)
+
+    def bwd(self, dy, c, dz=None, nxt=None):
+        """``dz``: already made (with its bias gradient) by the LayerNorm backward above; ``nxt``: see ``LayerNorm.bwd``
+        (the return value is then (dx, next dz))."""
         S, env = self.S, self.env
-        dz = H.axpby(dy, None, 0.5, 0.0, env.drop(self.p, self.s2))
+        fused = dz is not None
+        if not fused:
+            dz = H.axpby(dy, None, 0.5, 0.0, env.drop(self.p, self.s2))
         with env.side(dz, c.a):
             H.linear_bwd_weight(dz, c.a, S.g(self.w2))
-            H.colsum_grad(dz, S.g(self.b2))
+            if not fused:
+                H.colsum_grad(dz, S.g(self.b2))
         du = H.linear_bwd_data(dz, S.p(self.w2), epi=H.EPI_DACT, act="silu", aux=c.u, drop=env.drop(self.p, self.s1))
         with env.side(du, c.h):
             H.linear_bwd_weight(du, c.h, S.g(self.w1))
             H.colsum_grad(du, S.g(self.b1))
         dh = H.linear_bwd_data(du, S.p(self.w1))
-        return self.ln.bwd(dh, c.ln, dx_add=dy)
+        return self.ln.bwd(dh, c.ln, dx_add=dy, nxt=nxt)
 
 
 class SelfAttention:
@@ -212,21 +228,27 @@ class SelfAttention:
         y = H.linear_fwd(o, S.p(self.wo), S.p(self.bo), epi=H.EPI_RESID, resid=x, drop=env.drop(self.p, self.so))
         return y, Ctx(ln=ln_saved, h=h, qkv=qkv, o=o, lse=lse, lens=lens)
 
-    def bwd(self, dy, c):
+    def dz_spec(self):
+        return 1.0, self.env.drop(self.p, self.so), self.S.g(self.bo)
+
+    def bwd(self, dy, c, dz=None, nxt=None):
         S, env = self.S, self.env
         B, T, _ = dy.shape
-        d_o = env.drop(self.p, self.so)
-        dz = H.axpby(dy, None, 1.0, 0.0, d_o) if d_o.p > 0 else dy
+        fused = dz is not None
+        if not fused:
+            d_o = env.drop(self.p, self.so)
+            dz = H.axpby(dy, None, 1.0, 0.0, d_o) if d_o.p > 0 else dy
         with env.side(dz, c.o):
             H.linear_bwd_weight(dz, c.o, S.g(self.wo))
-            H.colsum_grad(dz, S.g(self.bo))
+            if not fused:
+                H.colsum_grad(dz, S.g(self.bo))
         do = H.linear_bwd_data(dz, S.p(self.wo))
         dqkv = H.attention_bwd(c.qkv, c.lens, c.o, do, c.lse, B, T, self.heads, env.drop(self.p, self.sa))
         with env.side(dqkv, c.h):
             H.linear_bwd_weight(dqkv, c.h, S.g(self.wi))
             H.colsum_grad(dqkv, S.g(self.bi))
         dh = H.linear_bwd_data(dqkv, S.p(self.wi))
-        return self.ln.bwd(dh, c.ln, dx_add=dy)
+        return self.ln.bwd(dh, c.ln, dx_add=dy, nxt=nxt)
 
 
 class ConvModule:
@@ -260,14 +282,20 @@ class ConvModule:
         y = H.linear_fwd(s, S.p(self.w2), S.p(self.b2), epi=H.EPI_RESID, resid=x, drop=env.drop(self.p, self.site))
         return y, Ctx(ln=ln_saved, h=h, g2=g2, c=c, stats=stats, s=s)
 
-    def bwd(self, dy, c):
+    def dz_spec(self):
+        return 1.0, self.env.drop(self.p, self.site), self.S.g(self.b2)
+
+    def bwd(self, dy, c, dz=None, nxt=None):
         S, env = self.S, self.env
         B, T, _ = dy.shape
-        d_o = env.drop(self.p, self.site)
-        dz = H.axpby(dy, None, 1.0, 0.0, d_o) if d_o.p > 0 else dy
+        fused = dz is not None
+        if not fused:
+            d_o = env.drop(self.p, self.site)
+            dz = H.axpby(dy, None, 1.0, 0.0, d_o) if d_o.p > 0 else dy
         with env.side(dz, c.s):
             H.linear_bwd_weight(dz, c.s, S.g(self.w2))
-            H.colsum_grad(dz, S.g(self.b2))
+            if not fused:
+                H.colsum_grad(dz, S.g(self.b2))
         ds = H.linear_bwd_data(dz, S.p(self.w2))
         gg, gb = self.bn.grads()
         dc = H.bn_act_bwd(ds, c.c, c.stats, gg, gb, "silu", training=env.training)
@@ -276,7 +304,7 @@ class ConvModule:
             H.linear_bwd_weight(dg2, c.h, S.g(self.w1))
             H.colsum_grad(dg2, S.g(self.b1))
         dh = H.linear_bwd_data(dg2, S.p(self.w1))
-        return self.ln.bwd(dh, c.ln, dx_add=dy)
+        return self.ln.bwd(dh, c.ln, dx_add=dy, nxt=nxt)
 
 
 class ConformerLayer:
@@ -297,11 +325,13 @@ class ConformerLayer:
 
     def bwd(self, dy, c):
         c1, c2, c3, c4, c5 = c
-        d = self.final.bwd(dy, c5)
-        d = self.ffn2.bwd(d, c4)
-        d = self.conv.bwd(d, c3)
-        d = self.attn.bwd(d, c2)
-        return self.ffn1.bwd(d, c1)
+        # every LayerNorm backward also makes the dropout-masked, scaled gradient (and the bias gradient) the
+        # sub-module below starts from
+        d, dz = self.final.bwd(dy, c5, nxt=self.ffn2.dz_spec())
+        d, dz = self.ffn2.bwd(d, c4, dz, nxt=self.conv.dz_spec())
+        d, dz = self.conv.bwd(d, c3, dz, nxt=self.attn.dz_spec())
+        d, dz = self.attn.bwd(d, c2, dz, nxt=self.ffn1.dz_spec())
+        return self.ffn1.bwd(d, c1, dz)
 
 
 class Conformer:

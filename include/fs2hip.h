@@ -142,6 +142,15 @@ int fs2hip_layernorm_bwd_blocks(int M);
 int fs2hip_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                          const float* rstd, const float* dx_add, float* dx, float* partial,
                          float* dgamma, float* dbeta, int M, int C, void* stream);
+/* The same with a second output for the sub-module below in the backward order (every Conformer sub-module is
+ * x + scale * Dropout(f(LayerNorm(x))), torchaudio conformer.py; call sites fs2/model.py:95-119): dz = dz_scale *
+ * dropmask * dx with the mask of that sub-module's output dropout (element index row * C + c, as fs2hip_axpby draws
+ * it), and its column sums -- the gradient of f's last bias.  partial is [fs2hip_layernorm_bwd_blocks(M)][3][C]:
+ * rows of dgamma | dbeta | colsum(dz) partial sums, finished by fs2hip_reduce_rows_multi. */
+int fs2hip_layernorm_bwd_dz(const float* dy, const float* x, const float* gamma, const float* mean,
+                            const float* rstd, const float* dx_add, float* dx, float* dz, float dz_scale,
+                            float drop_p, unsigned long long drop_seed, const unsigned long long* drop_step,
+                            float* partial, int M, int C, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Multi-head self-attention with key-padding mask (flash style; fp32 MFMA: v_mfma_f32_32x32x2_f32 for

@@ -202,3 +202,27 @@ def test_layernorm(H, M, C):
     close(dx, xr.grad + add, 16, "ln dx")
     close(dg, gr.grad, M, "ln dgamma")
     close(db, br.grad, M, "ln dbeta")
+
+
+@pytest.mark.parametrize("M,C,p", [(1000, 256, 0.1), (37, 512, 0.0), (5, 80, 0.5), (129, 1024, 0.2)])
+def test_layernorm_bwd_second_output(H, M, C, p):
+    """fs2hip_layernorm_bwd_dz: dx, dgamma, dbeta as the plain backward; dz = scale * dropmask * dx with exactly the
+    mask fs2hip_axpby draws for the same Drop record (bit-identical: same products in the same order), and dz's column
+    sums, finished with the deferred LayerNorm parameter sums."""
+    x, g, b, dy, add = rnd(M, C, seed=1), 1 + 0.1 * rnd(C, seed=2), rnd(C, seed=3), rnd(M, C, seed=4), rnd(M, C, seed=5)
+    _, mean, rstd = H.layernorm_fwd(x.cuda(), g.cuda(), b.cuda())
+    dg0, db0 = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    dx0 = H.layernorm_bwd(dy.cuda(), x.cuda(), g.cuda(), mean, rstd, dg0, db0, dx_add=add.cuda())
+    drop = H.Drop(p, 31337) if p > 0 else H.NO_DROP
+    dg, db, dzsum = (torch.full((C,), float("nan"), device="cuda") for _ in range(3))
+    dx, dz = H.layernorm_bwd(dy.cuda(), x.cuda(), g.cuda(), mean, rstd, dg, db, dx_add=add.cuda(), defer=True,
+                             dz_scale=0.5, dz_drop=drop, dz_colsum=dzsum)
+    H.flush_grad_reductions()
+    assert torch.equal(dx, dx0)
+    want = H.axpby(dx0, None, 0.5, 0.0, drop)
+    assert torch.equal(dz, want)
+    if p > 0:
+        assert abs((dz != 0).float().mean().item() - (1 - p)) < (0.15 if M * C < 1000 else 0.02)
+    close(dg, dg0, M, "dgamma")
+    close(db, db0, M, "dbeta")
+    close(dzsum, want.double().sum(0).float(), M, "colsum(dz)")
