@@ -213,6 +213,9 @@ extern "C" int fs2hip_gemm(const Fs2GemmArgs* args, void* stream) {
     }
   }
   if (a.splitk > 1 && (a.a_kcontig || a.b_kcontig || !a.workspace)) return FS2HIP_EINVAL;
+  if (a.splitk <= 1) a.counters = nullptr;
+  // (one arrival counter per output tile and tap; the smallest tile is 64 x 64)
+  if (a.counters && (long long)a.taps * ((a.Mc + 63) / 64) * ((a.Nc + 63) / 64) > FS2_SPLITK_COUNTERS) return FS2HIP_EINVAL;
   if (a.epi == FS2_EPI_RESID && !a.resid) return FS2HIP_EINVAL;
   if (a.epi == FS2_EPI_DACT && !a.aux) return FS2HIP_EINVAL;
   {  // the epilogue addresses its tensors with 32-bit byte offsets (gemm_common.h): each must stay below 2 GiB

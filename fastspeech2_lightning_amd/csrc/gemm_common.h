@@ -15,7 +15,8 @@ struct GemmP {
 // C/D layout of v_mfma_f32_32x32x2_f32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5):
 // one store instruction writes two full 128-byte row segments.
 //
-// EPI is a compile-time copy of a.epi (-1 = split-K slab: raw partial sums into the workspace), so that each
+// EPI is a compile-time copy of a.epi (-1 = split-K slab: raw partial sums into the workspace; -2: the same with
+// device-coherent stores, see splitk_finish), so that each
 // variant is one straight run of stores -- the epilogue is executed once per tile, from a cold
 // instruction cache, and must not be a chain of per-element branches.
 //
@@ -34,6 +35,12 @@ __device__ __forceinline__ float fs2_buf_load(__amdgpu_buffer_rsrc_t r, int voff
 }
 __device__ __forceinline__ void fs2_buf_store(__amdgpu_buffer_rsrc_t r, int voff, int soff, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+// device-coherent variants (sc1): the store is written through this XCD's L2, the load does not take a line another
+// XCD may have made stale -- what a relaxed agent-scope atomic store / load compiles to on gfx942 / gfx950
+constexpr int FS2_SC1 = 16;
+__device__ __forceinline__ void fs2_buf_store_sc1(__amdgpu_buffer_rsrc_t r, int voff, int soff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, FS2_SC1);
 }
 
 template <int BM, int BN, int EPI>
@@ -110,11 +117,84 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmP& p, const f32x16 
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = x[r] + a.res_scale * v[r];
       }
+      if (EPI == -2) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) fs2_buf_store(rc, vc, FS2_ROWOFF(i, r) * ldc * 4, v[r]);
+        for (int r = 0; r < 16; ++r) fs2_buf_store_sc1(rc, vc, FS2_ROWOFF(i, r) * ldc * 4, v[r]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) fs2_buf_store(rc, vc, FS2_ROWOFF(i, r) * ldc * 4, v[r]);
+      }
     }
   }
 #undef FS2_ROWOFF
+}
+
+// Split-K without a second launch: every workgroup of an output tile, after its slab tile is written, bumps the
+// tile's arrival counter; the one that finds splitk - 1 there is the last, sums the tile's slabs in slab order
+// (the order fs2hip_reduce_slabs uses: the result is the same bit for bit, whichever workgroup ends up last) and
+// writes C.  The eight XCDs' L2s are not coherent with each other, and the device-scope fences that would make
+// ordinary stores visible write back / invalidate a whole L2 each (measured: +6.8 ms per step, the other workgroups
+// of the XCD lose their operand tiles).  Instead the slab traffic itself is device-coherent: slabs are stored with
+// sc1 (written through), the workgroup waits for its stores to be acknowledged (vmcnt 0) before the counter's
+// device-scope atomic, and the last workgroup reads the slabs with sc1 loads.  The counter is re-armed for the next
+// launch on the stream.
+template <int BM, int BN>
+__device__ __forceinline__ void splitk_finish(const GemmP& p, int m0, int n0, int tapz) {
+  const Fs2GemmArgs& a = p.a;
+  __shared__ int last_one;
+  const int slot = (tapz * ((a.Mc + BM - 1) / BM) + m0 / BM) * p.tiles_n + n0 / BN;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's slab stores are acknowledged
+  __syncthreads();                                   // ... and everybody's
+  if (threadIdx.x == 0)
+    last_one = __hip_atomic_fetch_add(a.counters + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.splitk - 1;
+  __syncthreads();
+  if (!last_one) return;
+  const long long slab = (long long)a.Mc * a.Nc;
+  const long long kstride = (long long)a.taps * slab;  // workspace[split][taps][Mc * Nc]
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(a.workspace + (long long)tapz * slab), 0, 0x7ffffffc, 0x00020000);
+  float* C = a.C + (a.shift_operand == 1 ? (long long)tapz * a.c_tap_stride : 0);
+  const bool vec = (a.Nc % 4) == 0 && (a.ldc % 4) == 0 && ((uintptr_t)C % 16) == 0 && ((uintptr_t)a.workspace % 16) == 0;
+  constexpr int C4 = BN / 4;
+  for (int e = threadIdx.x; e < BM * C4; e += blockDim.x) {
+    const int m = m0 + e / C4, n = n0 + (e % C4) * 4;
+    if (m >= a.Mc || n >= a.Nc) continue;
+    const int off = (m * a.Nc + n) * 4;  // (< 2 GiB: checked by fs2hip_gemm)
+    if (vec) {
+      // eight slabs in flight per thread (these loads miss every cache by construction), added in slab order
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+      for (int k0 = 0; k0 < a.splitk; k0 += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
+              (void*)(a.workspace + (long long)tapz * slab + (k0 + u) * kstride), 0, k0 + u < a.splitk ? 0x7ffffffc : 0, 0x00020000);
+          v[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, off, 0, FS2_SC1));  // (0 past the last slab)
+        }
+        if (k0 == 0) {
+          t = v[0];
+#pragma unroll
+          for (int u = 1; u < 8; ++u)
+            if (u < a.splitk) t += v[u];
+        } else {
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (k0 + u < a.splitk) t += v[u];
+        }
+      }
+      *reinterpret_cast<f32x4*>(C + (long long)m * a.ldc + n) = t;
+    } else {
+      for (int i = 0; i < 4 && n + i < a.Nc; ++i) {
+        float t = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, off + 4 * i, 0, FS2_SC1));
+        for (int k = 1; k < a.splitk; ++k) {
+          const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
+              (void*)(a.workspace + (long long)tapz * slab + k * kstride), 0, 0x7ffffffc, 0x00020000);
+          t += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rk, off + 4 * i, 0, FS2_SC1));
+        }
+        C[(long long)m * a.ldc + n + i] = t;
+      }
+    }
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(a.counters + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <int BM, int BN>
@@ -124,7 +204,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, const f32x16 (&acc
   float* C = a.C;
   if (a.splitk > 1) {
     C = a.workspace + ((long long)split * a.taps + tapz) * ((long long)a.Mc * a.Nc);
-    gemm_epilogue_impl<BM, BN, -1>(p, acc, C, a.Nc, m0, n0, wm, wn, lane);
+    if (a.counters) {
+      gemm_epilogue_impl<BM, BN, -2>(p, acc, C, a.Nc, m0, n0, wm, wn, lane);
+      splitk_finish<BM, BN>(p, m0, n0, tapz);
+    } else {
+      gemm_epilogue_impl<BM, BN, -1>(p, acc, C, a.Nc, m0, n0, wm, wn, lane);
+    }
     return;
   }
   if (a.shift_operand == 1) C += (long long)tapz * a.c_tap_stride;

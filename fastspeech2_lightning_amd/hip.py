@@ -40,6 +40,7 @@ class GemmArgs(C.Structure):
         ("out_pre", C.c_void_p), ("ldpre", C.c_int),
         ("drop_p", C.c_float), ("drop_seed", C.c_ulonglong), ("drop_step", C.c_void_p),
         ("splitk", C.c_int), ("workspace", C.c_void_p), ("tile", C.c_int), ("workspace_floats", C.c_longlong),
+        ("counters", C.c_void_p),
         ("operand_bf16", C.c_int),
     ]
 
@@ -218,6 +219,22 @@ def _workspace(n: int, device) -> torch.Tensor:
     return reserve_workspace(n, device)
 
 
+SPLITK_COUNTERS = 4096  # FS2_SPLITK_COUNTERS
+SPLITK_IN_KERNEL = os.environ.get("FS2_SPLITK_IN_KERNEL", "1") != "0"  # measurement aid: "0" = separate reduce launch
+_COUNTERS = {}
+
+
+def splitk_counters(device) -> torch.Tensor:
+    """The per-output-tile arrival counters of the current stream's split-K GEMMs (zero between launches: the
+    workgroup that finishes a tile re-arms its counter).  Allocate before capturing a hipGraph."""
+    key = (device.index if isinstance(device, torch.device) else device, _stream())
+    c = _COUNTERS.get(key)
+    if c is None:
+        dev = device if isinstance(device, torch.device) else torch.device("cuda", device)
+        c = _COUNTERS[key] = torch.zeros(SPLITK_COUNTERS, device=dev, dtype=torch.int32)
+    return c
+
+
 # ------------------------------------------------------------------------------------------
 # GEMM family
 # ------------------------------------------------------------------------------------------
@@ -301,7 +318,8 @@ def _tile_key(a):
     # layouts, the conv geometry (T only matters to the shifted-operand cores, which refuse T < 32), the epilogue and
     # which of its tensors are present, 16-byte alignment of the output rows (the split-tail tiles need it), device
     flags = ((1 if a.bias else 0) | (2 if a.resid else 0) | (4 if a.aux else 0) | (8 if a.out_pre else 0)
-             | (16 if (a.ldc % 4 == 0 and (a.C or 0) % 16 == 0) else 0) | (32 if a.drop_p > 0 else 0))
+             | (16 if (a.ldc % 4 == 0 and (a.C or 0) % 16 == 0) else 0) | (32 if a.drop_p > 0 else 0)
+             | (64 if a.counters else 0))
     return (a.Mc, a.Nc, a.R, a.taps, a.a_kcontig, a.b_kcontig, a.shift_operand, a.splitk, a.epi, a.operand_bf16,
             a.T if a.taps > 1 else 0, flags, _current_device())
 
@@ -520,8 +538,12 @@ def linear_bwd_weight(dy, x, out, *, taps=1, T=0, n_valid=None):
         ws = _workspace(S * n, dy.device)
         kw["workspace"] = _p(ws)
         kw["workspace_floats"] = ws.numel()
+        in_kernel = SPLITK_IN_KERNEL and taps * ((N + 63) // 64) * ((K + 63) // 64) <= SPLITK_COUNTERS
+        if in_kernel:  # the last workgroup of every output tile sums the slabs: no second launch
+            kw["counters"] = _p(splitk_counters(dy.device))
         _gemm(_algorithmic=n_valid is None, **kw)
-        _ok(lib().fs2hip_reduce_slabs(_p(ws), _p(out), n, S, n, _stream()), "reduce_slabs")
+        if not in_kernel:
+            _ok(lib().fs2hip_reduce_slabs(_p(ws), _p(out), n, S, n, _stream()), "reduce_slabs")
     else:
         _gemm(_algorithmic=n_valid is None, **kw)
     return out

@@ -63,7 +63,10 @@ int fs2hip_version(void);
  *                        B row r + s(j) (zero outside), C + j*c_tap_stride.
  *     s(tap) = tap * tap_mul + tap_add.
  *   splitk > 1 (only with a_kcontig = b_kcontig = 0): R is cut in `splitk` chunks, partial
- *     tiles go to workspace[split][taps][Mc*Nc] and fs2hip_reduce_slabs finishes.
+ *     tiles go to workspace[split][taps][Mc*Nc].  With `counters` == NULL fs2hip_reduce_slabs finishes; with
+ *     `counters` (FS2_SPLITK_COUNTERS zero-initialised ints, one set per stream that runs split GEMMs) the workgroup
+ *     that delivers the LAST slab of an output tile sums the tile's slabs in slab order (the same sum, bit for bit) and
+ *     writes C itself, then re-arms the tile's counter: no second launch.
  * ------------------------------------------------------------------------------------ */
 typedef struct {
   const float* A;
@@ -95,6 +98,7 @@ typedef struct {
                64x64, 128x64, 128x128, 13/14/15 = persistent 128x128, 128x64, 64x64 whose last partial round of tiles
                is cut along the reduction and finished (sum + the same epilogue) by a second pass (needs `workspace`) */
   long long workspace_floats; /* capacity of `workspace` */
+  int* counters; /* splitk > 1: per-output-tile arrival counters (see above), or NULL */
   int operand_bf16; /* 0: fp32 MFMA (the default, the parity path).  1: "bf16-mixed" -- A and B stay fp32 in memory and
                        in LDS, are rounded to bf16 (RNE) in registers and multiplied with v_mfma_f32_32x32x16_bf16;
                        accumulation, bias/epilogue and C stay fp32.  2: "32-split" -- fp32 accuracy on the bf16 pipe:
@@ -104,6 +108,7 @@ typedef struct {
                        2.7x its matrix-pipe rate.  Only the direct-to-LDS cores (tile >= 4) carry modes 1 and 2;
                        shapes those cores refuse run in fp32 */
 } Fs2GemmArgs;
+#define FS2_SPLITK_COUNTERS 4096
 
 int fs2hip_gemm(const Fs2GemmArgs* args, void* stream);
 

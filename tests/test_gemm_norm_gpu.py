@@ -226,3 +226,36 @@ def test_layernorm_bwd_second_output(H, M, C, p):
     close(dg, dg0, M, "dgamma")
     close(db, db0, M, "dbeta")
     close(dzsum, want.double().sum(0).float(), M, "colsum(dz)")
+
+
+@pytest.mark.parametrize("M,N,K,taps,T", [(20736, 256, 1024, 1, 0), (20736, 1024, 256, 1, 0), (4096, 80, 256, 1, 0),
+                                           (2592, 512, 512, 5, 648), (4000, 256, 84, 1, 0), (1024, 64, 64, 1, 0)])
+@pytest.mark.parametrize("tile", [None, 3, 6, 7])
+def test_split_reduction_finished_in_kernel_is_bit_identical(H, monkeypatch, M, N, K, taps, T, tile):
+    """Weight gradients cut along the reduction: the last workgroup of every output tile sums the tile's slabs itself
+    (Fs2GemmArgs.counters).  Same slabs, same order as fs2hip_reduce_slabs -> the same bits on the same tile (tile None:
+    the autotuner may pick different tiles for the two variants, whose summation orders differ -> fp32 tolerance); and
+    the counters come back to zero, so the next launch on the stream (here: the same one, three times) starts clean."""
+    dy, x = rnd(M, N, seed=7).cuda(), rnd(M, K, seed=8).cuda()
+    if H.pick_splitk(N, K, M, taps) == 1:
+        pytest.skip("shape is not split")
+    saved = H.GEMM_TILES
+    try:
+        if tile is not None:
+            H.GEMM_TILES = (tile,)
+        H._TILE_CACHE.clear()
+        want = torch.empty(taps * N * K, device="cuda")
+        monkeypatch.setattr(H, "SPLITK_IN_KERNEL", False)
+        H.linear_bwd_weight(dy, x, want, taps=taps, T=T)
+        monkeypatch.setattr(H, "SPLITK_IN_KERNEL", True)
+        for _ in range(3):
+            got = torch.full_like(want, float("nan"))
+            H.linear_bwd_weight(dy, x, got, taps=taps, T=T)
+            if tile is not None:
+                assert torch.equal(got, want)
+            else:
+                close(got, want, M, "in-kernel finish, tuned tile")
+        assert int(H.splitk_counters(dy.device).abs().sum()) == 0
+    finally:
+        H.GEMM_TILES = saved
+        H._TILE_CACHE.clear()
