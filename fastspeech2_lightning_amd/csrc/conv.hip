@@ -209,6 +209,9 @@ extern "C" int fs2hip_dwconv_bwd(const float* dy, const float* x, int ldx, const
   FS2_LAUNCH_CHECK();
   const int nblk = fs2hip_dwconv_blocks(B, T);
   const long long stride = (long long)(K + 1) * C;
+  // (one launch for both when they take the row-parallel path of fs2hip_reduce_slabs anyway: same sums, same order)
+  if (dbias && stride <= 16384 && nblk >= 8)
+    return fs2_reduce_rows(partial, nblk, (int)stride, stride, dw, K * C, dbias, (hipStream_t)stream);
   int rc = fs2hip_reduce_slabs(partial, dw, (long long)K * C, nblk, stride, stream);
   if (rc) return rc;
   if (dbias) rc = fs2hip_reduce_slabs(partial + (long long)K * C, dbias, C, nblk, stride, stream);

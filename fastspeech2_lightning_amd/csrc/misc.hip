@@ -443,6 +443,8 @@ extern "C" int fs2hip_rowdot_bwd(const float* dout, const float* x, const float*
   const int nblk = fs2hip_rowdot_blocks(M);
   rowdot_bwd_kernel<<<dim3(nblk), dim3(256), 0, S_>>>(dout, x, w, lens, dx, partial, M, T, C);
   FS2_LAUNCH_CHECK();
+  if (C + 1 <= 16384 && nblk >= 8)  // (both sums in one launch: the path fs2hip_reduce_slabs would take for each)
+    return fs2_reduce_rows(partial, nblk, C + 1, C + 1, dw, C, dbias, S_);
   int rc = fs2hip_reduce_slabs(partial, dw, C, nblk, C + 1, stream);
   if (rc) return rc;
   return fs2hip_reduce_slabs(partial + C, dbias, 1, nblk, C + 1, stream);

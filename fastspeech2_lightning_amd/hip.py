@@ -220,7 +220,11 @@ def _workspace(n: int, device) -> torch.Tensor:
 
 
 SPLITK_COUNTERS = 4096  # FS2_SPLITK_COUNTERS
-SPLITK_IN_KERNEL = os.environ.get("FS2_SPLITK_IN_KERNEL", "1") != "0"  # measurement aid: "0" = separate reduce launch
+#: "1": the weight-gradient GEMMs finish their split reduction themselves (Fs2GemmArgs.counters; 140 fewer launches per
+#: step, bit-identical sums).  Off by default: measured time-neutral for the step (19.78 ms either way) while the GEMM
+#: launches get 6 % longer (device-coherent slab stores + the last workgroup's tail)
+SPLITK_IN_KERNEL = os.environ.get("FS2_SPLITK_IN_KERNEL", "0") != "0"
+SPLITK_MAX = int(os.environ.get("FS2_SPLITK_MAX", 16))
 _COUNTERS = {}
 
 
@@ -508,7 +512,9 @@ def linear_bwd_data(dy, w, *, epi=EPI_STORE, act=None, aux=None, alpha=1.0, drop
 
 def pick_splitk(Mc: int, Nc: int, R: int, taps: int = 1) -> int:
     tiles = ((Mc + 127) // 128) * ((Nc + 63) // 64) * taps
-    s = max(1, min(64, 512 // max(tiles, 1)))
+    # at most 16 slices: beyond that the slab traffic and the finish outweigh the extra workgroups (tools/splitk_sweep.py,
+    # 20736-row reduction: 256x256 output 67 us at 64 slices, 42 at 16; 80x256 57 -> 40; wider outputs unchanged)
+    s = max(1, min(SPLITK_MAX, 512 // max(tiles, 1)))
     if taps > 1:
         # conv weight gradients: at least one reduction chunk per XCD -- the slices are ordered (split, tap), so the taps
         # of a chunk (same dY rows, X rows shifted by one) then share that XCD's L2 instead of every (tap, split) slice
