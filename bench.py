@@ -401,7 +401,8 @@ def main():
                  "steps": n_split,
                  "note": "every GEMM operand cut exactly into three bf16 planes in registers, six partial products per "
                          "product on v_mfma_f32_32x32x16_bf16, fp32 accumulation: the fp32 kernels' error bound (same parity "
-                         "tests, same tolerances); attention, normalisations, losses and the optimizer unchanged"}
+                         "tests, same tolerances); the attention forward and dQ products the same way, dK/dV on the fp32 MFMAs; "
+                                 "normalisations, losses and the optimizer unchanged"}
         log(f"32-split: {dt * 1e3:.2f} ms/step")
     cpu = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
