@@ -1,0 +1,58 @@
+// bf16 operand storage for the "bf16-mixed" GEMMs (Fs2GemmArgs.operand_bf16 == 3): casts of fp32 tensors to the
+// k-contiguous bf16 rows the GEMM core reads -- weights once per step (as stored, and transposed for the data-gradient
+// GEMM), activations where their producer does not emit the bf16 copy itself.  HBM-bound: 4 B read + 2 B written per
+// element.  Rounding is to nearest even (v_cvt_pk_bf16_f32), as in the register-rounding mode.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x8_t __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst,
+                                                         long long n8) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+    const f32x4 a = reinterpret_cast<const f32x4*>(src)[2 * i], b = reinterpret_cast<const f32x4*>(src)[2 * i + 1];
+    const f32x8_t v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    reinterpret_cast<bf16x8_t*>(dst)[i] = __builtin_convertvector(v, bf16x8_t);
+  }
+}
+
+// dst[c][r] = bf16(src[r][c]) for a [rows][cols] matrix: 64 x 64 tiles through LDS (padded against bank conflicts),
+// reads and writes both contiguous.  dst rows are ld_dst elements apart; the pad columns rows..ld_dst-1 are zeroed.
+__global__ __launch_bounds__(256) void transpose_cast_bf16_kernel(const float* __restrict__ src, int rows, int cols,
+                                                                   int ld_src, __bf16* __restrict__ dst, int ld_dst) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? src[(long long)r * ld_src + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < cols && r < ld_dst) dst[(long long)c * ld_dst + r] = (__bf16)tile[tx][i];
+  }
+}
+
+}  // namespace
+
+extern "C" int fs2hip_cast_bf16(const float* src, void* dst, long long n, void* stream) {
+  if (n <= 0 || (n % 8) || ((uintptr_t)src % 16) || ((uintptr_t)dst % 16)) return FS2HIP_EINVAL;
+  const long long n8 = n / 8;
+  long long blocks = (n8 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  cast_bf16_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(src, (__bf16*)dst, n8);
+  FS2_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fs2hip_transpose_cast_bf16(const float* src, int rows, int cols, int ld_src, void* dst, int ld_dst,
+                                          void* stream) {
+  if (rows <= 0 || cols <= 0 || ld_src < cols || ld_dst < rows) return FS2HIP_EINVAL;
+  dim3 grid((cols + 63) / 64, (ld_dst + 63) / 64);
+  transpose_cast_bf16_kernel<<<grid, dim3(256), 0, (hipStream_t)stream>>>(src, rows, cols, ld_src, (__bf16*)dst, ld_dst);
+  FS2_LAUNCH_CHECK();
+  return 0;
+}

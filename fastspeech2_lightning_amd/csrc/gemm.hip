@@ -201,6 +201,19 @@ extern "C" int fs2hip_gemm(const Fs2GemmArgs* args, void* stream) {
   // dimension covers the rounded-up width: the float4 that straddles the edge stays inside the row)
   if (a.a_kcontig ? (a.R / (a.shift_operand == 0 ? a.taps : 1)) % 4 : a.lda < ((a.Mc + 3) / 4) * 4) return FS2HIP_EINVAL;
   if (a.b_kcontig ? (a.R / (a.shift_operand == 0 ? a.taps : 1)) % 4 : a.ldb < ((a.Nc + 3) / 4) * 4) return FS2HIP_EINVAL;
+  if (a.operand_bf16 == 3) {
+    // A and B hold bf16 (k-contiguous rows, leading dimensions and R in bf16 elements): from here on the reduction is
+    // counted in 4-byte slots of two elements, which is all the loaders of core v2 need to know
+    if (!a.a_kcontig || !a.b_kcontig || a.splitk != 1 || (a.R % 8) || (a.lda % 8) || (a.ldb % 8) || (a.b_tap_stride % 2) ||
+        (a.taps > 1 && (a.shift_operand != 0 || (a.R / a.taps) % 64)))
+      return FS2HIP_EINVAL;
+    a.R /= 2;
+    a.lda /= 2;
+    a.ldb /= 2;
+    a.b_tap_stride /= 2;
+  } else if (a.operand_bf16 < 0 || a.operand_bf16 > 3) {
+    return FS2HIP_EINVAL;
+  }
   p.Rper = a.R;
   if (a.taps > 1) {
     if (a.T <= 0 || a.Mc <= 0) return FS2HIP_EINVAL;
@@ -243,6 +256,7 @@ extern "C" int fs2hip_gemm(const Fs2GemmArgs* args, void* stream) {
     const bool odd_taps = a.taps > 1 && (a.shift_operand == 0 ? (p.Rper % 32) != 0 : a.T < 32);
     tile = v2_ok ? (odd_taps ? (v1_ok && !a.operand_bf16 ? 3 : 7) : (narrow ? 5 : 4)) : (narrow ? 2 : 1);  // (core v1 is fp32 only)
   }
+  if (a.operand_bf16 == 3 && (tile < 4 || tile > 9)) return FS2HIP_EINVAL;  // the one-tile-per-workgroup direct-to-LDS core only
   if (tile >= 4) {
     if (!v2_ok) return FS2HIP_EINVAL;
     return tile >= 10 ? fs2_gemm2p_launch(p, tile, nz, s) : fs2_gemm2_launch(p, tile, nz, s);

@@ -122,10 +122,12 @@ int launch_tile(GemmP& p, int nz, hipStream_t s) {
   if ((long long)p.tiles_m * p.tiles_n * nz > 0x7fffffffLL) return FS2HIP_EINVAL;
   dim3 grid(p.tiles_m * p.tiles_n * nz), block(256);
   int mode = TAPS_NONE;
+  if (a.operand_bf16 == 3 && !(a.a_kcontig && a.b_kcontig)) return FS2HIP_EINVAL;
   if (a.taps > 1) {
     if (a.shift_operand == 0) mode = (p.Rper % BK2 == 0) ? TAPS_RED : TAPS_GENERIC;
     else mode = a.T >= BK2 ? TAPS_ROWS : TAPS_GENERIC;
   }
+  if (mode == TAPS_GENERIC && a.operand_bf16 == 3) return FS2HIP_EINVAL;
   if (mode == TAPS_GENERIC) {
     if constexpr (GENERIC_TOO) {
       if (a.a_kcontig && a.b_kcontig) FS2_GO(true, true, TAPS_GENERIC);
@@ -136,7 +138,11 @@ int launch_tile(GemmP& p, int nz, hipStream_t s) {
       return FS2HIP_EINVAL;  // odd tap widths: only the 64x64 2-stage tile carries the generic decode
     }
   } else if (a.a_kcontig && a.b_kcontig) {  // forward: taps only as TAPS_RED
-    if (mode == TAPS_RED) FS2_GO(true, true, TAPS_RED);
+    if (a.operand_bf16 == 3) {  // bf16 in memory: these two instances only
+      if (mode == TAPS_RED) gemm2_kernel<BM, BN, true, true, NST, TAPS_RED, 3><<<grid, block, 0, s>>>(p);
+      else if (mode == TAPS_NONE) gemm2_kernel<BM, BN, true, true, NST, TAPS_NONE, 3><<<grid, block, 0, s>>>(p);
+      else return FS2HIP_EINVAL;
+    } else if (mode == TAPS_RED) FS2_GO(true, true, TAPS_RED);
     else if (mode == TAPS_NONE) FS2_GO(true, true, TAPS_NONE);
     else return FS2HIP_EINVAL;
   } else if (a.a_kcontig && !a.b_kcontig) {  // backward data

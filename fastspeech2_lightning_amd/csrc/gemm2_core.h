@@ -508,11 +508,51 @@ __device__ __forceinline__ void compute_ktile_split(f32x16 (&acc)[BM / 64][BN / 
   __builtin_amdgcn_sched_group_barrier(0x008, 6 * TM * TN, 0);
 }
 
-// BF: 0 = fp32 MFMA, 1 = operands rounded to bf16 ("bf16-mixed"), 2 = three-plane split ("32-split")
+// Operands that ARE bf16 in memory (Fs2GemmArgs.operand_bf16 == 3; both k-contiguous).  The loader is the fp32 one
+// with the reduction counted in 4-byte slots: a row of a K-tile is still one 128-byte line, now 64 reduction steps
+// deep, and the 16-byte chunk (2g + h) a lane half reads for "group g" is exactly the eight bf16 (k = 16g + 8h .. +7)
+// v_mfma_f32_32x32x16_bf16 wants from it: four MFMAs per accumulator and K-tile, no conversion, half the HBM, L2 and
+// LDS bytes per flop of the register-rounding mode.
+template <int BM, int BN>
+__device__ __forceinline__ void compute_ktile_bf16s(f32x16 (&acc)[BM / 64][BN / 64], const RdAddr<BM, true>& rda,
+                                                    const RdAddr<BN, true>& rdb, unsigned sa, unsigned sb) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  Frag<TM, true> fa[4];
+  Frag<TN, true> fb[4];
+  constexpr int RD = TM + TN;
+  frag_read<0, BM>(fa[0], rda, sa);
+  frag_read<0, BN>(fb[0], rdb, sb);
+  frag_read<1, BM>(fa[1], rda, sa);
+  frag_read<1, BN>(fb[1], rdb, sb);
+  frag_read<2, BM>(fa[2], rda, sa);
+  frag_read<2, BN>(fb[2], rdb, sb);
+  frag_read<3, BM>(fa[3], rda, sa);
+  frag_read<3, BN>(fb[3], rdb, sb);
+#define FS2_STEP(G)                                                                                              \
+  {                                                                                                              \
+    lds_wait<(3 - G) * RD>();                                                                                    \
+    fa[G].pin_all();                                                                                             \
+    fb[G].pin_all();                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                               \
+    _Pragma("unroll") for (int jn = 0; jn < TN; ++jn)                                                            \
+        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[G].q[i]),             \
+                                                             __builtin_bit_cast(bf16x8, fb[G].q[jn]), acc[i][jn], 0, 0, 0); \
+  }
+  FS2_STEP(0)
+  FS2_STEP(1)
+  FS2_STEP(2)
+  FS2_STEP(3)
+#undef FS2_STEP
+}
+
+// BF: 0 = fp32 MFMA, 1 = operands rounded to bf16 ("bf16-mixed"), 2 = three-plane split ("32-split"), 3 = bf16 in memory
 template <int BF, int BM, int BN, bool AKC, bool BKC>
 __device__ __forceinline__ void compute_ktile_any(f32x16 (&acc)[BM / 64][BN / 64], const RdAddr<BM, AKC>& rda,
                                                   const RdAddr<BN, BKC>& rdb, unsigned sa, unsigned sb) {
-  if constexpr (BF == 2) compute_ktile_split<BM, BN, AKC, BKC>(acc, rda, rdb, sa, sb);
+  if constexpr (BF == 3) {
+    static_assert(AKC && BKC, "bf16 storage: k-contiguous operands only");
+    compute_ktile_bf16s<BM, BN>(acc, rda, rdb, sa, sb);
+  } else if constexpr (BF == 2) compute_ktile_split<BM, BN, AKC, BKC>(acc, rda, rdb, sa, sb);
   else if constexpr (BF == 1) compute_ktile_bf16<BM, BN, AKC, BKC>(acc, rda, rdb, sa, sb);
   else compute_ktile<BM, BN, AKC, BKC>(acc, rda, rdb, sa, sb);
 }

@@ -87,6 +87,8 @@ SIGNATURES = {
     "fs2hip_grad_clip_coef": "pqffppp",
     "fs2hip_adamw_step": "ppppqpffffp",
     "fs2hip_axpby": "pppqfffQpp",
+    "fs2hip_cast_bf16": "ppqp",
+    "fs2hip_transpose_cast_bf16": "piiipip",
     "fs2hip_add_rowvec": "pppiiip",
     "fs2hip_dact_mul": "pppqip",
     "fs2hip_mask_from_lens": "ppiip",
@@ -427,7 +429,8 @@ def _gemm(_algorithmic=True, **kw):
     if not a.workspace:  # scratch for the split-tail tiles (13-15): at most one slab of partial sums per workgroup slot
         ws = _workspace(HYBRID_WS_FLOATS, _current_device())
         a.workspace, a.workspace_floats = _p(ws), ws.numel()
-    a.operand_bf16 = int(GEMM_BF16) if _algorithmic else 0
+    if not a.operand_bf16:  # (3 = bf16 operands in memory: set by the caller that passes bf16 tensors)
+        a.operand_bf16 = int(GEMM_BF16) if _algorithmic else 0
     a.tile = _tune_tile(a)
     if GEMM_PROFILE is None or not _algorithmic:  # (the one-hot embedding GEMM's flops are not algorithmic)
         _launch_gemm(a)
@@ -439,8 +442,9 @@ def _gemm(_algorithmic=True, **kw):
     ntap = a.taps if a.shift_operand == 1 else 1
     # algorithmic bytes: every operand element read once, every output element written once
     ra = a.R // a.taps if (a.taps > 1 and a.shift_operand == 0) else a.R
-    nbytes = 4.0 * (a.Mc * ra + a.Nc * a.R + a.Mc * a.Nc * ntap
-                    + (a.Mc * a.Nc if a.resid else 0) + (a.Mc * a.Nc if a.aux else 0) + (a.Mc * a.Nc if a.out_pre else 0))
+    esz = 2.0 if a.operand_bf16 == 3 else 4.0
+    nbytes = esz * (a.Mc * ra + a.Nc * a.R) + 4.0 * (a.Mc * a.Nc * ntap + (a.Mc * a.Nc if a.resid else 0)
+                                                     + (a.Mc * a.Nc if a.aux else 0) + (a.Mc * a.Nc if a.out_pre else 0))
     GEMM_PROFILE.append((e0, e1, 2.0 * a.Mc * a.Nc * a.R * ntap, a.Mc, a.Nc, a.R * ntap, nbytes,
                          (a.a_kcontig, a.b_kcontig, a.taps, a.shift_operand, a.splitk, a.epi, a.tile)))
 
@@ -449,8 +453,10 @@ def linear_fwd(x, w, bias=None, *, epi=EPI_STORE, act=None, resid=None, res_scal
                drop: Drop = NO_DROP, taps=1, T=0, out=None):
     """y[M, N] = epi(x[M, K*] @ w^T + bias).  ``w`` is [N, K] (taps == 1) or
     [taps, N, Kper] for a k-tap convolution over time (rows of x are (b, t), 'same' padding)."""
-    _chk(x, name="x"); _chk(w, name="w")
+    stored = x.dtype == torch.bfloat16  # bf16 operand storage: x and w hold bf16 (cast_bf16 / the producers' copies)
+    _chk(x, x.dtype if stored else torch.float32, "x"); _chk(w, x.dtype if stored else torch.float32, "w")
     M, Kper = _rows(x), x.shape[-1]
+    _req(not stored or (Kper % 8 == 0 and (taps == 1 or Kper % 64 == 0)), "linear_fwd: bf16 rows must be whole 16-byte pieces")
     if taps == 1:
         _req(w.dim() == 2 and w.shape[1] == Kper, f"linear_fwd: x has {Kper} columns, w is {tuple(w.shape)}")
         N = w.shape[0]
@@ -465,7 +471,7 @@ def linear_fwd(x, w, bias=None, *, epi=EPI_STORE, act=None, resid=None, res_scal
     kw = dict(A=_p(x), B=_p(w), C=_p(out), Mc=M, Nc=N, R=Kper * taps, lda=Kper, ldb=Kper, ldc=N,
               a_kcontig=1, b_kcontig=1, taps=taps, T=T, tap_mul=1, tap_add=-((taps - 1) // 2), shift_operand=0,
               b_tap_stride=N * Kper, epi=epi, act=_ACT[act], drop_p=drop.p, drop_seed=drop.seed,
-              drop_step=drop.step_ptr)
+              drop_step=drop.step_ptr, operand_bf16=3 if stored else 0)
     if bias is not None:
         _chk(bias, name="bias")
         _req(bias.numel() == N, "linear_fwd: bias size")
@@ -485,9 +491,14 @@ def linear_fwd(x, w, bias=None, *, epi=EPI_STORE, act=None, resid=None, res_scal
 def linear_bwd_data(dy, w, *, epi=EPI_STORE, act=None, aux=None, alpha=1.0, drop: Drop = NO_DROP,
                     taps=1, T=0, out=None):
     """dx[M, K] = epi(alpha * dy[M, N] @ w) with w [N, K] (or [taps, N, Kper], transposed conv)."""
-    _chk(dy, name="dy"); _chk(w, name="w")
+    stored = dy.dtype == torch.bfloat16  # bf16 operand storage: dy in bf16 and w TRANSPOSED, [K, N] in bf16
+    _chk(dy, dy.dtype if stored else torch.float32, "dy"); _chk(w, dy.dtype if stored else torch.float32, "w")
     M, N = _rows(dy), dy.shape[-1]
-    if taps == 1:
+    if stored:
+        _req(taps == 1 and w.dim() == 2 and w.shape[1] == N and N % 8 == 0,
+             "linear_bwd_data: bf16 operands need the transposed weight [K, N] (no taps)")
+        K = w.shape[0]
+    elif taps == 1:
         _req(w.dim() == 2 and w.shape[0] == N, "linear_bwd_data: dy columns != w rows")
         K = w.shape[1]
     else:
@@ -502,11 +513,38 @@ def linear_bwd_data(dy, w, *, epi=EPI_STORE, act=None, aux=None, alpha=1.0, drop
               a_kcontig=1, b_kcontig=0, taps=taps, T=T, tap_mul=-1, tap_add=(taps - 1) // 2, shift_operand=0,
               b_tap_stride=N * K, epi=epi, act=_ACT[act], alpha=float(alpha),
               drop_p=drop.p, drop_seed=drop.seed, drop_step=drop.step_ptr)
+    if stored:
+        kw.update(ldb=N, b_kcontig=1, tap_mul=1, tap_add=0, operand_bf16=3)
     if epi == EPI_DACT:
         _chk(aux, name="aux")
         _req(aux.shape == out.shape, "linear_bwd_data: aux shape")
         kw.update(aux=_p(aux), ldaux=K)
     _gemm(**kw)
+    return out
+
+
+def cast_bf16(x, out=None):
+    """bf16 copy (round to nearest even) of an fp32 tensor whose size is a multiple of 8."""
+    _chk(x, name="x")
+    _req(x.numel() % 8 == 0, "cast_bf16: size must be a multiple of 8")
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    _chk(out, torch.bfloat16, "out")
+    _req(out.numel() == x.numel(), "cast_bf16: output size")
+    _ok(lib().fs2hip_cast_bf16(_p(x), _p(out), x.numel(), _stream()), "cast_bf16")
+    return out
+
+
+def transpose_cast_bf16(w, out=None):
+    """[R, C] fp32 -> [C, R] bf16 (R a multiple of 8): the weight as the data-gradient GEMM's k-contiguous operand."""
+    _chk(w, name="w")
+    _req(w.dim() == 2 and w.shape[0] % 8 == 0, "transpose_cast_bf16: [R, C] with R a multiple of 8")
+    R, Cc = w.shape
+    if out is None:
+        out = torch.empty(Cc, R, device=w.device, dtype=torch.bfloat16)
+    _chk(out, torch.bfloat16, "out")
+    _req(out.numel() == R * Cc, "transpose_cast_bf16: output size")
+    _ok(lib().fs2hip_transpose_cast_bf16(_p(w), R, Cc, Cc, _p(out), R, _stream()), "transpose_cast_bf16")
     return out
 
 

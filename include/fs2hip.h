@@ -106,7 +106,10 @@ typedef struct {
                        product is the six partial products a_i b_j with i + j <= 2, accumulated in fp32, smallest first
                        (what is dropped is below the rounding of the fp32 product): the error bound of mode 0 at
                        2.7x its matrix-pipe rate.  Only the direct-to-LDS cores (tile >= 4) carry modes 1 and 2;
-                       shapes those cores refuse run in fp32 */
+                       shapes those cores refuse run in fp32.  3: bf16 operand STORAGE -- A and B point to bf16
+                       (k-contiguous rows: a_kcontig = b_kcontig = 1; lda, ldb, R, b_tap_stride in bf16 elements, all
+                       multiples of 8, tap widths multiples of 64; no split-K), C, bias and the epilogue tensors stay
+                       fp32; tiles 4..9 */
 } Fs2GemmArgs;
 #define FS2_SPLITK_COUNTERS 4096
 
@@ -278,6 +281,12 @@ int fs2hip_grad_clip_coef(const float* grad, long long n, float max_norm, float 
                           void* state, void* stream);
 int fs2hip_adamw_step(float* p, const float* g, float* m, float* v, long long n, const void* state,
                       float beta1, float beta2, float eps, float weight_decay, void* stream);
+
+/* bf16 operand storage (Fs2GemmArgs.operand_bf16 == 3; Lightning's `precision="bf16-mixed"` autocast copies in the
+ * reference): dst = bf16(src), round to nearest even, n % 8 == 0; and dst[c][r] = bf16(src[r][c]) for a [rows][cols]
+ * matrix with rows ld_src apart, dst rows ld_dst >= rows elements apart (pad columns zeroed). */
+int fs2hip_cast_bf16(const float* src, void* dst, long long n, void* stream);
+int fs2hip_transpose_cast_bf16(const float* src, int rows, int cols, int ld_src, void* dst, int ld_dst, void* stream);
 
 /* out = a * x * dropmask + b * y (y may be NULL);  out[b,t,:] = x[b,t,:] + e[b,:] */
 int fs2hip_axpby(const float* x, const float* y, float* out, long long n, float a, float b, float drop_p,
