@@ -161,9 +161,17 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
   stats[3 * C + c] = invstd;
 }
 
+// four fp32 -> four bf16 (round to nearest even), 8 bytes
+typedef __bf16 bn_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_bf16x4(void* dst, long long i4, float4 v) {
+  const f32x4 f = {v.x, v.y, v.z, v.w};
+  reinterpret_cast<bn_bf16x4*>(dst)[i4] = __builtin_convertvector(f, bn_bf16x4);
+}
+
+// out_b (may be null): a bf16 copy of the output for a GEMM that takes bf16 operands from memory (operand_bf16 == 3)
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ y, const float* __restrict__ stats,
-                                                          float* __restrict__ out, long long n4, int C, int act,
-                                                          Fs2Drop drop_in) {
+                                                          float* __restrict__ out, void* __restrict__ out_b, long long n4,
+                                                          int C, int act, Fs2Drop drop_in) {
   const Fs2Drop drop = fs2_resolve_drop(drop_in);
   const int c4n = C >> 2;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
@@ -177,6 +185,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
     o.z = fs2_act(act, fmaf(v.z, sc.z, sh.z)) * fs2_drop_factor(drop, (unsigned long long)(i * 4 + 2));
     o.w = fs2_act(act, fmaf(v.w, sc.w, sh.w)) * fs2_drop_factor(drop, (unsigned long long)(i * 4 + 3));
     reinterpret_cast<float4*>(out)[i] = o;
+    if (out_b) store_bf16x4(out_b, i, o);
   }
 }
 
@@ -243,8 +252,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
 // dy = scale * (dz - mean(dz) - xhat * mean(dz*xhat))   [training]   or scale * dz   [eval]
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ y,
                                                             const float* __restrict__ stats, const float* __restrict__ coef,
-                                                            float* __restrict__ dy, long long n4, int C, int act,
-                                                            Fs2Drop drop_in, int training) {
+                                                            float* __restrict__ dy, void* __restrict__ dy_b, long long n4,
+                                                            int C, int act, Fs2Drop drop_in, int training) {
   const Fs2Drop drop = fs2_resolve_drop(drop_in);
   const int c4n = C >> 2;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
@@ -265,7 +274,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
       dz.z = dz.z - k1.z - (v.z - mu.z) * is.z * k2.z;
       dz.w = dz.w - k1.w - (v.w - mu.w) * is.w * k2.w;
     }
-    reinterpret_cast<float4*>(dy)[i] = make_float4(sc.x * dz.x, sc.y * dz.y, sc.z * dz.z, sc.w * dz.w);
+    const float4 o = make_float4(sc.x * dz.x, sc.y * dz.y, sc.z * dz.z, sc.w * dz.w);
+    reinterpret_cast<float4*>(dy)[i] = o;
+    if (dy_b) store_bf16x4(dy_b, i, o);
   }
 }
 
@@ -306,24 +317,47 @@ extern "C" int fs2hip_bn_finalize(const float* partial, int nparts, long long co
   return 0;
 }
 
+extern "C" int fs2hip_bn_act_fwd_b(const float* y, const float* stats, float* out, void* out_bf16, int M, int C, int act,
+                                   float drop_p, unsigned long long drop_seed, const unsigned long long* drop_step,
+                                   void* stream);
 extern "C" int fs2hip_bn_act_fwd(const float* y, const float* stats, float* out, int M, int C, int act, float drop_p,
                                  unsigned long long drop_seed, const unsigned long long* drop_step, void* stream) {
-  if (M <= 0 || C <= 0 || (C % 4) || ((uintptr_t)y % 16) || ((uintptr_t)out % 16) || ((uintptr_t)stats % 16))
+  return fs2hip_bn_act_fwd_b(y, stats, out, nullptr, M, C, act, drop_p, drop_seed, drop_step, stream);
+}
+
+extern "C" int fs2hip_bn_act_fwd_b(const float* y, const float* stats, float* out, void* out_bf16, int M, int C, int act,
+                                   float drop_p, unsigned long long drop_seed, const unsigned long long* drop_step,
+                                   void* stream) {
+  if (M <= 0 || C <= 0 || (C % 4) || ((uintptr_t)y % 16) || ((uintptr_t)out % 16) || ((uintptr_t)stats % 16) ||
+      ((uintptr_t)out_bf16 % 8))
     return FS2HIP_EINVAL;
   const long long n4 = (long long)M * C / 4;
   long long blocks = (n4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  bn_act_fwd_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(y, stats, out, n4, C, act,
+  bn_act_fwd_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(y, stats, out, out_bf16, n4, C, act,
                                                                                      fs2_make_drop(drop_p, drop_seed, drop_step));
   FS2_LAUNCH_CHECK();
   return 0;
 }
 
 // partial: [fs2hip_colstats_parts(M)][2][C]; coef: [2][C] scratch (16-byte aligned)
+extern "C" int fs2hip_bn_act_bwd_b(const float* dout, const float* y, const float* stats, float* partial, float* coef,
+                                   float* dgamma, float* dbeta, float* dy, void* dy_bf16, int M, int C, int act,
+                                   float drop_p, unsigned long long drop_seed, const unsigned long long* drop_step,
+                                   int training, void* stream);
 extern "C" int fs2hip_bn_act_bwd(const float* dout, const float* y, const float* stats, float* partial, float* coef,
                                  float* dgamma, float* dbeta, float* dy, int M, int C, int act, float drop_p,
                                  unsigned long long drop_seed, const unsigned long long* drop_step, int training,
                                  void* stream) {
+  return fs2hip_bn_act_bwd_b(dout, y, stats, partial, coef, dgamma, dbeta, dy, nullptr, M, C, act, drop_p, drop_seed,
+                             drop_step, training, stream);
+}
+
+extern "C" int fs2hip_bn_act_bwd_b(const float* dout, const float* y, const float* stats, float* partial, float* coef,
+                                   float* dgamma, float* dbeta, float* dy, void* dy_bf16, int M, int C, int act,
+                                   float drop_p, unsigned long long drop_seed, const unsigned long long* drop_step,
+                                   int training, void* stream) {
+  if ((uintptr_t)dy_bf16 % 8) return FS2HIP_EINVAL;
   WideMap wm;
   if (M <= 0 || C <= 0 || !wide_ok(C, wm)) return FS2HIP_EINVAL;
   if (((uintptr_t)dout % 16) || ((uintptr_t)y % 16) || ((uintptr_t)stats % 16) || ((uintptr_t)partial % 16) ||
@@ -339,7 +373,7 @@ extern "C" int fs2hip_bn_act_bwd(const float* dout, const float* y, const float*
   const long long n4 = (long long)M * C / 4;
   long long blocks = (n4 + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  bn_bwd_apply_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(dout, y, stats, coef, dy, n4, C, act, drop, training);
+  bn_bwd_apply_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(dout, y, stats, coef, dy, dy_bf16, n4, C, act, drop, training);
   FS2_LAUNCH_CHECK();
   return 0;
 }

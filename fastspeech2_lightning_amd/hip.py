@@ -71,6 +71,8 @@ SIGNATURES = {
     "fs2hip_bn_finalize": "piqiippppffipip",
     "fs2hip_bn_act_fwd": "pppiiifQpp",
     "fs2hip_bn_act_bwd": "ppppppppiiifQpip",
+    "fs2hip_bn_act_fwd_b": "ppppiiifQpp",
+    "fs2hip_bn_act_bwd_b": "pppppppppiiifQpip",
     "fs2hip_posenc_table": "ppiip",
     "fs2hip_add_posenc": "ppppiiip",
     "fs2hip_embedding_fwd": "pppiiip",
@@ -259,6 +261,10 @@ GEMM_TUNE = os.environ.get("FS2_GEMM_TUNE", "1") != "0"
 #: registers and a product is the six partial products that matter, accumulated in fp32 (csrc/gemm2_core.h); the
 #: GEMM family only (attention stays on the fp32 MFMA), same error bound as "32-true" (tests/test_gemm_split_gpu.py).
 GEMM_BF16 = 0
+#: "bf16-mixed" only: GEMMs whose operands can be had as bf16 in memory without an extra pass (today: the PostNet
+#: convolutions, whose inputs / output gradients come from the BatchNorm kernels) read them as such
+#: (Fs2GemmArgs.operand_bf16 = 3) instead of rounding fp32 operands in registers.  "0" = measurement aid.
+BF16_STORAGE = os.environ.get("FS2_BF16_STORAGE", "1") != "0"
 PRECISIONS = {"32-true": 0, "32": 0, "fp32": 0, "bf16-mixed": 1, "bf16": 1, "32-split": 2}
 
 
@@ -494,10 +500,14 @@ def linear_bwd_data(dy, w, *, epi=EPI_STORE, act=None, aux=None, alpha=1.0, drop
     stored = dy.dtype == torch.bfloat16  # bf16 operand storage: dy in bf16 and w TRANSPOSED, [K, N] in bf16
     _chk(dy, dy.dtype if stored else torch.float32, "dy"); _chk(w, dy.dtype if stored else torch.float32, "w")
     M, N = _rows(dy), dy.shape[-1]
-    if stored:
-        _req(taps == 1 and w.dim() == 2 and w.shape[1] == N and N % 8 == 0,
-             "linear_bwd_data: bf16 operands need the transposed weight [K, N] (no taps)")
+    if stored and taps == 1:
+        _req(w.dim() == 2 and w.shape[1] == N and N % 8 == 0,
+             "linear_bwd_data: bf16 operands need the transposed weight [K, N]")
         K = w.shape[0]
+    elif stored:
+        _req(w.dim() == 3 and w.shape[0] == taps and w.shape[2] == N and N % 64 == 0 and T > 0 and M % T == 0,
+             "linear_bwd_data: bf16 operands need the per-tap transposed conv weight [taps, Kper, N], N a multiple of 64")
+        K = w.shape[1]
     elif taps == 1:
         _req(w.dim() == 2 and w.shape[0] == N, "linear_bwd_data: dy columns != w rows")
         K = w.shape[1]
@@ -513,8 +523,8 @@ def linear_bwd_data(dy, w, *, epi=EPI_STORE, act=None, aux=None, alpha=1.0, drop
               a_kcontig=1, b_kcontig=0, taps=taps, T=T, tap_mul=-1, tap_add=(taps - 1) // 2, shift_operand=0,
               b_tap_stride=N * K, epi=epi, act=_ACT[act], alpha=float(alpha),
               drop_p=drop.p, drop_seed=drop.seed, drop_step=drop.step_ptr)
-    if stored:
-        kw.update(ldb=N, b_kcontig=1, tap_mul=1, tap_add=0, operand_bf16=3)
+    if stored:  # NT on the transposed weight(s); the transposed convolution keeps its reversed tap order
+        kw.update(ldb=N, b_kcontig=1, operand_bf16=3)
     if epi == EPI_DACT:
         _chk(aux, name="aux")
         _req(aux.shape == out.shape, "linear_bwd_data: aux shape")
@@ -831,17 +841,19 @@ def bn_finalize(parts: Optional[StatParts], gamma, beta, running_mean, running_v
     return stats
 
 
-def bn_act_fwd(y, stats, act=None, drop: Drop = NO_DROP):
+def bn_act_fwd(y, stats, act=None, drop: Drop = NO_DROP, bf16_copy=False):
+    """``bf16_copy``: returns (out, out as bf16) -- the copy a bf16-operand GEMM (``linear_fwd`` on bf16 tensors) reads."""
     _chk(y, name="y"); _chk(stats, name="stats")
     M, Cc = _rows(y), y.shape[-1]
     _req(stats.numel() == 4 * Cc, "bn_act_fwd: stats size")
     out = torch.empty_like(y)
-    _ok(lib().fs2hip_bn_act_fwd(_p(y), _p(stats), _p(out), M, Cc, _ACT[act], drop.p, drop.seed, drop.step_ptr,
-                                _stream()), "bn_act_fwd")
-    return out
+    out_b = torch.empty(y.shape, device=y.device, dtype=torch.bfloat16) if bf16_copy else None
+    _ok(lib().fs2hip_bn_act_fwd_b(_p(y), _p(stats), _p(out), _p(out_b), M, Cc, _ACT[act], drop.p, drop.seed,
+                                  drop.step_ptr, _stream()), "bn_act_fwd")
+    return (out, out_b) if bf16_copy else out
 
 
-def bn_act_bwd(dout, y, stats, dgamma, dbeta, act=None, drop: Drop = NO_DROP, training=True):
+def bn_act_bwd(dout, y, stats, dgamma, dbeta, act=None, drop: Drop = NO_DROP, training=True, bf16_copy=False):
     for n, t in (("dout", dout), ("y", y), ("stats", stats), ("dgamma", dgamma), ("dbeta", dbeta)):
         _chk(t, name=n)
     M, Cc = _rows(y), y.shape[-1]
@@ -851,10 +863,11 @@ def bn_act_bwd(dout, y, stats, dgamma, dbeta, act=None, drop: Drop = NO_DROP, tr
     ws = _workspace(nparts * 2 * Cc + 2 * Cc, y.device)
     coef_ptr = ws.data_ptr() + 4 * nparts * 2 * Cc
     dy = torch.empty_like(y)
-    _ok(lib().fs2hip_bn_act_bwd(_p(dout), _p(y), _p(stats), _p(ws), coef_ptr, _p(dgamma), _p(dbeta), _p(dy), M,
-                                Cc, _ACT[act], drop.p, drop.seed, drop.step_ptr, int(training), _stream()),
+    dy_b = torch.empty(y.shape, device=y.device, dtype=torch.bfloat16) if bf16_copy else None
+    _ok(lib().fs2hip_bn_act_bwd_b(_p(dout), _p(y), _p(stats), _p(ws), coef_ptr, _p(dgamma), _p(dbeta), _p(dy), _p(dy_b),
+                                  M, Cc, _ACT[act], drop.p, drop.seed, drop.step_ptr, int(training), _stream()),
         "bn_act_bwd")
-    return dy
+    return (dy, dy_b) if bf16_copy else dy
 
 
 # ------------------------------------------------------------------------------------------

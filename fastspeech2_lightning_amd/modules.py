@@ -648,17 +648,28 @@ class PostNet:
             S.add(b, (chans[i + 1],), "id", P.init_bias_for(chans[i] * k))
             self.convs.append((w, b, BatchNorm(S, q + "1.", chans[i + 1]), env.new_site()))
 
+    def _stored(self):
+        """bf16-mixed with operand storage: a convolution whose input (forward) or output gradient (backward) has a
+        channel count that fills whole K-tiles per tap reads it as bf16 from memory -- the BatchNorm kernel that
+        produces it writes the bf16 copy in the same pass; the weights are cast when they are used."""
+        return H.GEMM_BF16 == 1 and H.BF16_STORAGE
+
     def fwd(self, x):
         S, env = self.S, self.env
         B, T, _ = x.shape
         saved = []
+        xb = None  # bf16 copy of x, when the layer that produced it was asked for one
         for i, (w, b, bn, site) in enumerate(self.convs):
-            raw = H.linear_fwd(x, S.p(w), S.p(b), taps=self.k, T=T)
+            if xb is not None:
+                raw = H.linear_fwd(xb.view(B * T, -1), H.cast_bf16(S.p(w)), S.p(b), taps=self.k, T=T).view(B, T, -1)
+            else:
+                raw = H.linear_fwd(x, S.p(w), S.p(b), taps=self.k, T=T)
             stats = bn.stats(H.colstats(raw) if env.training else None, env.training)
             act = "tanh" if i < self.n - 1 else None
-            out = H.bn_act_fwd(raw, stats, act, env.drop(self.dropout_p, site))
+            want_b = self._stored() and i + 1 < self.n and raw.shape[-1] % 64 == 0
+            out = H.bn_act_fwd(raw, stats, act, env.drop(self.dropout_p, site), bf16_copy=want_b)
             saved.append((x, raw, stats))
-            x = out
+            x, xb = out if want_b else (out, None)
         return x, saved
 
     def bwd(self, dy, saved, need_dx=True):
@@ -669,10 +680,20 @@ class PostNet:
             x, raw, stats = saved[i]
             gg, gb = bn.grads()
             act = "tanh" if i < self.n - 1 else None
-            draw = H.bn_act_bwd(dy, raw, stats, gg, gb, act, env.drop(self.dropout_p, site), training=env.training)
+            need = i > 0 or need_dx
+            want_b = need and self._stored() and raw.shape[-1] % 64 == 0
+            draw = H.bn_act_bwd(dy, raw, stats, gg, gb, act, env.drop(self.dropout_p, site), training=env.training,
+                                bf16_copy=want_b)
+            draw, draw_b = draw if want_b else (draw, None)
             with env.side(draw, x):
                 H.linear_bwd_weight(draw, x, S.g(w), taps=self.k, T=T)
                 H.colsum_grad(draw, S.g(b))
-            if i > 0 or need_dx:
+            if need and draw_b is not None:
+                wk = S.p(w)  # [taps, Cout, Cin] -> per tap [Cin, Cout] in bf16
+                wt = torch.empty(self.k, wk.shape[2], wk.shape[1], device=wk.device, dtype=torch.bfloat16)
+                for t in range(self.k):
+                    H.transpose_cast_bf16(wk[t], wt[t])
+                dy = H.linear_bwd_data(draw_b.view(B * T, -1), wt, taps=self.k, T=T).view(B, T, -1)
+            elif need:
                 dy = H.linear_bwd_data(draw, S.p(w), taps=self.k, T=T)
         return dy

@@ -224,6 +224,13 @@ int fs2hip_bn_act_bwd(const float* dout, const float* y, const float* stats, flo
                       float* dgamma, float* dbeta, float* dy, int M, int C, int act, float drop_p,
                       unsigned long long drop_seed, const unsigned long long* drop_step, int training,
                       void* stream);
+/* The same two with a second, bf16 copy of the output (out_bf16 / dy_bf16, [M][C] bf16, may be NULL) for a consuming GEMM
+ * that reads bf16 operands from memory (Fs2GemmArgs.operand_bf16 == 3): the PostNet convolutions in "bf16-mixed". */
+int fs2hip_bn_act_fwd_b(const float* y, const float* stats, float* out, void* out_bf16, int M, int C, int act,
+                        float drop_p, unsigned long long drop_seed, const unsigned long long* drop_step, void* stream);
+int fs2hip_bn_act_bwd_b(const float* dout, const float* y, const float* stats, float* partial, float* coef,
+                        float* dgamma, float* dbeta, float* dy, void* dy_bf16, int M, int C, int act, float drop_p,
+                        unsigned long long drop_seed, const unsigned long long* drop_step, int training, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Positional table / embeddings / bucketize  (fs2/layers.py:123-140, fs2/model.py:183-193,

@@ -96,3 +96,40 @@ def test_refused_shapes(H):
     x, w = rnd(64, 100, seed=1).bfloat16().cuda(), rnd(32, 100, seed=2).bfloat16().cuda()
     with pytest.raises((RuntimeError, ValueError)):
         H.linear_fwd(x, w)  # 100 bf16 per row: not whole 16-byte pieces
+
+
+def test_postnet_reads_bf16_operands_from_memory_in_bf16_mixed(H):
+    """bf16-mixed, PostNet: the four 512-channel convolutions take their input (forward) and three of them their output
+    gradient (data gradient) as the bf16 copy the BatchNorm kernels write, instead of rounding the fp32 tensor in
+    registers.  Same rounded operands, same products; the summation order differs (64-deep K-tiles), and an fp32
+    difference of 1e-6 upstream flips a bf16 rounding (4e-3) downstream here and there -> a whole train step (dropout on:
+    the copies carry the masks) agrees with the register-rounding mode at the bf16 level: losses 1e-4, all gradients
+    together 1e-2 relative L2 (measured 1.8e-3; the mode's bound against the fp32 oracle is 0.1), and the stored mode
+    really ran."""
+    from fastspeech2_lightning_amd.config import FastSpeech2Config, Stats
+    from fastspeech2_lightning_amd.model import FastSpeech2
+    from fastspeech2_lightning_amd.synthetic import DEFAULT_STATS, synthetic_batch
+    conf = dict(layers=1)
+    config = FastSpeech2Config(model=dict(encoder=conf, decoder=conf, learn_alignment=False),
+                               text=dict(symbols=dict(letters=[f"s{i}" for i in range(40)])))
+    batch = synthetic_batch(B=3, ts_lo=20, ts_hi=40, n_symbols=41, n_mels=80, seed=3, dur_hi=6)
+    res = {}
+    saved = H.BF16_STORAGE
+    try:
+        for stored in (False, True):
+            H.BF16_STORAGE = stored
+            H._TILE_CACHE.clear()
+            model = FastSpeech2(config, Stats(**DEFAULT_STATS), seed=11, precision="bf16-mixed")
+            model.train()
+            model.training_step(batch)
+            res[stored] = (dict(model.last_losses), {k: v.clone() for k, v in model.store.grad_state_dict().items()},
+                           {key[9] for key in H._TILE_CACHE})
+    finally:
+        H.BF16_STORAGE = saved
+        H._TILE_CACHE.clear()
+    assert 3 in res[True][2] and 3 not in res[False][2], "operand_bf16 == 3 launches: only in the stored mode"
+    for k, v in res[False][0].items():
+        assert abs(float(res[True][0][k]) - float(v)) < 1e-4 * max(1.0, abs(float(v))), k
+    num = sum(float((res[True][1][k] - g).pow(2).sum()) for k, g in res[False][1].items())
+    den = sum(float(g.pow(2).sum()) for g in res[False][1].values())
+    assert (num / den) ** 0.5 < 1e-2, (num / den) ** 0.5
