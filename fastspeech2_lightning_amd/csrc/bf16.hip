@@ -23,6 +23,8 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void transpose_cast_bf16_kernel(const float* __restrict__ src, int rows, int cols,
                                                                    int ld_src, __bf16* __restrict__ dst, int ld_dst) {
   __shared__ float tile[64][65];
+  src += (long long)blockIdx.z * rows * ld_src;  // (batch of matrices: the taps of a convolution weight)
+  dst += (long long)blockIdx.z * cols * ld_dst;
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int i = ty; i < 64; i += 4) {
@@ -49,9 +51,9 @@ extern "C" int fs2hip_cast_bf16(const float* src, void* dst, long long n, void* 
 }
 
 extern "C" int fs2hip_transpose_cast_bf16(const float* src, int rows, int cols, int ld_src, void* dst, int ld_dst,
-                                          void* stream) {
-  if (rows <= 0 || cols <= 0 || ld_src < cols || ld_dst < rows) return FS2HIP_EINVAL;
-  dim3 grid((cols + 63) / 64, (ld_dst + 63) / 64);
+                                          int batch, void* stream) {
+  if (rows <= 0 || cols <= 0 || ld_src < cols || ld_dst < rows || batch < 1 || batch > 65535) return FS2HIP_EINVAL;
+  dim3 grid((cols + 63) / 64, (ld_dst + 63) / 64, batch);
   transpose_cast_bf16_kernel<<<grid, dim3(256), 0, (hipStream_t)stream>>>(src, rows, cols, ld_src, (__bf16*)dst, ld_dst);
   FS2_LAUNCH_CHECK();
   return 0;

@@ -38,12 +38,20 @@ __global__ __launch_bounds__(256) void colstats_wide_kernel(const float* __restr
   float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0), pv = make_float4(0, 0, 0, 0);
   if (rl < wm.rpi) {
     pv = *reinterpret_cast<const float4*>(y + (long long)r0 * C + c4 * 4);
-    for (int r = r0 + rl; r < r1; r += wm.rpi) {
-      float4 v = *reinterpret_cast<const float4*>(y + (long long)r * C + c4 * 4);
+    auto add = [&](float4 v) {
       v.x -= pv.x; v.y -= pv.y; v.z -= pv.z; v.w -= pv.w;
       s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
       s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
+    };
+    int r = r0 + rl;
+    for (; r + 3 * wm.rpi < r1; r += 4 * wm.rpi) {  // four rows' loads in flight per thread, added in row order
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(y + (long long)(r + u * wm.rpi) * C + c4 * 4);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) add(v[u]);
     }
+    for (; r < r1; r += wm.rpi) add(*reinterpret_cast<const float4*>(y + (long long)r * C + c4 * 4));
   }
   red[0][tid] = s1;
   red[1][tid] = s2;
@@ -208,15 +216,31 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   if (rl < wm.rpi) {
     const float4 sc = reinterpret_cast<const float4*>(stats)[c4], sh = reinterpret_cast<const float4*>(stats + C)[c4];
     const float4 mu = reinterpret_cast<const float4*>(stats + 2 * C)[c4], is = reinterpret_cast<const float4*>(stats + 3 * C)[c4];
-    for (int r = r0 + rl; r < r1; r += wm.rpi) {
-      const long long idx = (long long)r * C + c4 * 4;
-      const float4 v = *reinterpret_cast<const float4*>(y + idx);
-      const float4 d = *reinterpret_cast<const float4*>(dout + idx);
+    auto add = [&](long long idx, const float4& v, const float4& d) {
       float dz;
       dz = dz_of(d.x, v.x, sc.x, sh.x, act, drop, idx + 0); s1.x += dz; s2.x += dz * (v.x - mu.x) * is.x;
       dz = dz_of(d.y, v.y, sc.y, sh.y, act, drop, idx + 1); s1.y += dz; s2.y += dz * (v.y - mu.y) * is.y;
       dz = dz_of(d.z, v.z, sc.z, sh.z, act, drop, idx + 2); s1.z += dz; s2.z += dz * (v.z - mu.z) * is.z;
       dz = dz_of(d.w, v.w, sc.w, sh.w, act, drop, idx + 3); s1.w += dz; s2.w += dz * (v.w - mu.w) * is.w;
+    };
+    int r = r0 + rl;
+    // a part is one workgroup per 64 rows, i.e. about five wavefronts per CU: four rows' loads in flight per thread
+    // (the sums are added in the same row order as before)
+    for (; r + 3 * wm.rpi < r1; r += 4 * wm.rpi) {
+      long long idx[4];
+      float4 v[4], d[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        idx[u] = (long long)(r + u * wm.rpi) * C + c4 * 4;
+        v[u] = *reinterpret_cast<const float4*>(y + idx[u]);
+        d[u] = *reinterpret_cast<const float4*>(dout + idx[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) add(idx[u], v[u], d[u]);
+    }
+    for (; r < r1; r += wm.rpi) {
+      const long long idx = (long long)r * C + c4 * 4;
+      add(idx, *reinterpret_cast<const float4*>(y + idx), *reinterpret_cast<const float4*>(dout + idx));
     }
   }
   red[0][tid] = s1;

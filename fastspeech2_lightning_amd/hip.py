@@ -90,7 +90,7 @@ SIGNATURES = {
     "fs2hip_adamw_step": "ppppqpffffp",
     "fs2hip_axpby": "pppqfffQpp",
     "fs2hip_cast_bf16": "ppqp",
-    "fs2hip_transpose_cast_bf16": "piiipip",
+    "fs2hip_transpose_cast_bf16": "piiipiip",
     "fs2hip_add_rowvec": "pppiiip",
     "fs2hip_dact_mul": "pppqip",
     "fs2hip_mask_from_lens": "ppiip",
@@ -546,15 +546,17 @@ def cast_bf16(x, out=None):
 
 
 def transpose_cast_bf16(w, out=None):
-    """[R, C] fp32 -> [C, R] bf16 (R a multiple of 8): the weight as the data-gradient GEMM's k-contiguous operand."""
+    """[R, C] fp32 -> [C, R] bf16 (R a multiple of 8): the weight as the data-gradient GEMM's k-contiguous operand;
+    [taps, R, C] -> [taps, C, R] for a convolution weight (one launch)."""
     _chk(w, name="w")
-    _req(w.dim() == 2 and w.shape[0] % 8 == 0, "transpose_cast_bf16: [R, C] with R a multiple of 8")
-    R, Cc = w.shape
+    _req(w.dim() in (2, 3) and w.shape[-2] % 8 == 0, "transpose_cast_bf16: [R, C] or [taps, R, C] with R a multiple of 8")
+    R, Cc = w.shape[-2:]
+    batch = w.shape[0] if w.dim() == 3 else 1
     if out is None:
-        out = torch.empty(Cc, R, device=w.device, dtype=torch.bfloat16)
+        out = torch.empty(*w.shape[:-2], Cc, R, device=w.device, dtype=torch.bfloat16)
     _chk(out, torch.bfloat16, "out")
-    _req(out.numel() == R * Cc, "transpose_cast_bf16: output size")
-    _ok(lib().fs2hip_transpose_cast_bf16(_p(w), R, Cc, Cc, _p(out), R, _stream()), "transpose_cast_bf16")
+    _req(out.numel() == w.numel(), "transpose_cast_bf16: output size")
+    _ok(lib().fs2hip_transpose_cast_bf16(_p(w), R, Cc, Cc, _p(out), R, batch, _stream()), "transpose_cast_bf16")
     return out
 
 

@@ -689,10 +689,7 @@ class PostNet:
                 H.linear_bwd_weight(draw, x, S.g(w), taps=self.k, T=T)
                 H.colsum_grad(draw, S.g(b))
             if need and draw_b is not None:
-                wk = S.p(w)  # [taps, Cout, Cin] -> per tap [Cin, Cout] in bf16
-                wt = torch.empty(self.k, wk.shape[2], wk.shape[1], device=wk.device, dtype=torch.bfloat16)
-                for t in range(self.k):
-                    H.transpose_cast_bf16(wk[t], wt[t])
+                wt = H.transpose_cast_bf16(S.p(w))  # [taps, Cout, Cin] -> per tap [Cin, Cout] in bf16
                 dy = H.linear_bwd_data(draw_b.view(B * T, -1), wt, taps=self.k, T=T).view(B, T, -1)
             elif need:
                 dy = H.linear_bwd_data(draw, S.p(w), taps=self.k, T=T)

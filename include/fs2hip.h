@@ -291,9 +291,11 @@ int fs2hip_adamw_step(float* p, const float* g, float* m, float* v, long long n,
 
 /* bf16 operand storage (Fs2GemmArgs.operand_bf16 == 3; Lightning's `precision="bf16-mixed"` autocast copies in the
  * reference): dst = bf16(src), round to nearest even, n % 8 == 0; and dst[c][r] = bf16(src[r][c]) for a [rows][cols]
- * matrix with rows ld_src apart, dst rows ld_dst >= rows elements apart (pad columns zeroed). */
+ * matrix with rows ld_src apart, dst rows ld_dst >= rows elements apart (pad columns zeroed), for `batch` matrices
+ * stored back to back (the taps of a convolution weight). */
 int fs2hip_cast_bf16(const float* src, void* dst, long long n, void* stream);
-int fs2hip_transpose_cast_bf16(const float* src, int rows, int cols, int ld_src, void* dst, int ld_dst, void* stream);
+int fs2hip_transpose_cast_bf16(const float* src, int rows, int cols, int ld_src, void* dst, int ld_dst, int batch,
+                               void* stream);
 
 /* out = a * x * dropmask + b * y (y may be NULL);  out[b,t,:] = x[b,t,:] + e[b,:] */
 int fs2hip_axpby(const float* x, const float* y, float* out, long long n, float a, float b, float drop_p,

@@ -34,6 +34,9 @@ def test_casts(H):
     w = rnd(264, 100, seed=2)
     wt = H.transpose_cast_bf16(w.cuda())
     assert wt.shape == (100, 264) and torch.equal(wt.cpu(), w.t().contiguous().bfloat16())
+    w3 = rnd(5, 72, 130, seed=3)
+    w3t = H.transpose_cast_bf16(w3.cuda())
+    assert w3t.shape == (5, 130, 72) and torch.equal(w3t.cpu(), w3.transpose(1, 2).contiguous().bfloat16())
 
 
 @pytest.mark.parametrize("tile", [4, 5, 6, 7, 8, 9, None])
