@@ -208,7 +208,12 @@ class FeedForward:
 class SelfAttention:
     """LayerNorm -> nn.MultiheadAttention(key_padding_mask) -> Dropout; y = x + f(x)."""
 
+    HEAD_DIMS = (16, 32, 64, 128)  # what the attention kernels are built for (fs2hip_attention_fwd refuses the rest)
+
     def __init__(self, S, env: Env, prefix, d, heads, p):
+        if heads <= 0 or d % heads or d // heads not in self.HEAD_DIMS:
+            raise ValueError(f"Conformer attention: input_dim {d} / heads {heads} gives a head dimension of "
+                             f"{d / max(heads, 1):g}; this build has attention kernels for head dimensions {self.HEAD_DIMS}")
         self.S, self.env, self.p, self.heads = S, env, p, heads
         self.ln = LayerNorm(S, prefix + "self_attn_layer_norm.", d)
         a = prefix + "self_attn."

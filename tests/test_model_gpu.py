@@ -371,3 +371,14 @@ def test_five_optimizer_steps_in_bf16_mixed_stay_close_to_fp32():
         totals.append(float(model.last_losses["total"]))
     assert totals[-1] < 0.8 * totals[0], totals
     assert all(bool(torch.isfinite(v).all()) for v in model.state_dict().values() if v.dtype.is_floating_point)
+
+
+def test_unsupported_head_dimension_is_refused_at_construction():
+    """A Conformer whose input_dim / heads is not one of the head dimensions the attention kernels are built for fails
+    when the model is built, with the reason -- not with an error code in the middle of the first step."""
+    from fastspeech2_lightning_amd.config import FastSpeech2Config
+    from fastspeech2_lightning_amd.model import FastSpeech2
+    config = FastSpeech2Config(model=dict(encoder=dict(layers=1, heads=3), decoder=dict(layers=1), learn_alignment=False),
+                               text=dict(symbols=dict(letters=[f"s{i}" for i in range(40)])))
+    with pytest.raises(ValueError, match="head dimension"):
+        FastSpeech2(config, Stats(**C.STATS))
