@@ -340,7 +340,10 @@ def main():
         # (tools/pmc_traffic.py): they cannot be collected from inside the process, so the committed figure carries
         # the hash of the kernel sources it was measured on and is only reported while that hash matches the tree
         traffic, traffic_src = None, "no profiles/*gemm_traffic.json for this tree"
-        for tfile in sorted((REPO / "profiles").glob("r*_gemm_traffic.json"), reverse=True):
+        default_cfg = (args.precision == "32-true" and args.batch == 32 and not args.gst and not args.learn_alignment)
+        if not default_cfg:  # the committed counter passes were taken on the default configuration only
+            traffic_src = "profiles/*_gemm_traffic.json is measured on the default configuration (32-true, batch 32)"
+        for tfile in (sorted((REPO / "profiles").glob("r*_gemm_traffic.json"), reverse=True) if default_cfg else ()):
             t = json.loads(tfile.read_text())
             if t.get("kernel_source_hash") == kernel_source_hash():
                 traffic = round(t["hbm_bytes_per_launch"])

@@ -114,6 +114,8 @@ def decl_norm(S: P.ParamStore, prefix):
 
 class LayerNorm:
     def __init__(self, S: P.ParamStore, prefix, dim):
+        if dim % 4 or not 0 < dim <= 1024:
+            raise ValueError(f"LayerNorm over {dim} channels: the kernels take widths that are multiples of 4, up to 1024")
         self.S, self.w, self.b, self.dim = S, prefix + "weight", prefix + "bias", dim
         S.add(self.w, (dim,), "id", P.init_ones)
         S.add(self.b, (dim,), "id", P.init_zeros)
@@ -260,7 +262,11 @@ class ConvModule:
     """LayerNorm -> Conv1d(D,2D,1) -> GLU -> depthwise Conv1d(k) -> BatchNorm1d -> SiLU -> Conv1d(D,D,1)
     -> Dropout; y = x + f(x)."""
 
+    KERNEL_SIZES = (3, 5, 7, 9, 15, 31)  # depthwise-convolution widths the kernels are instantiated for
+
     def __init__(self, S, env: Env, prefix, d, k, p):
+        if k not in self.KERNEL_SIZES:
+            raise ValueError(f"Conformer convolution module: depthwise kernel size {k}; this build carries {self.KERNEL_SIZES}")
         self.S, self.env, self.p, self.k, self.d = S, env, p, k, d
         self.ln = LayerNorm(S, prefix + "layer_norm.", d)
         q = prefix + "sequential."
