@@ -17,7 +17,9 @@ The JSON line also carries
                  launch duration, measured live with HIP events on the launch stream, against the
                  157.3 TFLOP/s fp32 matrix peak;
   cpu_baseline : the CPU oracle (pure-PyTorch restatement of the reference, ``oracle/``) timed on this
-                 box's host cores on a bounded sample of the same workload (rank 0, N = 1 only).
+                 box's host cores on a bounded sample of the same workload (rank 0, N = 1 only);
+  split_fp32, bf16_mixed_b64, learn_alignment : the same step in the other configurations of BASELINE.json / the
+                 reference (N = 1, default flags only; >= 20 timed steps each) -- reported beside ``value``, never as it.
 """
 from __future__ import annotations
 
@@ -137,14 +139,21 @@ def spawn_ranks(n: int) -> int:
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+    # rank 0's stdout is drained by a thread while all ranks are polled: a rank that dies must not leave the others
+    # (and this process) waiting in a rendezvous or a collective until the process-group timeout
+    import threading
+    from fastspeech2_lightning_amd.cli import wait_ranks
+    buf = []
+    t = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    t.start()
+    code = wait_ranks(procs)
+    t.join(10)
+    sys.stdout.write(b"".join(buf).decode())
     sys.stdout.flush()
-    return max(abs(c) for c in codes)
+    return code
 
 
-def main():
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200,
@@ -162,14 +171,232 @@ def main():
     ap.add_argument("--gst", action="store_true",
                     help="BASELINE.json configs[4] shape in fp32: multi-speaker (16) + GST style encoder, mel up to ~1200 frames")
     ap.add_argument("--precision", default="32-true", choices=["32-true", "32-split", "bf16-mixed"],
-                    help="bf16-mixed = BASELINE.json configs[2] (use with --batch 64): GEMM operands rounded to bf16 for the bf16 "
-                         "MFMA, fp32 accumulation / parameters / activations.  The headline metric is quoted on 32-true")
+                    help="bf16-mixed = BASELINE.json configs[2] (use with --batch 64): bf16 MFMA operands, fp32 accumulation / "
+                         "parameters / optimizer.  The headline metric is quoted on 32-true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-split-line", action="store_true", help="skip the secondary 32-split measurement")
+    ap.add_argument("--no-split-line", "--no-extra-legs", dest="no_extra_legs", action="store_true",
+                    help="skip the secondary measurements (32-split, bf16-mixed batch 64, learned alignment)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--learn-alignment", action="store_true",
                     help="reference default config: jointly learned alignment (aligner + MAS + CTC/bin losses)")
-    args = ap.parse_args()
+    return ap
+
+
+def config_signature(args) -> dict:
+    """What a counter profile (profiles/*_gemm_traffic.json) was measured on: reported only for the same configuration."""
+    return {"precision": args.precision, "batch": args.batch, "gst": bool(args.gst),
+            "learn_alignment": bool(args.learn_alignment)}
+
+
+class Rig:
+    """One model + resident synthetic batch + optimizer, and the step the benchmark times."""
+
+    def __init__(self, precision, batch_size, learn_alignment=False, gst=False, rank=0, world=1, local=0, force_sync=False):
+        from fastspeech2_lightning_amd.config import Stats
+        from fastspeech2_lightning_amd.model import FastSpeech2
+        from fastspeech2_lightning_amd.parallel import GradSync
+        from fastspeech2_lightning_amd.synthetic import DEFAULT_STATS, synthetic_batch
+
+        self.config = make_config(learn_alignment, gst)
+        spk = {f"spk{i}": i for i in range(16)} if gst else None
+        self.model = FastSpeech2(self.config, Stats(**DEFAULT_STATS), speaker2id=spk, device=f"cuda:{local}", seed=1234,
+                                 precision=precision)
+        self.model.train()
+        self.opt = self.model.configure_optimizers()[0][0]
+        self.model.configure_gradient_clipping(self.opt, 1.0, "norm")  # Trainer(gradient_clip_val=1.0), fs2/cli/train.py:38
+        # every rank gets the N = 1 batch's structure (lengths and durations: the same padded shapes, i.e. the same work
+        # per GPU -- weak scaling) with its own contents; rank 0's batch is exactly the single-GPU one
+        self.batch = synthetic_batch(B=batch_size, ts_lo=96, ts_hi=128, n_symbols=64, n_mels=80, seed=1234,
+                                     content_seed=None if rank == 0 else 1234 + rank,
+                                     dur_hi=18 if gst else 9, learn_alignment=learn_alignment)
+        if gst:
+            self.batch["speaker_id"] = torch.arange(batch_size, dtype=torch.int32) % 16
+        self.sync = None
+        if world > 1 or force_sync:
+            self.sync = GradSync(self.model.store, force=force_sync)
+            self.sync.broadcast_parameters(0)
+            self.model.data_parallel(self.sync, rank)
+            self.opt.grad_scale = self.sync.grad_scale
+        self.dev_batch = self.model.prepare_batch(self.batch)  # inputs resident in HBM before the timed region
+        self.frames = int(self.batch["mel_lens"].sum())
+        self.padded = int(self.batch["mel"].shape[0] * self.batch["mel"].shape[1])
+        self.wait_events = None  # N > 1: (before, after) HIP events around every GradSync.wait() of the timed steps
+
+    def step(self):
+        with torch.no_grad():  # the native loop: the optimizer reads the flat gradient buffer, no autograd node
+            self.model.training_step(self.dev_batch)
+        if self.sync:
+            if self.wait_events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self.sync.wait()
+                e1.record()
+                self.wait_events.append((e0, e1))
+            else:
+                self.sync.wait()
+        self.opt.step()
+
+    def timed(self, steps, run=None):
+        run = run or self.step
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    def step_flops(self):
+        """SURVEY.md 8d closed form on the padded shapes, backward = 2 x forward."""
+        b = self.batch
+        Bq, Ts_p, Tm_p = int(b["text"].shape[0]), int(b["text"].shape[1]), int(b["mel"].shape[1])
+        f = 3.0 * (Bq * Ts_p * (4 * (3019264 + 1024 * Ts_p) + 1990656)
+                   + Bq * Tm_p * (4 * (3019264 + 1024 * Tm_p) + 40960 + 8683520))
+        if self.config.model.learn_alignment:
+            f += 3.0 * Bq * (Ts_p * 868352 + Tm_p * (115200 + 240 * Ts_p))
+        return f
+
+
+def gemm_profile(rig, record=True):
+    """Live measurement of the dominant kernel family: HIP events around every GEMM launch of one eager step, on the
+    launch stream.  Every rank runs the steps (they contain the collectives); ``record`` says who keeps the events.
+    A GPU-side spin first, so that the host runs ahead and the events bracket device time only.  The side stream is
+    switched off for these two steps: with two streams a GEMM shares the chip with another kernel and its own launch
+    duration says nothing about the kernel.  Returns (launch records, event-pair overhead in ms)."""
+    from fastspeech2_lightning_amd import hip as H
+    model = rig.model
+    side_was, model.env.side_enabled = model.env.side_enabled, False
+    H.GEMM_PROFILE = [] if record else None
+    rig.step()
+    torch.cuda.synchronize()
+    H.GEMM_PROFILE = [] if record else None
+    torch.cuda._sleep(int(0.06 * 2.0e9))
+    rig.step()
+    torch.cuda.synchronize()
+    prof, H.GEMM_PROFILE = H.GEMM_PROFILE, None
+    model.env.side_enabled = side_was
+    if not record:
+        return None, 0.0
+    # A HIP event pair costs device time of its own (two marker packets the command processor serialises with the
+    # kernel between them).  It is measured in the same run -- pairs with nothing in between, each behind a kernel so
+    # that the queue is busy as it is in the step -- and taken off every interval; without it the per-launch
+    # durations come out 3-4 us longer than rocprofv3's kernel durations for the same launches.
+    pairs = []
+    xs = torch.zeros(1 << 20, device=model.device_)
+    for _ in range(40):
+        H.axpby(xs, None, 1.0, 0.0, out=xs)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        e1.record()
+        pairs.append((e0, e1))
+    torch.cuda.synchronize()
+    ov = sorted(a.elapsed_time(b) for a, b in pairs)[len(pairs) // 2]  # median, ms
+    return prof, ov
+
+
+def gemm_numbers(prof, ov):
+    raw_ms = sum(q[0].elapsed_time(q[1]) for q in prof)
+    ms = raw_ms - ov * len(prof)
+    flops = sum(q[2] for q in prof)
+    nbytes = sum(q[6] for q in prof)
+    return {"launches_per_step": len(prof), "avg_launch_us": round(ms * 1e3 / len(prof), 2),
+            "flops_per_launch": round(flops / len(prof)), "algorithmic_bytes_per_launch": round(nbytes / len(prof)),
+            "gemm_ms_per_step": round(ms, 3), "event_pair_overhead_us": round(ov * 1e3, 2),
+            "gemm_ms_per_step_raw_events": round(raw_ms, 3),
+            "_tflops": flops / (ms * 1e-3) / 1e12, "_gbs": nbytes / (ms * 1e-3) / 1e9}
+
+
+def log_gemm_breakdown(prof):
+    by = {}
+    for e0, e1, fl, mc, nc, r, _nb, kind in prof:
+        t, f, n = by.get((mc, nc, r, kind), (0.0, 0.0, 0))
+        by[(mc, nc, r, kind)] = (t + e0.elapsed_time(e1), f + fl, n + 1)
+    for (mc, nc, r, kind), (t, f, n) in sorted(by.items(), key=lambda kv: -kv[1][0])[:48]:
+        ak, bk, taps, sh, sk, epi, tile = kind[:7]
+        log(f"gemm Mc={mc:6d} Nc={nc:5d} R={r:6d} {'NT'[ak]}{'NT'[bk]} taps={taps} sh={sh} splitk={sk:2d} epi={epi} "
+            f"tile={tile} {kind[7:]} x{n:3d}: {t:7.3f} ms  {f / t / 1e9:6.1f} TFLOP/s")
+
+
+def committed_traffic(args):
+    """HBM-side bytes per GEMM launch come from two separate rocprofv3 --pmc passes over this same command
+    (tools/pmc_traffic.py): they cannot be collected from inside the process, so the committed figure carries the hash
+    of the kernel sources and the configuration it was measured on, and is only reported while both match."""
+    want, tree = config_signature(args), kernel_source_hash()
+    reason = "no profiles/*gemm_traffic.json for this configuration"
+    for tfile in sorted((REPO / "profiles").glob("r*_gemm_traffic.json"), reverse=True):
+        t = json.loads(tfile.read_text())
+        cfg = t.get("config")
+        if cfg is None:  # files of rounds 1-2 carry no stamp: by their names, the *_bf16_* ones are bf16-mixed batch 64
+            cfg = ({"precision": "bf16-mixed", "batch": 64, "gst": False, "learn_alignment": False} if "bf16" in tfile.name
+                   else {"precision": "32-true", "batch": 32, "gst": False, "learn_alignment": False})
+        if cfg != want:
+            continue
+        if t.get("kernel_source_hash") == tree:
+            return round(t["hbm_bytes_per_launch"]), (f"profiles/{tfile.name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH "
+                                                     f"doubled; kernel sources {tree}; {cfg})")
+        reason = (f"profiles/{tfile.name} is stale: measured on kernel sources {t.get('kernel_source_hash', 'unstamped')}, "
+                  f"tree is {tree}")
+        break
+    return None, reason
+
+
+def roofline_of(args, precision, prof, ov):
+    g = gemm_numbers(prof, ov)
+    tf, gbs = g.pop("_tflops"), g.pop("_gbs")
+    if precision == "bf16-mixed":
+        # both fractions (SURVEY.md 8d): operand + result bytes against HBM, flops against the dense bf16 MFMA peak.
+        # The ridge is ~310 flop/B; the family's intensity decides which one bounds it.
+        intensity = g["flops_per_launch"] / max(g["algorithmic_bytes_per_launch"], 1)
+        hbm_bound = intensity < PEAK_BF16_MFMA_TFLOPS * 1e3 / PEAK_HBM_GBS
+        r = ({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)}
+             if hbm_bound else
+             {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+              "frac": round(tf / PEAK_BF16_MFMA_TFLOPS, 4)})
+        r.update(traffic=None, flop_per_byte=round(intensity, 1), achieved_tflops=round(tf, 2), achieved_gbs=round(gbs, 1),
+                 frac_of_bf16_mfma_peak=round(tf / PEAK_BF16_MFMA_TFLOPS, 4), frac_of_hbm_peak=round(gbs / PEAK_HBM_GBS, 4),
+                 kernel="gemm family on v_mfma_f32_32x32x16_bf16, fp32 accumulate")
+        r.update(g)
+        return r
+    split_main = precision == "32-split"
+    # 32-split: six bf16 MFMA products per algorithmic product -> the pipe's ceiling for fp32-accurate flops
+    peak = round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1) if split_main else PEAK_FP32_MFMA_TFLOPS
+    r = {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4)}
+    if args is not None:
+        r["traffic"], r["traffic_source"] = committed_traffic(args)
+    else:
+        r["traffic"] = None
+    r["kernel"] = ("gemm2_kernel / gemm2p_kernel family, 32-split instances (6 x v_mfma_f32_32x32x16_bf16 per 32x32x16 block; "
+                   "peak = dense bf16 MFMA peak / 6)" if split_main else
+                   "gemm2_kernel / gemm2p_kernel / gemm_kernel family (fp32 v_mfma_f32_32x32x2_f32), tile autotuned per shape")
+    r.update(g)
+    return r
+
+
+def extra_leg(name, precision, batch_size, learn_alignment, steps, local, want_roofline):
+    """One of the secondary configurations: own model, own batch, warm-up (tile tuning), >= 20 timed steps."""
+    rig = Rig(precision, batch_size, learn_alignment=learn_alignment, local=local)
+    for _ in range(3):
+        rig.step()
+    torch.cuda.synchronize()
+    dt = rig.timed(steps) / steps
+    out = {"precision": precision, "batch_per_gpu": batch_size, "learn_alignment": learn_alignment, "steps": steps,
+           "ms_per_step": round(dt * 1e3, 3), "value": round(rig.frames / dt, 1), "unit": "mel-frames/s",
+           "real_frames_per_step": rig.frames, "padded_frames_per_step": rig.padded}
+    tf = rig.step_flops() / dt / 1e12
+    out["whole_step_tflops"] = round(tf, 2)
+    out["whole_step_frac_of_mfma_peak"] = round(tf / (PEAK_BF16_MFMA_TFLOPS if precision == "bf16-mixed" else PEAK_FP32_MFMA_TFLOPS), 4)
+    if want_roofline:
+        prof, ov = gemm_profile(rig)
+        if os.environ.get("FS2_BENCH_GEMM_BREAKDOWN"):
+            log_gemm_breakdown(prof)
+        out["roofline"] = roofline_of(None, precision, prof, ov)
+    log(f"{name}: {dt * 1e3:.2f} ms/step, {rig.frames / dt:,.0f} mel-frames/s")
+    del rig
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    args = build_parser().parse_args()
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -205,44 +432,17 @@ def main():
             dist.init_process_group(backend)
 
     from fastspeech2_lightning_amd import hip as H
-    from fastspeech2_lightning_amd.config import Stats
-    from fastspeech2_lightning_amd.model import FastSpeech2
-    from fastspeech2_lightning_amd.parallel import GradSync
-    from fastspeech2_lightning_amd.synthetic import DEFAULT_STATS, synthetic_batch
+    from fastspeech2_lightning_amd.parallel import share_tile_table
 
-    config = make_config(args.learn_alignment, args.gst)
-    spk = {f"spk{i}": i for i in range(16)} if args.gst else None
-    model = FastSpeech2(config, Stats(**DEFAULT_STATS), speaker2id=spk, device=f"cuda:{local}", seed=1234,
-                        precision=args.precision)
-    model.train()
-    opt = model.configure_optimizers()[0][0]
-    # every rank gets the N = 1 batch's structure (lengths and durations: the same padded shapes, i.e. the same work per
-    # GPU -- weak scaling) with its own contents; rank 0's batch is exactly the single-GPU one
-    batch = synthetic_batch(B=args.batch, ts_lo=96, ts_hi=128, n_symbols=64, n_mels=80, seed=1234,
-                            content_seed=None if rank == 0 else 1234 + rank,
-                            dur_hi=18 if args.gst else 9, learn_alignment=args.learn_alignment)
-    if args.gst:
-        batch["speaker_id"] = torch.arange(args.batch, dtype=torch.int32) % 16
-    sync = None
     force_sync = bool(os.environ.get("FS2_BENCH_FORCE_SYNC"))  # one rank, collectives issued anyway (RCCL call path)
     if force_sync and world == 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(f"cuda:{local}"))
-    if world > 1 or force_sync:
-        sync = GradSync(model.store, force=force_sync)
-        sync.broadcast_parameters(0)
-        model.data_parallel(sync, rank)
-        opt.grad_scale = sync.grad_scale
-    dev_batch = model.prepare_batch(batch)  # inputs resident in HBM before the timed region
-    frames = int(batch["mel_lens"].sum())
-    padded = int(batch["mel"].shape[0] * batch["mel"].shape[1])
-
-    def step():
-        model.training_step(dev_batch)
-        if sync:
-            sync.wait()
-        opt.step()
+    rig = Rig(args.precision, args.batch, args.learn_alignment, args.gst, rank, world, local, force_sync)
+    model, frames, padded = rig.model, rig.frames, rig.padded
+    step = rig.step
+    f_step, n_params = rig.step_flops(), model.store.num_trainable
 
     def barrier():
         if world > 1:
@@ -254,6 +454,10 @@ def main():
         step()
         torch.cuda.synchronize()
         log(f"warm-up step {i}: {(time.perf_counter() - t_w) * 1e3:.1f} ms")
+        if i == 0 and world > 1:
+            # every rank runs the tiles rank 0 tuned in its first step: same summation order on every rank
+            n_sig = share_tile_table(0)
+            log(f"tile table of rank 0 adopted ({n_sig} signatures)")
 
     use_graph = args.graph and not args.no_graph and world == 1
     model.env.side_enabled = model.env.side_enabled and not use_graph  # (FS2_SIDE_STREAM=0 keeps it off)
@@ -270,6 +474,8 @@ def main():
         log("hipGraph captured and replayed once")
     run = graph.replay if graph is not None else step
 
+    if rig.sync is not None:
+        rig.wait_events = []
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -278,10 +484,16 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    exchange_wait_ms = None
+    if rig.wait_events:
+        # time the main stream spent between "bucket waits enqueued" and "all buckets reduced": what is left of the
+        # exchange after the backward pass it overlaps with (0 = fully hidden)
+        exchange_wait_ms = sum(a.elapsed_time(b) for a, b in rig.wait_events) / len(rig.wait_events)
+    rig.wait_events = None
     if world > 1:
-        t = torch.tensor([elapsed], device=f"cuda:{local}", dtype=torch.float64)
+        t = torch.tensor([elapsed, exchange_wait_ms or 0.0], device=f"cuda:{local}", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
+        elapsed, exchange_wait_ms = float(t[0]), float(t[1])
         f = torch.tensor([frames, padded], device=f"cuda:{local}", dtype=torch.float64)
         dist.all_reduce(f, op=dist.ReduceOp.SUM)
         frames_all, padded_all = int(f[0]), int(f[1])
@@ -292,124 +504,43 @@ def main():
 
     roofline = None
     if not args.no_roofline:
-        # live measurement of the dominant kernel: HIP events around every GEMM launch of an eager step.
-        # Every rank runs the steps (they contain the collectives); rank 0 records.  A GPU-side spin first,
-        # so that the host runs ahead and the events bracket device time only.  The side stream is switched off
-        # for these two steps: with two streams a GEMM shares the chip with another kernel and its own launch
-        # duration says nothing about the kernel.
-        side_was, model.env.side_enabled = model.env.side_enabled, False
-        rec = rank == 0
-        H.GEMM_PROFILE = [] if rec else None
-        step()
-        torch.cuda.synchronize()
-        H.GEMM_PROFILE = [] if rec else None
-        torch.cuda._sleep(int(0.06 * 2.0e9))
-        step()
-        torch.cuda.synchronize()
-        prof, H.GEMM_PROFILE = H.GEMM_PROFILE, None
-        model.env.side_enabled = side_was
-    if roofline is None and not args.no_roofline and rank == 0:
-        if os.environ.get("FS2_BENCH_GEMM_BREAKDOWN"):
-            by = {}
-            for e0, e1, fl, mc, nc, r, _nb, kind in prof:
-                t, f, n = by.get((mc, nc, r, kind), (0.0, 0.0, 0))
-                by[(mc, nc, r, kind)] = (t + e0.elapsed_time(e1), f + fl, n + 1)
-            for (mc, nc, r, kind), (t, f, n) in sorted(by.items(), key=lambda kv: -kv[1][0])[:40]:
-                ak, bk, taps, sh, sk, epi, tile = kind
-                log(f"gemm Mc={mc:6d} Nc={nc:5d} R={r:6d} {'NT'[ak]}{'NT'[bk]} taps={taps} sh={sh} splitk={sk:2d} epi={epi} "
-                    f"tile={tile} x{n:3d}: {t:7.3f} ms  {f / t / 1e9:6.1f} TFLOP/s")
-        # A HIP event pair costs device time of its own (two marker packets the command processor serialises with the
-        # kernel between them).  It is measured in the same run -- pairs with nothing in between, each behind a GEMM so
-        # that the queue is busy as it is in the step -- and taken off every interval; without it the per-launch
-        # durations come out 3-4 us longer than rocprofv3's kernel durations for the same launches.
-        pairs = []
-        xs = torch.zeros(1 << 20, device=f"cuda:{local}")
-        for _ in range(40):
-            H.axpby(xs, None, 1.0, 0.0, out=xs)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            e1.record()
-            pairs.append((e0, e1))
-        torch.cuda.synchronize()
-        ov = sorted(a.elapsed_time(b) for a, b in pairs)[len(pairs) // 2]  # median, ms
-        raw_ms = sum(q[0].elapsed_time(q[1]) for q in prof)
-        ms = raw_ms - ov * len(prof)
-        flops = sum(q[2] for q in prof)
-        achieved = flops / (ms * 1e-3) / 1e12
-        # HBM-side bytes per launch come from two separate rocprofv3 --pmc passes over this same command
-        # (tools/pmc_traffic.py): they cannot be collected from inside the process, so the committed figure carries
-        # the hash of the kernel sources it was measured on and is only reported while that hash matches the tree
-        traffic, traffic_src = None, "no profiles/*gemm_traffic.json for this tree"
-        default_cfg = (args.precision == "32-true" and args.batch == 32 and not args.gst and not args.learn_alignment)
-        if not default_cfg:  # the committed counter passes were taken on the default configuration only
-            traffic_src = "profiles/*_gemm_traffic.json is measured on the default configuration (32-true, batch 32)"
-        for tfile in (sorted((REPO / "profiles").glob("r*_gemm_traffic.json"), reverse=True) if default_cfg else ()):
-            t = json.loads(tfile.read_text())
-            if t.get("kernel_source_hash") == kernel_source_hash():
-                traffic = round(t["hbm_bytes_per_launch"])
-                traffic_src = (f"profiles/{tfile.name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled; "
-                               f"kernel sources {t['kernel_source_hash']})")
-                break
-            traffic_src = (f"profiles/{tfile.name} is stale: measured on kernel sources "
-                           f"{t.get('kernel_source_hash', 'unstamped')}, tree is {kernel_source_hash()}")
-            break
-        bf16 = args.precision == "bf16-mixed"
-        if bf16:
-            # operands and results stay fp32 in HBM, so at the bf16 MFMA rate these GEMMs sit below the ridge point
-            # (~100 flop/B against ~310): the bound is the memory side, and the figure is algorithmic bytes per second
-            nbytes = sum(q[6] for q in prof)
-            gbs = nbytes / (ms * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
-                        "algorithmic_bytes_per_launch": round(nbytes / len(prof)),
-                        "kernel": "gemm2_kernel / gemm2p_kernel family, bf16 operands (v_mfma_f32_32x32x16_bf16), fp32 in HBM and LDS",
-                        "launches_per_step": len(prof), "avg_launch_us": round(ms * 1e3 / len(prof), 2),
-                        "flops_per_launch": round(flops / len(prof)), "achieved_tflops": round(achieved, 2),
-                        "frac_of_bf16_mfma_peak": round(achieved / PEAK_BF16_MFMA_TFLOPS, 4),
-                        "gemm_ms_per_step": round(ms, 3), "event_pair_overhead_us": round(ov * 1e3, 2),
-                        "gemm_ms_per_step_raw_events": round(raw_ms, 3)}
-        else:
-            split_main = args.precision == "32-split"
-            # 32-split: six bf16 MFMA products per algorithmic product -> the pipe's ceiling for fp32-accurate flops
-            peak = round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1) if split_main else PEAK_FP32_MFMA_TFLOPS
-            roofline = {
-                    "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
-                    "algorithmic_bytes_per_launch": round(sum(q[6] for q in prof) / len(prof)),
-                    "kernel": ("gemm2_kernel / gemm2p_kernel family, 32-split instances (6 x v_mfma_f32_32x32x16_bf16 per 32x32x16 block; "
-                               "peak = dense bf16 MFMA peak / 6)" if split_main else
-                               "gemm2_kernel / gemm2p_kernel / gemm_kernel family (fp32 v_mfma_f32_32x32x2_f32), tile autotuned per shape"),
-                    "launches_per_step": len(prof),
-                    "avg_launch_us": round(ms * 1e3 / len(prof), 2), "flops_per_launch": round(flops / len(prof)),
-                    "gemm_ms_per_step": round(ms, 3), "event_pair_overhead_us": round(ov * 1e3, 2),
-                    "gemm_ms_per_step_raw_events": round(raw_ms, 3)}
-
+        prof, ov = gemm_profile(rig, record=rank == 0)
+        if rank == 0:
+            if os.environ.get("FS2_BENCH_GEMM_BREAKDOWN"):
+                log_gemm_breakdown(prof)
+            roofline = roofline_of(args, args.precision, prof, ov)
     log("roofline pass done")
-    # The same step with precision "32-split" (fp32-accurate GEMMs on the bf16 matrix pipe, tests/test_gemm_split_gpu.py):
-    # reported beside the headline, never as it -- `value` above is the exact fp32 MFMA path.
-    split = None
-    if args.precision == "32-true" and world == 1 and not args.no_split_line and graph is None:
+
+    # The other configurations, beside the headline and never as it (`value` above is the exact fp32 MFMA path):
+    #  * 32-split: fp32-accurate GEMMs on the bf16 matrix pipe (tests/test_gemm_split_gpu.py), same model and batch;
+    #  * bf16_mixed_b64: BASELINE.json configs[2];
+    #  * learn_alignment: the reference's default model (fs2/config/__init__.py:139-142).
+    split = bf16_b64 = align = None
+    default_cfg = config_signature(args) == {"precision": "32-true", "batch": 32, "gst": False, "learn_alignment": False}
+    if default_cfg and world == 1 and not args.no_extra_legs and graph is None:
+        n_leg = max(20, args.steps // 4)
         model.precision = "32-split"
         for _ in range(2):
             step()  # (tunes the tiles of the split instances)
-        torch.cuda.synchronize()
-        n_split = max(20, args.steps // 4)
-        t1 = time.perf_counter()
-        for _ in range(n_split):
-            step()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t1) / n_split
+        dt = rig.timed(n_leg) / n_leg
         model.precision = "32-true"
         split = {"precision": "32-split", "ms_per_step": round(dt * 1e3, 3), "value": round(frames / dt, 1), "unit": "mel-frames/s",
-                 "steps": n_split,
-                 "note": "every GEMM operand cut exactly into three bf16 planes in registers, six partial products per "
-                         "product on v_mfma_f32_32x32x16_bf16, fp32 accumulation: the fp32 kernels' error bound (same parity "
-                         "tests, same tolerances); the attention forward and dQ products the same way, dK/dV on the fp32 MFMAs; "
-                                 "normalisations, losses and the optimizer unchanged"}
+                 "steps": n_leg,
+                 "note": "GEMM operands as three exact bf16 planes, six partial products per product on "
+                         "v_mfma_f32_32x32x16_bf16, fp32 accumulation: the fp32 kernels' error bound (same parity tests, same "
+                         "tolerances); the attention forward and dQ products the same way, dK/dV on the fp32 MFMAs; "
+                         "normalisations, losses and the optimizer unchanged"}
         log(f"32-split: {dt * 1e3:.2f} ms/step")
     cpu = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
-        cpu = cpu_baseline(config, batch)
+        cpu_cfg, cpu_batch = rig.config, rig.batch
+    if default_cfg and world == 1 and not args.no_extra_legs and graph is None:
+        del rig, model, step, run
+        torch.cuda.empty_cache()
+        bf16_b64 = extra_leg("bf16_mixed_b64", "bf16-mixed", 64, False, n_leg, local, not args.no_roofline)
+        align = extra_leg("learn_alignment", "32-true", 32, True, n_leg, local, False)
+    if not args.no_cpu_baseline and rank == 0 and world == 1:
+        cpu = cpu_baseline(cpu_cfg, cpu_batch)
         log("cpu baseline done")
 
     if rank == 0:
@@ -420,7 +551,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"32-true": "f32", "32-split": "f32 (GEMM products from three exact bf16 planes per operand, f32 accumulate)",
-                      "bf16-mixed": "bf16 MFMA operands, f32 accumulate / parameters / activations"}[args.precision],
+                      "bf16-mixed": "bf16 MFMA operands, f32 accumulate / parameters / optimizer"}[args.precision],
             "data": "synthetic",
             "config": {"workload": (f"BASELINE.json configs[1]: fp32 train step, batch={args.batch}/GPU" if args.precision != "bf16-mixed" else
                                     f"BASELINE.json configs[2]: bf16-mixed train step, batch={args.batch}/GPU") + ", LJSpeech-shaped synthetic "
@@ -428,25 +559,24 @@ def main():
                                    + (" [--gst: multi-speaker + GST, mel up to ~1200 frames (configs[4] shape, fp32)]" if args.gst else ""),
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "real_frames_per_step": frames_all, "padded_frames_per_step": padded_all,
-                       "precision": args.precision, "parallelism": f"dp{world}", "hipgraph": bool(graph is not None), "streams": 2 if model.env.side_enabled else 1,
-                       "parameters": model.store.num_trainable},
+                       "precision": args.precision, "parallelism": f"dp{world}", "hipgraph": bool(graph is not None),
+                       "streams": 1 if (use_graph or os.environ.get("FS2_SIDE_STREAM", "1") == "0") else 2,
+                       "parameters": n_params},
             "per_gpu_value": round(frames_all * args.steps / elapsed / world, 1),
             "padded_frames_per_s": round(padded_all * args.steps / elapsed, 1),
             "loss_total": round(losses.get("total", float("nan")), 5),
-            "roofline": roofline, "cpu_baseline": cpu, "split_fp32": split,
+            "roofline": roofline, "cpu_baseline": cpu, "split_fp32": split, "bf16_mixed_b64": bf16_b64,
+            "learn_alignment": align,
         }
+        if exchange_wait_ms is not None:
+            line["exchange_wait_ms"] = round(exchange_wait_ms, 3)  # max over ranks of the per-step mean
         # whole-step view (SURVEY.md 8d closed form, padded shapes, backward = 2 x forward): algorithmic FLOPs of the
-        # step / step time against the fp32 MFMA peak -- beside the dominant kernel's own roofline above
-        Bq, Ts_p, Tm_p = int(batch["text"].shape[0]), int(batch["text"].shape[1]), int(batch["mel"].shape[1])
-        f_step = 3.0 * (Bq * Ts_p * (4 * (3019264 + 1024 * Ts_p) + 1990656)
-                        + Bq * Tm_p * (4 * (3019264 + 1024 * Tm_p) + 40960 + 8683520))
-        if args.learn_alignment:
-            f_step += 3.0 * Bq * (Ts_p * 868352 + Tm_p * (115200 + 240 * Ts_p))
+        # step / step time against the MFMA peak -- beside the dominant kernel's own roofline above
         tf = f_step / (ms_per_step * 1e-3) / 1e12
         line["whole_step"] = {"algorithmic_tflop_per_step_per_gpu": round(f_step / 1e12, 4), "achieved_tflops_per_gpu": round(tf, 2)}
         if args.precision != "bf16-mixed":
             line["whole_step"]["frac_of_fp32_mfma_peak"] = round(tf / PEAK_FP32_MFMA_TFLOPS, 4)
-        else:  # (attention and everything outside the GEMM family still computes in fp32)
+        else:
             line["whole_step"]["frac_of_bf16_mfma_peak"] = round(tf / PEAK_BF16_MFMA_TFLOPS, 4)
         print(json.dumps(line), flush=True)
     if world > 1 or force_sync:

@@ -105,7 +105,7 @@ def build_parser() -> argparse.ArgumentParser:
     tr.add_argument("config_file", type=Path)
     tr.add_argument("-c", "--config-args", action="append", default=[], metavar="KEY=VALUE")
     tr.add_argument("-d", "--devices", default="auto", help="GPUs on this node: a count or 'auto' (all visible)")
-    tr.add_argument("--precision", default="32-true", choices=["32-true", "bf16-mixed"])
+    tr.add_argument("--precision", default="32-true", choices=["32-true", "32-split", "bf16-mixed"])
     tr.add_argument("--resume", type=Path, default=None, help="checkpoint to resume from (default: <run dir>/checkpoints/last.ckpt when present)")
     tr.add_argument("--output-dir", type=Path, default=None, help="run directory (default: training.logger.save_dir/name/version)")
     tr.add_argument("--max-steps", type=int, default=None, help="overrides training.max_steps")
@@ -185,10 +185,14 @@ class Trainer:
                 sd = torch.load(finetune, map_location="cpu", weights_only=False)["state_dict"]
                 self.model.load_state_dict(sd)
         self.model.train()
-        self.opt = self.model.configure_optimizers()[0][0]
-        self.opt.max_grad_norm = GRADIENT_CLIP_VAL
+        opts, scheds = self.model.configure_optimizers()
+        self.opt, self.sched = opts[0], scheds[0]["scheduler"]
+        # Trainer(gradient_clip_val=1.0): Lightning passes the value through this hook before every optimizer step;
+        # here it is constant, so once (the clip is part of the fused optimizer launch)
+        self.model.configure_gradient_clipping(self.opt, GRADIENT_CLIP_VAL, "norm")
         if ckpt is not None:
             self.global_step, self.epoch = self.model.restore_training_state(ckpt, self.opt)
+            self.sched.last_epoch = self.opt.steps_done()  # host mirror of the device-resident schedule
             self.best = ckpt.get("fs2l_best_monitor", float("inf"))
             self.batches_in_epoch = int(ckpt.get("fs2l_batches_in_epoch", 0))
         else:
@@ -199,7 +203,7 @@ class Trainer:
             self.sync.broadcast_parameters(0)
             self.model.data_parallel(self.sync, rank)
             self.opt.grad_scale = self.sync.grad_scale
-            # every rank must sum in the same order: rank 0's tuned GEMM tiles are adopted by all once it has them
+        self._tiles_shared = world == 1
         cfg = self.model.config
         self.train_set = FeatureDataset(p["train_rows"], cfg, self.model.lang2id, self.model.speaker2id)
         self.val_set = FeatureDataset(p["val_rows"], cfg, self.model.lang2id, self.model.speaker2id)
@@ -238,12 +242,20 @@ class Trainer:
     # ---- one step -------------------------------------------------------------------------------------------
     def step(self, batch):
         self.model.current_epoch_ = self.epoch
-        self.model.training_step(batch)
+        with torch.no_grad():  # the native loop reads the flat gradient buffer directly: no autograd node needed
+            self.model.training_step(batch)
         if self.sync:
             self.sync.wait()
         self.opt.step()
+        self.sched.step()  # host arithmetic only (the kernels advance the device record themselves)
         self.global_step += 1
         self.batches_in_epoch += 1
+        if not self._tiles_shared:
+            # every rank sums in the same order: the GEMM tiles rank 0 tuned during its first step are adopted by all
+            # (shapes first seen later are tuned per rank; their tiles only change the summation order)
+            from .parallel import share_tile_table
+            share_tile_table(0)
+            self._tiles_shared = True
 
     def log(self, record: dict):
         record = dict(record, step=self.global_step, epoch=self.epoch, time=round(time.time(), 3))
@@ -253,6 +265,7 @@ class Trainer:
             print(json.dumps(record), flush=True)
 
     def log_train(self):
+        self.model.check_bad_data()  # fs2/variance_adaptor.py:289-305, read where the host synchronises anyway
         slots = self.model._loss_slots.cpu()  # the one D2H copy per log interval
         from .model import LOSS_KEYS
         rec = {f"training/{k}_loss": float(slots[i]) for i, k in enumerate(LOSS_KEYS) if k in self.model.last_losses}
@@ -316,6 +329,7 @@ class Trainer:
                 if not self.args.ckpt_every:
                     self.save("last.ckpt")
         torch.cuda.synchronize()
+        self.model.check_bad_data()
         self.save("last.ckpt")
         if self.metrics:
             self.metrics.close()
@@ -335,7 +349,33 @@ def spawn_ranks(n: int, argv: list) -> int:
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, "-m", "fastspeech2_lightning_amd"] + argv, env=env))
-    return max(abs(p.wait()) for p in procs)
+    return wait_ranks(procs)
+
+
+def wait_ranks(procs: list, poll_s: float = 0.2) -> int:
+    """Waits for every rank; when one exits non-zero the others -- which would sit in a rendezvous or a collective
+    until the process-group timeout -- are terminated, and that rank's code is returned."""
+    failed = None
+    while any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            rc = p.poll()
+            if rc not in (None, 0) and failed is None:
+                failed = (r, rc)
+                print(f"rank {r} exited with code {rc}: stopping the other ranks", file=sys.stderr, flush=True)
+                for q in procs:
+                    if q.poll() is None:
+                        q.terminate()
+        time.sleep(poll_s)
+        if failed is not None:
+            deadline = time.time() + 10.0
+            while any(p.poll() is None for p in procs) and time.time() < deadline:
+                time.sleep(poll_s)
+            for q in procs:
+                if q.poll() is None:
+                    q.kill()
+    if failed is not None:
+        return abs(failed[1]) or 1
+    return max((abs(p.returncode) for p in procs), default=0)
 
 
 def train(args, argv) -> int:

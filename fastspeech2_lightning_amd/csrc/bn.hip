@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
     o.y = fs2_act(act, fmaf(v.y, sc.y, sh.y)) * fs2_drop_factor(drop, (unsigned long long)(i * 4 + 1));
     o.z = fs2_act(act, fmaf(v.z, sc.z, sh.z)) * fs2_drop_factor(drop, (unsigned long long)(i * 4 + 2));
     o.w = fs2_act(act, fmaf(v.w, sc.w, sh.w)) * fs2_drop_factor(drop, (unsigned long long)(i * 4 + 3));
-    reinterpret_cast<float4*>(out)[i] = o;
+    if (out) reinterpret_cast<float4*>(out)[i] = o;   // (null: the activations exist only as the bf16 operand)
     if (out_b) store_bf16x4(out_b, i, o);
   }
 }
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
       dz.w = dz.w - k1.w - (v.w - mu.w) * is.w * k2.w;
     }
     const float4 o = make_float4(sc.x * dz.x, sc.y * dz.y, sc.z * dz.z, sc.w * dz.w);
-    reinterpret_cast<float4*>(dy)[i] = o;
+    if (dy) reinterpret_cast<float4*>(dy)[i] = o;
     if (dy_b) store_bf16x4(dy_b, i, o);
   }
 }
@@ -353,7 +353,7 @@ extern "C" int fs2hip_bn_act_fwd_b(const float* y, const float* stats, float* ou
                                    float drop_p, unsigned long long drop_seed, const unsigned long long* drop_step,
                                    void* stream) {
   if (M <= 0 || C <= 0 || (C % 4) || ((uintptr_t)y % 16) || ((uintptr_t)out % 16) || ((uintptr_t)stats % 16) ||
-      ((uintptr_t)out_bf16 % 8))
+      ((uintptr_t)out_bf16 % 8) || (!out && !out_bf16))
     return FS2HIP_EINVAL;
   const long long n4 = (long long)M * C / 4;
   long long blocks = (n4 + 255) / 256;
@@ -381,7 +381,7 @@ extern "C" int fs2hip_bn_act_bwd_b(const float* dout, const float* y, const floa
                                    float* dgamma, float* dbeta, float* dy, void* dy_bf16, int M, int C, int act,
                                    float drop_p, unsigned long long drop_seed, const unsigned long long* drop_step,
                                    int training, void* stream) {
-  if ((uintptr_t)dy_bf16 % 8) return FS2HIP_EINVAL;
+  if (((uintptr_t)dy_bf16 % 8) || (!dy && !dy_bf16)) return FS2HIP_EINVAL;
   WideMap wm;
   if (M <= 0 || C <= 0 || !wide_ok(C, wm)) return FS2HIP_EINVAL;
   if (((uintptr_t)dout % 16) || ((uintptr_t)y % 16) || ((uintptr_t)stats % 16) || ((uintptr_t)partial % 16) ||

@@ -84,9 +84,13 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict
 }
 
 // dy [B*T][C]; x as in the forward; dx has the layout of x.  partial [blk][K+1][C]: dw taps, dbias.
-template <int K, bool GLU>
+// DXB: dx is written as bf16 (the operand of the pointwise convolution's data- and weight-gradient GEMMs)
+__device__ __forceinline__ unsigned short dw_bf16(float v) {
+  return __builtin_bit_cast(unsigned short, (__bf16)v);  // round to nearest even, NaN stays NaN
+}
+template <int K, bool GLU, bool DXB = false>
 __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                          int ldx, const float* __restrict__ w, float* __restrict__ dx,
+                                                          int ldx, const float* __restrict__ w, void* __restrict__ dxv,
                                                           float* __restrict__ partial, int B, int T, int C) {
   constexpr int PAD = (K - 1) / 2, WIN = RUN + K - 1;
   __shared__ float red[4][K + 1][64];
@@ -136,12 +140,22 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict
 #pragma unroll
     for (int k = 0; k < K; ++k) dwk[k] = fmaf(gy, a[o + k], dwk[k]);
     if (cok && t < T) {
-      float* row = dx + ((long long)b * T + t) * ldx;
-      if (GLU) {
-        row[c] = da * sc[o];
-        row[C + c] = da * vc[o] * sc[o] * (1.f - sc[o]);
+      if constexpr (DXB) {
+        unsigned short* row = (unsigned short*)dxv + ((long long)b * T + t) * ldx;
+        if (GLU) {
+          row[c] = dw_bf16(da * sc[o]);
+          row[C + c] = dw_bf16(da * vc[o] * sc[o] * (1.f - sc[o]));
+        } else {
+          row[c] = dw_bf16(da);
+        }
       } else {
-        row[c] = da;
+        float* row = (float*)dxv + ((long long)b * T + t) * ldx;
+        if (GLU) {
+          row[c] = da * sc[o];
+          row[C + c] = da * vc[o] * sc[o] * (1.f - sc[o]);
+        } else {
+          row[c] = da;
+        }
       }
     }
   }
@@ -187,13 +201,28 @@ extern "C" int fs2hip_dwconv_fwd(const float* x, int ldx, const float* w, const 
   return 0;
 }
 
-#define DW_BWD(KK)                                                                                   \
-  if (glu) dwconv_bwd_kernel<KK, true><<<grid, dim3(256), 0, s>>>(dy, x, ldx, w, dx, partial, B, T, C); \
-  else dwconv_bwd_kernel<KK, false><<<grid, dim3(256), 0, s>>>(dy, x, ldx, w, dx, partial, B, T, C);
+#define DW_BWD(KK)                                                                                                \
+  if (dx_bf16) {                                                                                                  \
+    if (glu) dwconv_bwd_kernel<KK, true, true><<<grid, dim3(256), 0, s>>>(dy, x, ldx, w, dx, partial, B, T, C);    \
+    else dwconv_bwd_kernel<KK, false, true><<<grid, dim3(256), 0, s>>>(dy, x, ldx, w, dx, partial, B, T, C);       \
+  } else {                                                                                                        \
+    if (glu) dwconv_bwd_kernel<KK, true><<<grid, dim3(256), 0, s>>>(dy, x, ldx, w, dx, partial, B, T, C);          \
+    else dwconv_bwd_kernel<KK, false><<<grid, dim3(256), 0, s>>>(dy, x, ldx, w, dx, partial, B, T, C);             \
+  }
 
 // partial: [fs2hip_dwconv_blocks(B,T)][K+1][C]; dw [K][C], dbias [C] are finished here
+extern "C" int fs2hip_dwconv_bwd_b(const float* dy, const float* x, int ldx, const float* w, void* dx, int dx_bf16,
+                                   float* partial, float* dw, float* dbias, int B, int T, int C, int K, int glu,
+                                   void* stream);
 extern "C" int fs2hip_dwconv_bwd(const float* dy, const float* x, int ldx, const float* w, float* dx, float* partial,
                                  float* dw, float* dbias, int B, int T, int C, int K, int glu, void* stream) {
+  return fs2hip_dwconv_bwd_b(dy, x, ldx, w, dx, 0, partial, dw, dbias, B, T, C, K, glu, stream);
+}
+
+// dx_bf16: dx (layout of x, leading dimension ldx) is written as bf16
+extern "C" int fs2hip_dwconv_bwd_b(const float* dy, const float* x, int ldx, const float* w, void* dx, int dx_bf16,
+                                   float* partial, float* dw, float* dbias, int B, int T, int C, int K, int glu,
+                                   void* stream) {
   if (B <= 0 || T <= 0 || C <= 0 || ldx < (glu ? 2 * C : C) || !partial) return FS2HIP_EINVAL;
   dim3 grid((C + 63) / 64, (T + 4 * RUN - 1) / (4 * RUN), B);
   hipStream_t s = (hipStream_t)stream;

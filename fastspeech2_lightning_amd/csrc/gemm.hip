@@ -193,6 +193,46 @@ extern "C" int fs2hip_gemm(const Fs2GemmArgs* args, void* stream) {
   if (a.Mc <= 0 || a.Nc <= 0 || a.R <= 0) return FS2HIP_EINVAL;
   if (a.taps < 1) a.taps = 1;
   if (a.splitk < 1) a.splitk = 1;
+  if (a.operand_bf16 == 4) {  // bf16 in memory, any orientation: its own core and its own preconditions
+    if (((uintptr_t)a.A % 16) || ((uintptr_t)a.B % 16) || (a.lda % 8) || (a.ldb % 8)) return FS2HIP_EINVAL;
+    if ((a.a_kcontig || a.b_kcontig) && (a.R / (a.shift_operand == 0 && a.taps > 1 ? a.taps : 1)) % 8) return FS2HIP_EINVAL;
+    if (!a.a_kcontig && (a.b_kcontig || a.lda < ((a.Mc + 7) / 8) * 8)) return FS2HIP_EINVAL;
+    if (!a.b_kcontig && a.ldb < ((a.Nc + 7) / 8) * 8) return FS2HIP_EINVAL;
+    if ((a.Nc % 4) || (a.ldc % 4) || ((uintptr_t)a.C % 16) || (a.bias && ((uintptr_t)a.bias % 16))) return FS2HIP_EINVAL;
+    const bool wgrad = !a.a_kcontig && !a.b_kcontig;
+    if (a.splitk > 1 && (!wgrad || !a.workspace || ((uintptr_t)a.workspace % 16) || (a.io_bf16 & 1))) return FS2HIP_EINVAL;
+    if (a.colsum && !wgrad) return FS2HIP_EINVAL;
+    p.Rper = a.R;
+    if (a.taps > 1) {
+      if (a.T <= 0) return FS2HIP_EINVAL;
+      if (a.shift_operand == 0) {
+        if (!a.a_kcontig || a.R % a.taps || a.Mc % a.T) return FS2HIP_EINVAL;
+        p.Rper = a.R / a.taps;
+      } else if (!wgrad || a.R % a.T) {
+        return FS2HIP_EINVAL;
+      }
+    }
+    if (a.epi == FS2_EPI_RESID && (!a.resid || (a.ldr % 4) || ((uintptr_t)a.resid % 16))) return FS2HIP_EINVAL;
+    if (a.epi == FS2_EPI_DACT && (!a.aux || (a.ldaux % 4) || ((uintptr_t)a.aux % 16))) return FS2HIP_EINVAL;
+    if (a.out_pre && ((a.ldpre % 4) || ((uintptr_t)a.out_pre % 16))) return FS2HIP_EINVAL;
+    {  // 32-bit byte offsets everywhere: every tensor below 2 GiB
+      const long long lim = 0x7fffffffLL - 65536;
+      const long long a_rows = a.a_kcontig ? a.Mc : a.R, b_rows = a.b_kcontig ? a.Nc : a.R;
+      if (2LL * (a_rows + 2LL * a.taps) * a.lda + 2LL * a.R >= lim) return FS2HIP_EINVAL;
+      if (2LL * (b_rows + 2LL * a.taps) * a.ldb + 2LL * a.R + 2LL * a.taps * (a.b_tap_stride > 0 ? a.b_tap_stride : 0) >= lim)
+        return FS2HIP_EINVAL;
+      auto fits = [&](long long ld) { return 4LL * a.Mc * ld < lim; };
+      if (!fits(a.splitk > 1 ? a.Nc : a.ldc) || (a.out_pre && !fits(a.ldpre)) || (a.epi == FS2_EPI_RESID && !fits(a.ldr)) ||
+          (a.epi == FS2_EPI_DACT && !fits(a.ldaux)))
+        return FS2HIP_EINVAL;
+    }
+    a.counters = nullptr;
+    p.drop = fs2_make_drop(a.drop_p, a.drop_seed, a.drop_step);
+    const int nzb = (a.shift_operand == 1 ? a.taps : 1) * a.splitk;
+    int tb = a.tile;
+    if (tb == 0) tb = (long long)((a.Mc + 127) / 128) * ((a.Nc + 127) / 128) * nzb >= 256 ? 20 : 23;
+    return fs2_gemmb_launch(p, tb, nzb, (hipStream_t)stream);
+  }
   // vector-load preconditions: the contiguous dimension of every operand is a multiple of 4
   // floats and rows start 16-byte aligned
   if ((a.lda % 4) || (a.ldb % 4)) return FS2HIP_EINVAL;
@@ -211,7 +251,7 @@ extern "C" int fs2hip_gemm(const Fs2GemmArgs* args, void* stream) {
     a.lda /= 2;
     a.ldb /= 2;
     a.b_tap_stride /= 2;
-  } else if (a.operand_bf16 < 0 || a.operand_bf16 > 3) {
+  } else if (a.operand_bf16 < 0 || a.operand_bf16 > 4) {
     return FS2HIP_EINVAL;
   }
   p.Rper = a.R;

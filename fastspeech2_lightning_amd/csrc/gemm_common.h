@@ -234,6 +234,8 @@ int fs2_gemm2_launch(GemmP& p, int tile, int nz, hipStream_t s);
 // persistent v2 core (gemm2p.hip); tile: 10 = 64x64, 11 = 128x64, 12 = 128x128 (all 2-stage); 13 / 14 = 128x128 /
 // 128x64 with the last partial round of tiles cut along the reduction
 int fs2_gemm2p_launch(GemmP& p, int tile, int nz, hipStream_t s);
+// bf16-storage core (gemm_bf16.hip); tile: 20 = 128x128 (2 stages), 21 = 128x128 (3), 22 = 128x64 (2), 23 = 64x64 (3)
+int fs2_gemmb_launch(GemmP& p, int tile, int nz, hipStream_t s);
 // finishes the reduction-split tail tiles of a persistent launch (reduce.hip)
 int fs2_tail_fixup(const float* ws, int S, long long slab, float* C, int ldc, const float* bias, float alpha, int m0,
                    int Mc, int Nc, hipStream_t s);

@@ -87,8 +87,12 @@ __global__ __launch_bounds__(256) void bucket_embed_add_kernel(const float* __re
 // ---------------------------------------------------------------------------------------------
 // LengthRegulator  fs2/variance_adaptor.py:65-81
 // ---------------------------------------------------------------------------------------------
+// expect / mismatch / bad_count (all optional): the reference's consistency check of the aligner's durations
+// (fs2/variance_adaptor.py:289-305): mismatch[b] = sum_j dur[b][j] != expect[b]; every mismatch also bumps the
+// persistent counter, so that the host can poll ONE word and read the per-utterance flags only when it is non-zero.
 __global__ void lr_cumsum_kernel(const int* __restrict__ dur, int* __restrict__ cum, int* __restrict__ out_lens,
-                                 int B, int Ts, int Tm) {
+                                 const int* __restrict__ expect, int* __restrict__ mismatch,
+                                 int* __restrict__ bad_count, int B, int Ts, int Tm) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   int s = 0;
@@ -98,6 +102,11 @@ __global__ void lr_cumsum_kernel(const int* __restrict__ dur, int* __restrict__ 
     cum[b * Ts + j] = s;
   }
   out_lens[b] = s < Tm ? s : Tm;
+  if (expect && mismatch) {
+    const int bad = s != expect[b];
+    mismatch[b] = bad;
+    if (bad && bad_count) atomicAdd(bad_count, 1);
+  }
 }
 
 // one wavefront per output frame: j = first token with cum[j] > t
@@ -308,6 +317,15 @@ __global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ x,
   }
 }
 
+// x *= *scalar, the scalar in device memory (the upstream gradient autograd hands to the step's backward node:
+// exactly 1 unless the caller scaled the loss, and then the pass is skipped)
+__global__ __launch_bounds__(256) void scale_dev_kernel(float* __restrict__ x, long long n, const float* __restrict__ scalar) {
+  const float s = *scalar;
+  if (s == 1.0f) return;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    x[i] *= s;
+}
+
 // out[b,t,:] = x[b,t,:] + e[b,:]   (speaker / language / style vectors, fs2/model.py:203-213)
 __global__ __launch_bounds__(256) void add_rowvec_kernel(const float* __restrict__ x, const float* __restrict__ e,
                                                           float* __restrict__ out, int B, int T, int D) {
@@ -403,7 +421,7 @@ extern "C" int fs2hip_length_regulate_fwd(const float* x, const int* dur, const 
                                           int* cum, int* out_lens, int* src_idx, int B, int Ts, int Tm, int D,
                                           void* stream) {
   if (B <= 0 || Ts <= 0 || Tm <= 0 || D <= 0 || (D % 4)) return FS2HIP_EINVAL;
-  lr_cumsum_kernel<<<dim3((B + 63) / 64), dim3(64), 0, S_>>>(dur, cum, out_lens, B, Ts, Tm);
+  lr_cumsum_kernel<<<dim3((B + 63) / 64), dim3(64), 0, S_>>>(dur, cum, out_lens, nullptr, nullptr, nullptr, B, Ts, Tm);
   FS2_LAUNCH_CHECK();
   const long long rows = (long long)B * Tm;
   lr_gather_kernel<<<dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, S_>>>(x, cum, posenc_table, out, src_idx, B, Ts, Tm, D);
@@ -411,9 +429,10 @@ extern "C" int fs2hip_length_regulate_fwd(const float* x, const int* dur, const 
   return 0;
 }
 
-extern "C" int fs2hip_duration_cumsum(const int* dur, int* cum, int* out_lens, int B, int Ts, int Tm, void* stream) {
-  if (B <= 0 || Ts <= 0) return FS2HIP_EINVAL;
-  lr_cumsum_kernel<<<dim3((B + 63) / 64), dim3(64), 0, S_>>>(dur, cum, out_lens, B, Ts, Tm);
+extern "C" int fs2hip_duration_cumsum(const int* dur, int* cum, int* out_lens, const int* expect_lens, int* mismatch,
+                                      int* bad_count, int B, int Ts, int Tm, void* stream) {
+  if (B <= 0 || Ts <= 0 || ((expect_lens == nullptr) != (mismatch == nullptr))) return FS2HIP_EINVAL;
+  lr_cumsum_kernel<<<dim3((B + 63) / 64), dim3(64), 0, S_>>>(dur, cum, out_lens, expect_lens, mismatch, bad_count, B, Ts, Tm);
   FS2_LAUNCH_CHECK();
   return 0;
 }
@@ -495,6 +514,13 @@ extern "C" int fs2hip_axpby(const float* x, const float* y, float* out, long lon
   if (n <= 0) return FS2HIP_EINVAL;
   axpby_kernel<<<dim3(grid_for(n, 256, 8192)), dim3(256), 0, S_>>>(x, y, out, n, a, b,
                                                                     fs2_make_drop(drop_p, drop_seed, drop_step));
+  FS2_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fs2hip_scale_dev(float* x, long long n, const float* scalar, void* stream) {
+  if (n <= 0 || !scalar) return FS2HIP_EINVAL;
+  scale_dev_kernel<<<dim3(grid_for(n, 256, 8192)), dim3(256), 0, S_>>>(x, n, scalar);
   FS2_LAUNCH_CHECK();
   return 0;
 }

@@ -7,9 +7,21 @@ namespace {
 constexpr int LN_MAX_CH = 4;           // C <= 1024: at most 4 float4 chunks per lane
 constexpr int LN_BWD_ROWS = 32;        // rows per workgroup in the backward (4 waves x 8 rows)
 
-template <int NCH>
+__device__ __forceinline__ uint2 ln_pack_bf16(float4 o) {
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  typedef float f32v4 __attribute__((ext_vector_type(4)));
+  const f32v4 v = {o.x, o.y, o.z, o.w};
+  return __builtin_bit_cast(uint2, __builtin_convertvector(v, bf16x4));  // round to nearest even
+}
+__device__ __forceinline__ float4 ln_unpack_bf16(uint2 u) {
+  return make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                     __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
+}
+
+// YB: y is bf16 (the operand a bf16-storage GEMM reads: the normalised activations exist only in that form)
+template <int NCH, bool YB>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta, float* __restrict__ y,
+                                                      const float* __restrict__ beta, void* __restrict__ y,
                                                       float* __restrict__ mean, float* __restrict__ rstd, int M,
                                                       int C, float eps) {
   const int lane = threadIdx.x & 63;
@@ -50,7 +62,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
       o.y = (v[j].y - mu) * rs * g.y + b.y;
       o.z = (v[j].z - mu) * rs * g.z + b.z;
       o.w = (v[j].w - mu) * rs * g.w + b.w;
-      reinterpret_cast<float4*>(y + (long long)row * C)[i] = o;
+      if constexpr (YB) reinterpret_cast<uint2*>((unsigned short*)y + (long long)row * C)[i] = ln_pack_bf16(o);
+      else reinterpret_cast<float4*>((float*)y + (long long)row * C)[i] = o;
     }
   }
 }
@@ -60,12 +73,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // DZ: a second output dz = dz_scale * dropmask * dx (the gradient entering the sub-module below through its output
 // dropout and residual scale: what would otherwise be an axpby launch over dx) and partial[blk][2][C] = sum_rows dz
 // (the gradient of that sub-module's last bias: what would otherwise be a column-sum launch over dz)
-template <int NCH, bool DZ>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+// DYB: dy is bf16 (the result of a bf16-storage data-gradient GEMM); ZB: dz is written as bf16 (the operand of the next
+// data-gradient and weight-gradient GEMMs; its column sums are those of the rounded values)
+template <int NCH, bool DZ, bool DYB = false, bool ZB = false>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, const float* __restrict__ x,
                                                       const float* __restrict__ gamma, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, const float* __restrict__ dx_add,
                                                       float* __restrict__ dx, float* __restrict__ partial, int M, int C,
-                                                      float* __restrict__ dz, float dz_scale, Fs2Drop drop_in) {
+                                                      void* __restrict__ dz, float dz_scale, Fs2Drop drop_in) {
   constexpr int NP = DZ ? 3 : 2;
   __shared__ float red[4][NP][LN_MAX_CH * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -92,7 +107,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
       int i = lane + 64 * j;
       if (i < c4) {
         float4 xv = reinterpret_cast<const float4*>(x + (long long)row * C)[i];
-        d[j] = reinterpret_cast<const float4*>(dy + (long long)row * C)[i];
+        if constexpr (DYB) d[j] = ln_unpack_bf16(reinterpret_cast<const uint2*>((const unsigned short*)dy + (long long)row * C)[i]);
+        else d[j] = reinterpret_cast<const float4*>((const float*)dy + (long long)row * C)[i];
         xh[j] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
       } else {
         d[j] = make_float4(0, 0, 0, 0);
@@ -127,7 +143,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
           z.y = o.y * dz_scale * fs2_drop_factor(drop, e + 1);
           z.z = o.z * dz_scale * fs2_drop_factor(drop, e + 2);
           z.w = o.w * dz_scale * fs2_drop_factor(drop, e + 3);
-          reinterpret_cast<float4*>(dz + (long long)row * C)[i] = z;
+          if constexpr (ZB) {
+            const uint2 zb = ln_pack_bf16(z);
+            reinterpret_cast<uint2*>((unsigned short*)dz + (long long)row * C)[i] = zb;
+            z = ln_unpack_bf16(zb);
+          } else {
+            reinterpret_cast<float4*>((float*)dz + (long long)row * C)[i] = z;
+          }
           dzs[j].x += z.x; dzs[j].y += z.y; dzs[j].z += z.z; dzs[j].w += z.w;
         }
       }
@@ -158,9 +180,25 @@ extern "C" int fs2hip_layernorm_fwd(const float* x, const float* gamma, const fl
   hipStream_t s = (hipStream_t)stream;
   const int nch = (C / 4 + 63) / 64;
   switch (nch) {
-    case 1: ln_fwd_kernel<1><<<grid, block, 0, s>>>(x, gamma, beta, y, mean, rstd, M, C, eps); break;
-    case 2: ln_fwd_kernel<2><<<grid, block, 0, s>>>(x, gamma, beta, y, mean, rstd, M, C, eps); break;
-    default: ln_fwd_kernel<4><<<grid, block, 0, s>>>(x, gamma, beta, y, mean, rstd, M, C, eps); break;
+    case 1: ln_fwd_kernel<1, false><<<grid, block, 0, s>>>(x, gamma, beta, y, mean, rstd, M, C, eps); break;
+    case 2: ln_fwd_kernel<2, false><<<grid, block, 0, s>>>(x, gamma, beta, y, mean, rstd, M, C, eps); break;
+    default: ln_fwd_kernel<4, false><<<grid, block, 0, s>>>(x, gamma, beta, y, mean, rstd, M, C, eps); break;
+  }
+  FS2_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fs2hip_layernorm_fwd_b(const float* x, const float* gamma, const float* beta, void* y_bf16,
+                                      float* mean, float* rstd, int M, int C, float eps, void* stream) {
+  if (M <= 0 || C <= 0 || (C % 4) || C > LN_MAX_CH * 256) return FS2HIP_EINVAL;
+  if (((uintptr_t)x % 16) || ((uintptr_t)y_bf16 % 8) || ((uintptr_t)gamma % 16) || ((uintptr_t)beta % 16)) return FS2HIP_EINVAL;
+  dim3 grid((M + 3) / 4), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  const int nch = (C / 4 + 63) / 64;
+  switch (nch) {
+    case 1: ln_fwd_kernel<1, true><<<grid, block, 0, s>>>(x, gamma, beta, y_bf16, mean, rstd, M, C, eps); break;
+    case 2: ln_fwd_kernel<2, true><<<grid, block, 0, s>>>(x, gamma, beta, y_bf16, mean, rstd, M, C, eps); break;
+    default: ln_fwd_kernel<4, true><<<grid, block, 0, s>>>(x, gamma, beta, y_bf16, mean, rstd, M, C, eps); break;
   }
   FS2_LAUNCH_CHECK();
   return 0;
@@ -208,4 +246,45 @@ extern "C" int fs2hip_layernorm_bwd_dz(const float* dy, const float* x, const fl
   }
   FS2_LAUNCH_CHECK();
   return 0;  // partial is [nblk][3][C]; the caller finishes it with fs2hip_reduce_rows_multi
+}
+
+// The same backward with bf16 on either side of it.  flags bit 0: dy is bf16; bit 1: dz is bf16.  dz == NULL: no
+// second output (partial is [nblk][2][C]), else partial is [nblk][3][C].  The caller finishes the partial sums.
+extern "C" int fs2hip_layernorm_bwd_x(const void* dy, const float* x, const float* gamma, const float* mean,
+                                      const float* rstd, const float* dx_add, float* dx, void* dz, float dz_scale,
+                                      float drop_p, unsigned long long drop_seed, const unsigned long long* drop_step,
+                                      float* partial, int M, int C, int flags, void* stream) {
+  if (M <= 0 || C <= 0 || (C % 4) || C > LN_MAX_CH * 256 || !partial) return FS2HIP_EINVAL;
+  const bool dyb = flags & 1, zb = flags & 2;
+  if (((uintptr_t)x % 16) || ((uintptr_t)dy % (dyb ? 8 : 16)) || ((uintptr_t)dx % 16) || ((uintptr_t)gamma % 16)) return FS2HIP_EINVAL;
+  if (dz && ((uintptr_t)dz % (zb ? 8 : 16))) return FS2HIP_EINVAL;
+  if (dx_add && ((uintptr_t)dx_add % 16)) return FS2HIP_EINVAL;
+  const int nblk = fs2hip_layernorm_bwd_blocks(M);
+  hipStream_t s = (hipStream_t)stream;
+  const Fs2Drop drop = fs2_make_drop(dz ? drop_p : 0.f, drop_seed, drop_step);
+  const int nch = (C / 4 + 63) / 64;
+#define FS2_LNB(N_, DZ_, DYB_, ZB_) \
+  ln_bwd_kernel<N_, DZ_, DYB_, ZB_><<<dim3(nblk), dim3(256), 0, s>>>(dy, x, gamma, mean, rstd, dx_add, dx, partial, M, C, dz, dz_scale, drop)
+#define FS2_LNB_N(N_)                                      \
+  do {                                                     \
+    if (!dz) {                                             \
+      if (dyb) FS2_LNB(N_, false, true, false);            \
+      else FS2_LNB(N_, false, false, false);               \
+    } else if (dyb) {                                      \
+      if (zb) FS2_LNB(N_, true, true, true);               \
+      else FS2_LNB(N_, true, true, false);                 \
+    } else {                                               \
+      if (zb) FS2_LNB(N_, true, false, true);              \
+      else FS2_LNB(N_, true, false, false);                \
+    }                                                      \
+  } while (0)
+  switch (nch) {
+    case 1: FS2_LNB_N(1); break;
+    case 2: FS2_LNB_N(2); break;
+    default: FS2_LNB_N(4); break;
+  }
+#undef FS2_LNB_N
+#undef FS2_LNB
+  FS2_LAUNCH_CHECK();
+  return 0;
 }

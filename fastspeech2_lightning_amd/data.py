@@ -233,10 +233,21 @@ def validate(model, batches: Iterable[dict], process_group=None) -> dict:
         vec = torch.stack([losses[k].detach().float() for k in keys])
         total = vec if total is None else total + vec
         n += 1
-    if total is None:
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
+    if total is None and not distributed:
         return {}
+    if distributed:
+        # a rank whose shard is empty still takes part in the exchange (with zero sums) -- and learns the keys from it
+        box = [keys]
+        gathered = [None] * dist.get_world_size(process_group)
+        dist.all_gather_object(gathered, box[0], group=process_group)
+        keys = next((k for k in gathered if k), None)
+        if keys is None:
+            return {}
+        if total is None:
+            total = torch.zeros(len(keys), device=model.device_, dtype=torch.float32)
     stat = torch.cat([total, total.new_tensor([float(n)])])
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
+    if distributed:
         dist.all_reduce(stat, group=process_group)
     mean = (stat[:-1] / stat[-1]).cpu()
     return {f"validation/{k}_loss": float(v) for k, v in zip(keys, mean)}

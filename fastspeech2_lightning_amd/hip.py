@@ -42,6 +42,8 @@ class GemmArgs(C.Structure):
         ("splitk", C.c_int), ("workspace", C.c_void_p), ("tile", C.c_int), ("workspace_floats", C.c_longlong),
         ("counters", C.c_void_p),
         ("operand_bf16", C.c_int),
+        ("io_bf16", C.c_int),
+        ("colsum", C.c_void_p),
     ]
 
 
@@ -59,6 +61,9 @@ SIGNATURES = {
     "fs2hip_layernorm_bwd_blocks": "i",
     "fs2hip_layernorm_bwd": "ppppppppppiip",
     "fs2hip_layernorm_bwd_dz": "ppppppppffQppiip",
+    "fs2hip_layernorm_fwd_b": "ppppppiifp",
+    "fs2hip_layernorm_bwd_x": "ppppppppffQppiiip",
+    "fs2hip_dwconv_bwd_b": "ppippipppiiiiip",
     "fs2hip_attention_fwd": "ppppiiiifQpip",
     "fs2hip_attention_bwd": "pppppppiiiifQpip",
     "fs2hip_dwconv_blocks": "ii",
@@ -80,7 +85,7 @@ SIGNATURES = {
     "fs2hip_bucket_embed_add": "pfpippppiip",
     "fs2hip_length_regulate_fwd": "pppppppiiiip",
     "fs2hip_length_regulate_bwd": "pppiiiip",
-    "fs2hip_duration_cumsum": "pppiiip",
+    "fs2hip_duration_cumsum": "ppppppiiip",
     "fs2hip_rowdot_fwd": "pppppiiip",
     "fs2hip_rowdot_blocks": "i",
     "fs2hip_rowdot_bwd": "ppppppppiiip",
@@ -92,6 +97,7 @@ SIGNATURES = {
     "fs2hip_cast_bf16": "ppqp",
     "fs2hip_transpose_cast_bf16": "piiipiip",
     "fs2hip_add_rowvec": "pppiiip",
+    "fs2hip_scale_dev": "pqpp",
     "fs2hip_dact_mul": "pppqip",
     "fs2hip_mask_from_lens": "ppiip",
     "fs2hip_duration_round": "pfpip",
@@ -280,6 +286,7 @@ def get_precision() -> str:
     return {0: "32-true", 1: "bf16-mixed", 2: "32-split"}[int(GEMM_BF16)]
 
 
+GEMM_TILES_B = (20, 21, 22, 23)  # bf16-storage core (operand_bf16 == 4): 128x128 (2 / 3 stages), 128x64, 64x64
 GEMM_TILES = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)  # 1-3: register-staged BK=16 core; 4-9: direct-to-LDS BK=32 core;
 #                                                      10-12: persistent direct-to-LDS core; 13-15: + split tail
 _TILE_CACHE = {}
@@ -325,14 +332,25 @@ def refine_tiles_in_step(step, rounds: int = 5, candidates: int = 2, top: int = 
     return base, changed
 
 
+def _q(n: int) -> int:
+    """Long extents in eighths of an octave: training batches differ in their padded length from step to step (the
+    row count of every decoder GEMM is B x Tm), and a tile that is fastest at 20 736 rows is fastest at 20 480 too --
+    without this every new batch shape would re-run the tuner for every GEMM of the step."""
+    if n <= 2048:
+        return n
+    g = 1 << (n.bit_length() - 4)
+    return (n + g - 1) // g * g
+
+
 def _tile_key(a):
     # everything that decides which tiles are legal for a launch or how fast they are: the shape, the operand
     # layouts, the conv geometry (T only matters to the shifted-operand cores, which refuse T < 32), the epilogue and
     # which of its tensors are present, 16-byte alignment of the output rows (the split-tail tiles need it), device
     flags = ((1 if a.bias else 0) | (2 if a.resid else 0) | (4 if a.aux else 0) | (8 if a.out_pre else 0)
              | (16 if (a.ldc % 4 == 0 and (a.C or 0) % 16 == 0) else 0) | (32 if a.drop_p > 0 else 0)
-             | (64 if a.counters else 0))
-    return (a.Mc, a.Nc, a.R, a.taps, a.a_kcontig, a.b_kcontig, a.shift_operand, a.splitk, a.epi, a.operand_bf16,
+             | (64 if a.counters else 0) | (128 * a.io_bf16) | (512 if a.colsum else 0))
+    # (a cached tile that an exact shape does not admit is dropped again by _launch_gemm)
+    return (_q(a.Mc), _q(a.Nc), _q(a.R), a.taps, a.a_kcontig, a.b_kcontig, a.shift_operand, a.splitk, a.epi, a.operand_bf16,
             a.T if a.taps > 1 else 0, flags, _current_device())
 
 
@@ -390,6 +408,8 @@ def _tune_tile(a) -> int:
     timings = []
     # the BK=16 core has no bf16 instance (it runs in fp32): last resort in bf16-mixed mode
     order = sorted(GEMM_TILES, key=lambda t: (t < 4, t)) if a.operand_bf16 else GEMM_TILES
+    if a.operand_bf16 == 4:
+        order = GEMM_TILES_B
     for tile in order:
         if a.operand_bf16 and tile < 4 and best:
             break
@@ -435,7 +455,7 @@ def _gemm(_algorithmic=True, **kw):
     if not a.workspace:  # scratch for the split-tail tiles (13-15): at most one slab of partial sums per workgroup slot
         ws = _workspace(HYBRID_WS_FLOATS, _current_device())
         a.workspace, a.workspace_floats = _p(ws), ws.numel()
-    if not a.operand_bf16:  # (3 = bf16 operands in memory: set by the caller that passes bf16 tensors)
+    if not a.operand_bf16:  # (3 / 4 = bf16 operands in memory: set by the caller that passes bf16 tensors)
         a.operand_bf16 = int(GEMM_BF16) if _algorithmic else 0
     a.tile = _tune_tile(a)
     if GEMM_PROFILE is None or not _algorithmic:  # (the one-hot embedding GEMM's flops are not algorithmic)
@@ -448,21 +468,25 @@ def _gemm(_algorithmic=True, **kw):
     ntap = a.taps if a.shift_operand == 1 else 1
     # algorithmic bytes: every operand element read once, every output element written once
     ra = a.R // a.taps if (a.taps > 1 and a.shift_operand == 0) else a.R
-    esz = 2.0 if a.operand_bf16 == 3 else 4.0
-    nbytes = esz * (a.Mc * ra + a.Nc * a.R) + 4.0 * (a.Mc * a.Nc * ntap + (a.Mc * a.Nc if a.resid else 0)
-                                                     + (a.Mc * a.Nc if a.aux else 0) + (a.Mc * a.Nc if a.out_pre else 0))
+    esz = 2.0 if a.operand_bf16 >= 3 else 4.0
+    osz = 2.0 if (a.io_bf16 & 1) else 4.0
+    nbytes = (esz * (a.Mc * ra + a.Nc * a.R) + osz * a.Mc * a.Nc * ntap + 4.0 * (a.Mc * a.Nc if a.resid else 0)
+              + (2.0 if (a.io_bf16 & 2) else 4.0) * (a.Mc * a.Nc if a.aux else 0) + osz * (a.Mc * a.Nc if a.out_pre else 0))
     GEMM_PROFILE.append((e0, e1, 2.0 * a.Mc * a.Nc * a.R * ntap, a.Mc, a.Nc, a.R * ntap, nbytes,
                          (a.a_kcontig, a.b_kcontig, a.taps, a.shift_operand, a.splitk, a.epi, a.tile)))
 
 
 def linear_fwd(x, w, bias=None, *, epi=EPI_STORE, act=None, resid=None, res_scale=1.0, out_pre=None,
-               drop: Drop = NO_DROP, taps=1, T=0, out=None):
+               drop: Drop = NO_DROP, taps=1, T=0, out=None, out_dtype=torch.float32):
     """y[M, N] = epi(x[M, K*] @ w^T + bias).  ``w`` is [N, K] (taps == 1) or
-    [taps, N, Kper] for a k-tap convolution over time (rows of x are (b, t), 'same' padding)."""
-    stored = x.dtype == torch.bfloat16  # bf16 operand storage: x and w hold bf16 (cast_bf16 / the producers' copies)
+    [taps, N, Kper] for a k-tap convolution over time (rows of x are (b, t), 'same' padding).
+    bf16 ``x`` and ``w`` (operand storage, ``operand_bf16 = 4``): the result is ``out_dtype`` (fp32 or bf16; ``out_pre``
+    has the same type); ``bias`` and ``resid`` stay fp32."""
+    stored = x.dtype == torch.bfloat16
     _chk(x, x.dtype if stored else torch.float32, "x"); _chk(w, x.dtype if stored else torch.float32, "w")
     M, Kper = _rows(x), x.shape[-1]
     _req(not stored or (Kper % 8 == 0 and (taps == 1 or Kper % 64 == 0)), "linear_fwd: bf16 rows must be whole 16-byte pieces")
+    _req(stored or out_dtype == torch.float32, "linear_fwd: bf16 results need bf16 operands")
     if taps == 1:
         _req(w.dim() == 2 and w.shape[1] == Kper, f"linear_fwd: x has {Kper} columns, w is {tuple(w.shape)}")
         N = w.shape[0]
@@ -471,13 +495,14 @@ def linear_fwd(x, w, bias=None, *, epi=EPI_STORE, act=None, resid=None, res_scal
              "linear_fwd: conv weight must be [taps, N, Kper] and rows a multiple of T")
         N = w.shape[1]
     if out is None:
-        out = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
-    _chk(out, name="out")
+        out = torch.empty(*x.shape[:-1], N, device=x.device, dtype=out_dtype)
+    _chk(out, out.dtype if stored else torch.float32, name="out")
     _req(_rows(out) == M and out.shape[-1] == N, "linear_fwd: bad output shape")
+    obf = out.dtype == torch.bfloat16
     kw = dict(A=_p(x), B=_p(w), C=_p(out), Mc=M, Nc=N, R=Kper * taps, lda=Kper, ldb=Kper, ldc=N,
               a_kcontig=1, b_kcontig=1, taps=taps, T=T, tap_mul=1, tap_add=-((taps - 1) // 2), shift_operand=0,
               b_tap_stride=N * Kper, epi=epi, act=_ACT[act], drop_p=drop.p, drop_seed=drop.seed,
-              drop_step=drop.step_ptr, operand_bf16=3 if stored else 0)
+              drop_step=drop.step_ptr, operand_bf16=4 if stored else 0, io_bf16=1 if obf else 0)
     if bias is not None:
         _chk(bias, name="bias")
         _req(bias.numel() == N, "linear_fwd: bias size")
@@ -487,7 +512,7 @@ def linear_fwd(x, w, bias=None, *, epi=EPI_STORE, act=None, resid=None, res_scal
         _req(resid.shape == out.shape, "linear_fwd: residual shape")
         kw.update(resid=_p(resid), ldr=N, res_scale=float(res_scale))
     if out_pre is not None:
-        _chk(out_pre, name="out_pre")
+        _chk(out_pre, out.dtype, name="out_pre")
         _req(out_pre.shape == out.shape, "linear_fwd: out_pre shape")
         kw.update(out_pre=_p(out_pre), ldpre=N)
     _gemm(**kw)
@@ -495,40 +520,41 @@ def linear_fwd(x, w, bias=None, *, epi=EPI_STORE, act=None, resid=None, res_scal
 
 
 def linear_bwd_data(dy, w, *, epi=EPI_STORE, act=None, aux=None, alpha=1.0, drop: Drop = NO_DROP,
-                    taps=1, T=0, out=None):
-    """dx[M, K] = epi(alpha * dy[M, N] @ w) with w [N, K] (or [taps, N, Kper], transposed conv)."""
-    stored = dy.dtype == torch.bfloat16  # bf16 operand storage: dy in bf16 and w TRANSPOSED, [K, N] in bf16
+                    taps=1, T=0, out=None, out_dtype=torch.float32):
+    """dx[M, K] = epi(alpha * dy[M, N] @ w) with w [N, K] (or [taps, N, Kper], transposed conv).
+    bf16 ``dy`` and ``w`` (operand storage): the weight is read as it is stored (reduction-major operand of the
+    bf16 core); ``aux`` may be fp32 or bf16, the result is ``out_dtype``."""
+    stored = dy.dtype == torch.bfloat16
     _chk(dy, dy.dtype if stored else torch.float32, "dy"); _chk(w, dy.dtype if stored else torch.float32, "w")
+    _req(stored or out_dtype == torch.float32, "linear_bwd_data: bf16 results need bf16 operands")
     M, N = _rows(dy), dy.shape[-1]
-    if stored and taps == 1:
-        _req(w.dim() == 2 and w.shape[1] == N and N % 8 == 0,
-             "linear_bwd_data: bf16 operands need the transposed weight [K, N]")
-        K = w.shape[0]
-    elif stored:
-        _req(w.dim() == 3 and w.shape[0] == taps and w.shape[2] == N and N % 64 == 0 and T > 0 and M % T == 0,
-             "linear_bwd_data: bf16 operands need the per-tap transposed conv weight [taps, Kper, N], N a multiple of 64")
-        K = w.shape[1]
-    elif taps == 1:
+    if taps == 1:
         _req(w.dim() == 2 and w.shape[0] == N, "linear_bwd_data: dy columns != w rows")
         K = w.shape[1]
     else:
         _req(w.dim() == 3 and w.shape[0] == taps and w.shape[1] == N and T > 0 and M % T == 0,
              "linear_bwd_data: conv weight must be [taps, N, Kper]")
         K = w.shape[2]
+    _req(not stored or (N % 8 == 0 and K % 8 == 0 and (taps == 1 or N % 64 == 0)),
+         "linear_bwd_data: bf16 operands need N and K multiples of 8 (tap widths multiples of 64)")
     if out is None:
-        out = torch.empty(*dy.shape[:-1], K, device=dy.device, dtype=torch.float32)
-    _chk(out, name="out")
+        out = torch.empty(*dy.shape[:-1], K, device=dy.device, dtype=out_dtype)
+    _chk(out, out.dtype if stored else torch.float32, name="out")
     _req(_rows(out) == M and out.shape[-1] == K, "linear_bwd_data: bad output shape")
+    io = 1 if out.dtype == torch.bfloat16 else 0
     kw = dict(A=_p(dy), B=_p(w), C=_p(out), Mc=M, Nc=K, R=N * taps, lda=N, ldb=K, ldc=K,
               a_kcontig=1, b_kcontig=0, taps=taps, T=T, tap_mul=-1, tap_add=(taps - 1) // 2, shift_operand=0,
               b_tap_stride=N * K, epi=epi, act=_ACT[act], alpha=float(alpha),
               drop_p=drop.p, drop_seed=drop.seed, drop_step=drop.step_ptr)
-    if stored:  # NT on the transposed weight(s); the transposed convolution keeps its reversed tap order
-        kw.update(ldb=N, b_kcontig=1, operand_bf16=3)
     if epi == EPI_DACT:
-        _chk(aux, name="aux")
+        _req(aux is not None, "linear_bwd_data: the act' epilogue needs aux")
+        _chk(aux, torch.bfloat16 if (stored and aux.dtype == torch.bfloat16) else torch.float32, name="aux")
         _req(aux.shape == out.shape, "linear_bwd_data: aux shape")
         kw.update(aux=_p(aux), ldaux=K)
+        if aux.dtype == torch.bfloat16:
+            io |= 2
+    if stored:
+        kw.update(operand_bf16=4, io_bf16=io)
     _gemm(**kw)
     return out
 
@@ -575,26 +601,42 @@ def pick_splitk(Mc: int, Nc: int, R: int, taps: int = 1) -> int:
     return s
 
 
-def linear_bwd_weight(dy, x, out, *, taps=1, T=0, n_valid=None):
+def linear_bwd_weight(dy, x, out, *, taps=1, T=0, n_valid=None, bias_grad=None):
     """dw[N, K] = dy[M, N]^T @ x[M, K]  (or dw[taps, N, Kper] for the k-tap conv).
     Written into ``out`` (a view of the flat gradient buffer).  ``n_valid``: only the first
-    n_valid columns of dy produce output rows (dy's row length may be padded to a multiple of 4)."""
-    _chk(dy, name="dy"); _chk(x, name="x"); _chk(out, name="out")
+    n_valid columns of dy produce output rows (dy's row length may be padded to a multiple of 4).
+    bf16 ``dy`` and ``x`` (operand storage): both are read as stored (reduction-major operands of the bf16 core), and
+    ``bias_grad`` [N], when given, receives dy's column sums from the same launch (second stage at the next
+    ``flush_grad_reductions()``) -- the separate column-sum pass over dy disappears."""
+    stored = dy.dtype == torch.bfloat16
+    _chk(dy, dy.dtype if stored else torch.float32, name="dy"); _chk(x, dy.dtype if stored else torch.float32, name="x")
+    _chk(out, name="out")
     M, lda, K = _rows(dy), dy.shape[-1], x.shape[-1]
     N = lda if n_valid is None else int(n_valid)
     _req(_rows(x) == M and N <= lda, "linear_bwd_weight: row mismatch")
     _req(out.numel() == taps * N * K, "linear_bwd_weight: bad gradient shape")
     _req(taps == 1 or (T > 0 and M % T == 0), "linear_bwd_weight: rows must be a multiple of T")
+    _req(not stored or (lda % 8 == 0 and K % 8 == 0 and N % 8 == 0 and (taps == 1 or T >= 64)),
+         "linear_bwd_weight: bf16 operands need row lengths that are multiples of 8 (convolutions: T >= 64)")
+    _req(bias_grad is None or stored, "linear_bwd_weight: the fused bias gradient is part of the bf16 core")
     S = pick_splitk(N, K, M, taps)
     kw = dict(A=_p(dy), B=_p(x), C=_p(out), Mc=N, Nc=K, R=M, lda=lda, ldb=K, ldc=K, a_kcontig=0, b_kcontig=0,
               taps=taps, T=T if taps > 1 else 0, tap_mul=1, tap_add=-((taps - 1) // 2),
               shift_operand=1 if taps > 1 else 0, c_tap_stride=N * K, splitk=S)
+    if stored:
+        kw.update(operand_bf16=4)
+        if bias_grad is not None:
+            _chk(bias_grad, name="bias_grad")
+            _req(bias_grad.numel() == N, "linear_bwd_weight: bias gradient size")
+            part = torch.empty(S * N, device=dy.device, dtype=torch.float32)
+            kw["colsum"] = _p(part)
+            _defer_reduction(part, S, N, N, bias_grad, N, None)
     if S > 1:
         n = taps * N * K
         ws = _workspace(S * n, dy.device)
         kw["workspace"] = _p(ws)
         kw["workspace_floats"] = ws.numel()
-        in_kernel = SPLITK_IN_KERNEL and taps * ((N + 63) // 64) * ((K + 63) // 64) <= SPLITK_COUNTERS
+        in_kernel = (not stored) and SPLITK_IN_KERNEL and taps * ((N + 63) // 64) * ((K + 63) // 64) <= SPLITK_COUNTERS
         if in_kernel:  # the last workgroup of every output tile sums the slabs: no second launch
             kw["counters"] = _p(splitk_counters(dy.device))
         _gemm(_algorithmic=n_valid is None, **kw)
@@ -684,25 +726,28 @@ def colsum_grad(x, out):
 # ------------------------------------------------------------------------------------------
 # LayerNorm
 # ------------------------------------------------------------------------------------------
-def layernorm_fwd(x, gamma, beta, eps=1e-5):
+def layernorm_fwd(x, gamma, beta, eps=1e-5, out_dtype=torch.float32):
+    """``out_dtype=torch.bfloat16``: y is written as bf16 only (the operand of a bf16-storage GEMM)."""
     _chk(x, name="x"); _chk(gamma, name="gamma"); _chk(beta, name="beta")
     M, Cc = _rows(x), x.shape[-1]
     _req(gamma.numel() == Cc and beta.numel() == Cc, "layernorm_fwd: parameter size")
-    y = torch.empty_like(x)
+    y = torch.empty(x.shape, device=x.device, dtype=out_dtype)
     mean = torch.empty(M, device=x.device, dtype=torch.float32)
     rstd = torch.empty(M, device=x.device, dtype=torch.float32)
-    _ok(lib().fs2hip_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, Cc, eps, _stream()),
-        "layernorm_fwd")
+    fn = lib().fs2hip_layernorm_fwd_b if out_dtype == torch.bfloat16 else lib().fs2hip_layernorm_fwd
+    _ok(fn(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, Cc, eps, _stream()), "layernorm_fwd")
     return y, mean, rstd
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dx_add=None, defer=False, dz_scale=None,
-                  dz_drop: Drop = NO_DROP, dz_colsum=None):
+                  dz_drop: Drop = NO_DROP, dz_colsum=None, dz_dtype=torch.float32):
     """Returns dx (+ dx_add); writes dgamma/dbeta (``defer``: at the next ``flush_grad_reductions()``).
     With ``dz_scale``: returns (dx, dz), dz = dz_scale * dropmask(dz_drop) * dx, and ``dz_colsum`` receives dz's column
-    sums at the next ``flush_grad_reductions()`` (like dgamma/dbeta, which are then always deferred)."""
-    for n, t in (("dy", dy), ("x", x), ("gamma", gamma), ("mean", mean), ("rstd", rstd), ("dgamma", dgamma),
-                 ("dbeta", dbeta)):
+    sums at the next ``flush_grad_reductions()`` (like dgamma/dbeta, which are then always deferred).
+    bf16 storage: ``dy`` may be bf16 (a data-gradient GEMM's result) and ``dz_dtype`` bf16 (the next GEMMs' operand)."""
+    dyb = dy.dtype == torch.bfloat16
+    _chk(dy, dy.dtype if dyb else torch.float32, "dy")
+    for n, t in (("x", x), ("gamma", gamma), ("mean", mean), ("rstd", rstd), ("dgamma", dgamma), ("dbeta", dbeta)):
         _chk(t, name=n)
     M, Cc = _rows(x), x.shape[-1]
     _req(dy.shape == x.shape and mean.numel() == M and rstd.numel() == M and dgamma.numel() == Cc
@@ -712,17 +757,29 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dx_add=None, defer=Fa
         _req(dx_add.shape == x.shape, "layernorm_bwd: dx_add shape")
     dx = torch.empty_like(x)
     nblk = lib().fs2hip_layernorm_bwd_blocks(M)
+    zb = dz_dtype == torch.bfloat16
     if dz_scale is not None:
         _chk(dz_colsum, name="dz_colsum")
         _req(dz_colsum.numel() == Cc, "layernorm_bwd: dz_colsum size")
-        dz = torch.empty_like(x)
+        dz = torch.empty(x.shape, device=x.device, dtype=dz_dtype)
         part = torch.empty(nblk * 3 * Cc, device=x.device, dtype=torch.float32)
-        _ok(lib().fs2hip_layernorm_bwd_dz(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx_add), _p(dx), _p(dz),
-                                          float(dz_scale), dz_drop.p, dz_drop.seed, dz_drop.step_ptr, _p(part), M, Cc,
-                                          _stream()), "layernorm_bwd_dz")
+        if dyb or zb:
+            _ok(lib().fs2hip_layernorm_bwd_x(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx_add), _p(dx), _p(dz),
+                                             float(dz_scale), dz_drop.p, dz_drop.seed, dz_drop.step_ptr, _p(part), M, Cc,
+                                             (1 if dyb else 0) | (2 if zb else 0), _stream()), "layernorm_bwd_x")
+        else:
+            _ok(lib().fs2hip_layernorm_bwd_dz(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx_add), _p(dx), _p(dz),
+                                              float(dz_scale), dz_drop.p, dz_drop.seed, dz_drop.step_ptr, _p(part), M, Cc,
+                                              _stream()), "layernorm_bwd_dz")
         _defer_reduction(part, nblk, 2 * Cc, 3 * Cc, dgamma, Cc, dbeta)
         _defer_reduction(part[2 * Cc:], nblk, Cc, 3 * Cc, dz_colsum, Cc, None)
         return dx, dz
+    if dyb:
+        part = torch.empty(nblk * 2 * Cc, device=x.device, dtype=torch.float32)
+        _ok(lib().fs2hip_layernorm_bwd_x(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx_add), _p(dx), None, 0.0,
+                                         0.0, 0, None, _p(part), M, Cc, 1, _stream()), "layernorm_bwd_x")
+        _defer_reduction(part, nblk, 2 * Cc, 2 * Cc, dgamma, Cc, dbeta)
+        return dx
     if defer and nblk > 1:
         part = torch.empty(nblk * 2 * Cc, device=x.device, dtype=torch.float32)
         _ok(lib().fs2hip_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx_add), _p(dx), _p(part),
@@ -793,8 +850,8 @@ def dwconv_fwd(x, w, bias, B, T, *, glu=False, stats=False):
     return y, (StatParts(partial, nparts, lib().fs2hip_dwconv_part_rows(), T, B * T) if stats else None)
 
 
-def dwconv_bwd(dy, x, w, dw, dbias, B, T, *, glu=False):
-    """Returns dx (layout of x); writes dw [K, C] and dbias [C]."""
+def dwconv_bwd(dy, x, w, dw, dbias, B, T, *, glu=False, out_dtype=torch.float32):
+    """Returns dx (layout of x; ``out_dtype`` fp32 or bf16); writes dw [K, C] and dbias [C]."""
     _chk(dy, name="dy"); _chk(x, name="x"); _chk(w, name="w"); _chk(dw, name="dw")
     K, Cc = w.shape
     ldx = x.shape[-1]
@@ -803,11 +860,11 @@ def dwconv_bwd(dy, x, w, dw, dbias, B, T, *, glu=False):
     if dbias is not None:
         _chk(dbias, name="dbias")
         _req(dbias.numel() == Cc, "dwconv_bwd: dbias size")
-    dx = torch.empty_like(x)
+    dx = torch.empty(x.shape, device=x.device, dtype=out_dtype)
     nblk = lib().fs2hip_dwconv_blocks(B, T)
     ws = _workspace(nblk * (K + 1) * Cc, x.device)
-    _ok(lib().fs2hip_dwconv_bwd(_p(dy), _p(x), ldx, _p(w), _p(dx), _p(ws), _p(dw), _p(dbias), B, T, Cc, K, int(glu),
-                                _stream()), "dwconv_bwd")
+    _ok(lib().fs2hip_dwconv_bwd_b(_p(dy), _p(x), ldx, _p(w), _p(dx), int(out_dtype == torch.bfloat16), _p(ws), _p(dw),
+                                  _p(dbias), B, T, Cc, K, int(glu), _stream()), "dwconv_bwd")
     return dx
 
 
@@ -843,19 +900,23 @@ def bn_finalize(parts: Optional[StatParts], gamma, beta, running_mean, running_v
     return stats
 
 
-def bn_act_fwd(y, stats, act=None, drop: Drop = NO_DROP, bf16_copy=False):
-    """``bf16_copy``: returns (out, out as bf16) -- the copy a bf16-operand GEMM (``linear_fwd`` on bf16 tensors) reads."""
+def bn_act_fwd(y, stats, act=None, drop: Drop = NO_DROP, bf16_copy=False, bf16_only=False):
+    """``bf16_copy``: returns (out, out as bf16) -- the form a bf16-operand GEMM (``linear_fwd`` on bf16 tensors) reads;
+    ``bf16_only``: returns the bf16 form alone (no fp32 tensor is written)."""
     _chk(y, name="y"); _chk(stats, name="stats")
     M, Cc = _rows(y), y.shape[-1]
     _req(stats.numel() == 4 * Cc, "bn_act_fwd: stats size")
-    out = torch.empty_like(y)
-    out_b = torch.empty(y.shape, device=y.device, dtype=torch.bfloat16) if bf16_copy else None
+    out = None if bf16_only else torch.empty_like(y)
+    out_b = torch.empty(y.shape, device=y.device, dtype=torch.bfloat16) if (bf16_copy or bf16_only) else None
     _ok(lib().fs2hip_bn_act_fwd_b(_p(y), _p(stats), _p(out), _p(out_b), M, Cc, _ACT[act], drop.p, drop.seed,
                                   drop.step_ptr, _stream()), "bn_act_fwd")
+    if bf16_only:
+        return out_b
     return (out, out_b) if bf16_copy else out
 
 
-def bn_act_bwd(dout, y, stats, dgamma, dbeta, act=None, drop: Drop = NO_DROP, training=True, bf16_copy=False):
+def bn_act_bwd(dout, y, stats, dgamma, dbeta, act=None, drop: Drop = NO_DROP, training=True, bf16_copy=False,
+               bf16_only=False):
     for n, t in (("dout", dout), ("y", y), ("stats", stats), ("dgamma", dgamma), ("dbeta", dbeta)):
         _chk(t, name=n)
     M, Cc = _rows(y), y.shape[-1]
@@ -864,11 +925,13 @@ def bn_act_bwd(dout, y, stats, dgamma, dbeta, act=None, drop: Drop = NO_DROP, tr
     nparts = lib().fs2hip_colstats_parts(M)
     ws = _workspace(nparts * 2 * Cc + 2 * Cc, y.device)
     coef_ptr = ws.data_ptr() + 4 * nparts * 2 * Cc
-    dy = torch.empty_like(y)
-    dy_b = torch.empty(y.shape, device=y.device, dtype=torch.bfloat16) if bf16_copy else None
+    dy = None if bf16_only else torch.empty_like(y)
+    dy_b = torch.empty(y.shape, device=y.device, dtype=torch.bfloat16) if (bf16_copy or bf16_only) else None
     _ok(lib().fs2hip_bn_act_bwd_b(_p(dout), _p(y), _p(stats), _p(ws), coef_ptr, _p(dgamma), _p(dbeta), _p(dy), _p(dy_b),
                                   M, Cc, _ACT[act], drop.p, drop.seed, drop.step_ptr, int(training), _stream()),
         "bn_act_bwd")
+    if bf16_only:
+        return dy_b
     return (dy, dy_b) if bf16_copy else dy
 
 
@@ -1040,6 +1103,14 @@ def axpby(x, y=None, a=1.0, b=1.0, drop: Drop = NO_DROP, out=None):
     return out
 
 
+def scale_dev(x, scalar):
+    """x *= scalar, ``scalar`` a 1-element fp32 tensor in device memory (nothing is moved when it holds exactly 1)."""
+    _chk(x, name="x"); _chk(scalar, name="scalar")
+    _req(scalar.numel() == 1, "scale_dev: one scalar")
+    _ok(lib().fs2hip_scale_dev(_p(x), x.numel(), _p(scalar), _stream()), "scale_dev")
+    return x
+
+
 def add_rowvec(x, e, B, T):
     _chk(x, name="x"); _chk(e, name="e")
     D = x.shape[-1]
@@ -1111,14 +1182,25 @@ def mas(x, in_lens, out_lens, is_log=False):
     return hard, hard_idx, dur
 
 
-def duration_cumsum(dur, Tm):
-    """(cum [B, Ts] inclusive cumulative durations, lens [B] = min(total, Tm))."""
+def duration_cumsum(dur, Tm, expect=None, bad_count=None):
+    """(cum [B, Ts] inclusive cumulative durations, lens [B] = min(total, Tm)).  With ``expect`` [B] int32 a third
+    result: mismatch [B] int32 = (total != expect) -- and every mismatch adds 1 to ``bad_count`` (1-element int32)."""
     _chk(dur, torch.int32, "dur")
     B, Ts = dur.shape
     cum = torch.empty(B, Ts, device=dur.device, dtype=torch.int32)
     lens = torch.empty(B, device=dur.device, dtype=torch.int32)
-    _ok(lib().fs2hip_duration_cumsum(_p(dur), _p(cum), _p(lens), B, Ts, int(Tm), _stream()), "duration_cumsum")
-    return cum, lens
+    mismatch = None
+    if expect is not None:
+        _chk(expect, torch.int32, "expect")
+        _req(expect.numel() == B, "duration_cumsum: expect size")
+        mismatch = torch.empty(B, device=dur.device, dtype=torch.int32)
+        if bad_count is not None:
+            _chk(bad_count, torch.int32, "bad_count")
+            _req(bad_count.numel() == 1, "duration_cumsum: bad_count is one word")
+    _ok(lib().fs2hip_duration_cumsum(_p(dur), _p(cum), _p(lens), _p(expect), _p(mismatch),
+                                     _p(bad_count) if expect is not None else None, B, Ts, int(Tm), _stream()),
+        "duration_cumsum")
+    return (cum, lens) if expect is None else (cum, lens, mismatch)
 
 
 def avg_variance(var, cum):

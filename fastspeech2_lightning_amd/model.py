@@ -41,6 +41,7 @@ class VarianceAdaptor:
 
     def __init__(self, S: P.ParamStore, env: M.Env, config: FastSpeech2Config, stats: Stats):
         self.S, self.env, self.config = S, env, config
+        self.bad_count = None  # set by the model: persistent device word counting duration / mel_lens mismatches
         vp, d = config.model.variance_predictors, config.model.encoder.input_dim
         pre = "variance_adaptor."
         # declaration order = execution order: energy, pitch, duration
@@ -94,7 +95,9 @@ class VarianceAdaptor:
                 if tgt is not None and tgt.shape[1] == Ts and Ts != Tm_:
                     raise ValueError("pitch/energy targets are already phone-averaged: learned alignment needs "
                                      "frame-level targets (fs2/variance_adaptor.py:269-279)")
-            cum_a, _ = H.duration_cumsum(dur_aligned, Tm_)
+            # fs2/variance_adaptor.py:289-305: the aligner's durations must add up to mel_lens; the per-utterance
+            # flags stay on the device (FastSpeech2.check_bad_data reads them, no sync in a training step)
+            cum_a, _, c["bad"] = H.duration_cumsum(dur_aligned, Tm_, expect=mel_lens, bad_count=self.bad_count)
             if energy_t is not None and cfg.energy.level.value == "phone":
                 energy_t = H.avg_variance(energy_t, cum_a)
             if pitch_t is not None and cfg.pitch.level.value == "phone":
@@ -255,6 +258,33 @@ class FastSpeech2Loss:
         return losses
 
 
+class _DeliverGrad(torch.autograd.Function):
+    """What makes ``training_step``'s result a loss autograd can differentiate (fs2/model.py:384-390 returns the
+    loss and Lightning calls ``loss.backward()``).  The backward pass itself has already run inside ``training_step``
+    -- explicit launch sequences on two HIP streams, no tape -- and left d(total)/d(parameters) in the flat gradient
+    buffer; this node's backward only hands that buffer to autograd as the flat parameter's gradient (an alias, no
+    copy) after multiplying it by the upstream gradient (a device scalar: exactly 1 for ``loss.backward()``, 1/N when
+    the caller divides the loss for gradient accumulation; the pass is skipped for 1)."""
+
+    @staticmethod
+    def forward(ctx, flat_param, total, model):
+        ctx.model = model
+        return total.view_as(total)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        m = ctx.model
+        g = m.store.grad
+        with torch.cuda.device(g.device):
+            H.scale_dev(g, grad_out.to(torch.float32).reshape(1).contiguous())
+        p = m.flat_param
+        if p.grad is not None and p.grad.untyped_storage().data_ptr() == g.untyped_storage().data_ptr():
+            # gradient accumulation without zero_grad(): the previous delivery aliases the buffer the backward pass has
+            # just overwritten -- impossible to add to.  training_step() moves it aside before it runs (see there).
+            raise RuntimeError("FastSpeech2: the previous step's gradient still aliases the flat gradient buffer")
+        return g.view(g.shape), None, None
+
+
 class FastSpeech2(_Base):
     _VERSION: str = "1.2"
 
@@ -330,6 +360,13 @@ class FastSpeech2(_Base):
             self.postnet = None
             self.output_key = "output"
         S.finalize(self.device_, seed)
+        # the one nn.Parameter autograd / torch.optim / Lightning see: an alias of the flat buffer (its .grad, once
+        # loss.backward() has run, an alias of the flat gradient buffer)
+        self.flat_param = torch.nn.Parameter(S.flat)
+        self.bad_count = torch.zeros(1, device=self.device_, dtype=torch.int32)
+        self._bad_seen, self._pending_bad, self._in_step = 0, [], False
+        if self.variance_adaptor is not None:
+            self.variance_adaptor.bad_count = self.bad_count
         self._reorder_state_dict_keys()
         self.loss = FastSpeech2Loss(self)
         self._tables = {}
@@ -380,7 +417,10 @@ class FastSpeech2(_Base):
         return self.train(False)
 
     def parameters(self, recurse=True):  # the flat buffer is the parameter
-        return iter([self.store.flat])
+        return iter([self.flat_param])
+
+    def named_parameters(self, *a, **k):
+        return iter([("flat_param", self.flat_param)])
 
     def state_dict(self, *a, **k):
         return self.store.state_dict()
@@ -433,6 +473,8 @@ class FastSpeech2(_Base):
 
     def _forward(self, batch, control=None, inference=False):
         H.set_precision(self.precision)
+        if self.env.stored:
+            self.store.refresh_bf16()  # the weights as bf16, once per step: every GEMM orientation reads this mirror
         control = control or InferenceControl()
         if "duration_control" in batch and batch["duration_control"] and batch["duration_control"][0]:
             control.duration = batch["duration_control"][0]
@@ -474,6 +516,10 @@ class FastSpeech2(_Base):
         va, va_ctx = self.variance_adaptor.fwd(x, batch, src_lens, self._table, int(Tm), control, inference,
                                                teacher_forcing, text_emb=inputs)
         self._hard_idx = va_ctx.get("hard_idx")
+        if va_ctx.get("bad") is not None:
+            self._pending_bad.append((va_ctx["bad"], list(batch.get("basename") or [])))
+            if len(self._pending_bad) > 4096:
+                self.check_bad_data()
         self._early_ctc = None
         if save and va.get("attn_logprob") is not None and self.env.side_enabled:
             # The forward-sum (CTC) loss of the aligner and its gradient are a 2 x Tm-step serial recursion per
@@ -500,6 +546,8 @@ class FastSpeech2(_Base):
         if self.env.training and self.store.bn_counters.numel():
             self.store.bn_counters.add_(1)  # every BatchNorm of the model has run once in train mode
         self.env.join()  # variance predictors of a teacher-forced forward ran on the side stream under the decoder
+        if not self._in_step:  # called directly (evaluation, teacher forcing): raise at once, as the reference does
+            self.check_bad_data()
         return {
             "output": output, "postnet_output": postnet_output,
             "src_mask": H.mask_from_lens(src_lens, Ts), "src_lens": src_lens,
@@ -583,22 +631,52 @@ class FastSpeech2(_Base):
 
     # ---- Lightning-style hooks ----------------------------------------------------------------------
     def training_step(self, batch, batch_idx=0):
-        """fs2/model.py:384-390 -- forward, losses, and (here) the backward pass as well."""
+        """fs2/model.py:384-390 -- forward, losses, and (here) the backward pass as well.  Returns the total loss as a
+        tensor autograd can differentiate with respect to the flat parameter: ``loss.backward()`` (Lightning's automatic
+        optimization, or a plain torch loop) delivers the gradient this call has already computed -- see
+        ``_DeliverGrad``.  The native loops (``fs2l train``, ``bench.py``) skip that call and let the optimizer read
+        the flat gradient buffer directly."""
         if not self.training:
             raise RuntimeError("training_step() needs model.train()")
-        output = self(batch)
-        losses = self.loss(output, self._ctx["batch"], self.current_epoch)
-        self.backward()
+        p = self.flat_param
+        if p.grad is not None and p.grad.untyped_storage().data_ptr() == self.store.grad.untyped_storage().data_ptr():
+            p.grad = p.grad.clone()  # accumulation across steps (no zero_grad in between): keep what was delivered
+        self._in_step = True
+        try:
+            output = self(batch)
+            losses = self.loss(output, self._ctx["batch"], self.current_epoch)
+            self.backward()
+        finally:
+            self._in_step = False
         self.last_losses, self.last_output = losses, output
+        if torch.is_grad_enabled():
+            return _DeliverGrad.apply(p, losses["total"], self)
         return losses["total"]
+
+    def check_bad_data(self):
+        """fs2/variance_adaptor.py:289-305: raises ``BadDataError`` naming the utterances whose aligner durations did not
+        add up to ``mel_lens``.  One 4-byte read of the device counter; the per-utterance flags are only fetched when it
+        moved.  Called where the host synchronises anyway: a direct ``forward()``, ``validation_step``, the trainer's
+        logging interval."""
+        pend, self._pending_bad = self._pending_bad, []
+        if not pend:
+            return
+        n = int(self.bad_count.cpu())
+        if n == self._bad_seen:
+            return
+        self._bad_seen = n
+        mismatches = [name for flags, names in pend for name, f in zip(names or map(str, range(flags.numel())), flags.cpu().tolist()) if f]
+        raise BadDataError(f"Something failed with the following items, please check them for errors: {mismatches}")
 
     def validation_step(self, batch, batch_idx=0):
         """fs2/model.py:515-528 (plots/audio logging are out of scope)."""
         was = self.training
         self.eval()
-        output = self(batch)
-        losses = self.loss(output, self.prepare_batch(batch), self.current_epoch)
-        self.train(was)
+        try:
+            output = self(batch)
+            losses = self.loss(output, self.prepare_batch(batch), self.current_epoch)
+        finally:
+            self.train(was)
         return losses
 
     def predict_step(self, batch, batch_idx=0):
@@ -609,12 +687,31 @@ class FastSpeech2(_Base):
         return out
 
     def configure_optimizers(self):
-        """fs2/model.py:530-549: AdamW + NoamLR stepped per optimizer step (both fused on the device)."""
-        from .optim import FusedAdamWNoam
+        """fs2/model.py:530-549: ``([AdamW], [{"scheduler": NoamLR, "interval": "step"}])`` -- here a
+        ``torch.optim.Optimizer`` whose ``step()`` is the fused clip + AdamW + schedule launch over the flat buffers and
+        a ``torch.optim.lr_scheduler.LRScheduler`` that mirrors the device-resident schedule on the host."""
+        from .optim import FusedAdamWNoam, NoamLR
         o = self.config.training.optimizer
         self.optimizer = FusedAdamWNoam(self.store, self.step_state, o.learning_rate, tuple(o.betas), o.eps,
-                                        o.weight_decay, o.warmup_steps)
-        return [self.optimizer], [{"scheduler": self.optimizer, "interval": "step"}]
+                                        o.weight_decay, o.warmup_steps, param=self.flat_param,
+                                        param_names=self.reference_parameter_names())
+        self.scheduler = NoamLR(self.optimizer, o.warmup_steps)
+        return [self.optimizer], [{"scheduler": self.scheduler, "interval": "step"}]
+
+    def configure_gradient_clipping(self, optimizer, gradient_clip_val=None, gradient_clip_algorithm=None):
+        """Lightning's hook for ``Trainer(gradient_clip_val=1.0)`` (fs2/cli/train.py:38), called between backward and
+        ``optimizer.step()``.  Global-norm clipping is part of the fused optimizer launch (the norm is one pass over
+        the flat gradient, the coefficient goes into the device record): the value is handed over instead of running
+        ``torch.nn.utils.clip_grad_norm_``.  Clipping by value has no fused form and takes torch's."""
+        from .optim import FusedAdamWNoam
+        if gradient_clip_algorithm in (None, "norm") and isinstance(optimizer, FusedAdamWNoam):
+            optimizer.max_grad_norm = gradient_clip_val
+            return
+        if gradient_clip_val:
+            if gradient_clip_algorithm == "value":
+                torch.nn.utils.clip_grad_value_(self.parameters(), gradient_clip_val)
+            else:
+                torch.nn.utils.clip_grad_norm_(self.parameters(), gradient_clip_val)
 
     # ---- checkpoint hooks (fs2/model.py:270-378) ------------------------------------------------------
     def on_save_checkpoint(self, checkpoint):
@@ -669,7 +766,8 @@ class FastSpeech2(_Base):
         ckpt = {"epoch": int(epoch), "global_step": int(global_step), "pytorch-lightning_version": "2.6.1",
                 "state_dict": OrderedDict((k, v.cpu()) for k, v in self.state_dict().items()),
                 "hyper_parameters": {"lang2id": dict(self.lang2id), "speaker2id": dict(self.speaker2id)},
-                "loops": {}, "callbacks": {}}
+                "callbacks": {}}  # (no "loops": Lightning then takes progress from global_step / epoch; an empty dict
+        #                          would be indexed for "fit_loop" by Trainer.fit(ckpt_path=...))
         if optimizer is not None:
             ckpt["optimizer_states"] = [optimizer.torch_state_dict(self.reference_parameter_names())]
             ckpt["lr_schedulers"] = [optimizer.torch_scheduler_state_dict()]

@@ -44,6 +44,16 @@ class Env:
         self._site += 1
         return self._site
 
+    @property
+    def stored(self) -> bool:
+        """"bf16-mixed" with bf16 operand STORAGE: between GEMMs, activations and gradients exist only as the bf16
+        operands those GEMMs read (written by the producing kernel: LayerNorm, a GEMM epilogue, BatchNorm + activation,
+        the depthwise convolution's backward), weights are read from the bf16 mirror of the flat buffer
+        (``ParamStore.refresh_bf16``, one cast pass per step) in every orientation, and a layer's bias gradient comes
+        out of its weight-gradient GEMM.  The residual stream, normalisation statistics, attention, losses and the
+        optimizer stay fp32."""
+        return H.GEMM_BF16 == 1 and H.BF16_STORAGE
+
     def drop(self, p: float, site: int) -> H.Drop:
         if not self.training or p <= 0.0:
             return H.NO_DROP
@@ -120,19 +130,20 @@ class LayerNorm:
         S.add(self.w, (dim,), "id", P.init_ones)
         S.add(self.b, (dim,), "id", P.init_zeros)
 
-    def fwd(self, x):
-        y, mean, rstd = H.layernorm_fwd(x, self.S.p(self.w), self.S.p(self.b))
+    def fwd(self, x, out_dtype=torch.float32):
+        y, mean, rstd = H.layernorm_fwd(x, self.S.p(self.w), self.S.p(self.b), out_dtype=out_dtype)
         return y, (x, mean, rstd)
 
-    def bwd(self, dy, saved, dx_add=None, nxt=None):
+    def bwd(self, dy, saved, dx_add=None, nxt=None, dz_dtype=torch.float32):
         """``nxt`` = (scale, Drop, bias gradient) of the sub-module below (its ``dz_spec()``): returns (dx, dz) with
-        dz = scale * dropmask * dx made, and its column sums (that bias gradient) started, by the same kernel."""
+        dz = scale * dropmask * dx made, and its column sums (that bias gradient) started, by the same kernel.
+        ``dy`` may be bf16 and dz is ``dz_dtype`` (bf16 operand storage)."""
         x, mean, rstd = saved
         if nxt is None:
             return H.layernorm_bwd(dy, x, self.S.p(self.w), mean, rstd, self.S.g(self.w), self.S.g(self.b), dx_add, defer=True)
         scale, drop, bias_grad = nxt
         return H.layernorm_bwd(dy, x, self.S.p(self.w), mean, rstd, self.S.g(self.w), self.S.g(self.b), dx_add, defer=True,
-                               dz_scale=scale, dz_drop=drop, dz_colsum=bias_grad)
+                               dz_scale=scale, dz_drop=drop, dz_colsum=bias_grad, dz_dtype=dz_dtype)
 
 
 class BatchNorm:
@@ -163,25 +174,34 @@ class BatchNorm:
 class FeedForward:
     """LayerNorm -> Linear(D,F) -> SiLU -> Dropout -> Linear(F,D) -> Dropout; y = x + 0.5 * f(x)."""
 
-    def __init__(self, S, env: Env, prefix, d, f, p):
-        self.S, self.env, self.p = S, env, p
+    def __init__(self, S, env: Env, prefix, d, f, p, dims_ok=False):
+        self.S, self.env, self.p, self.dims_ok = S, env, p, dims_ok
         self.ln = LayerNorm(S, prefix + "sequential.0.", d)
         self.w1, self.b1 = prefix + "sequential.1.weight", prefix + "sequential.1.bias"
         self.w2, self.b2 = prefix + "sequential.4.weight", prefix + "sequential.4.bias"
         decl_linear(S, prefix + "sequential.1.", f, d)
         decl_linear(S, prefix + "sequential.4.", d, f)
         self.s1, self.s2 = env.new_site(), env.new_site()
-        self.f = f
+        self.f, self.d = f, d
 
     def fwd(self, x):
         S, env = self.S, self.env
+        if env.stored and self.dims_ok:
+            bf = torch.bfloat16
+            h, ln_saved = self.ln.fwd(x, bf)
+            u = torch.empty(*x.shape[:-1], self.f, device=x.device, dtype=bf)
+            a = H.linear_fwd(h, S.pb(self.w1), S.p(self.b1), epi=H.EPI_ACT, act="silu", out_pre=u,
+                             drop=env.drop(self.p, self.s1), out_dtype=bf)
+            y = H.linear_fwd(a, S.pb(self.w2), S.p(self.b2), epi=H.EPI_RESID, resid=x, res_scale=0.5,
+                             drop=env.drop(self.p, self.s2))
+            return y, Ctx(ln=ln_saved, h=h, u=u, a=a, stored=True)
         h, ln_saved = self.ln.fwd(x)
         u = torch.empty(*x.shape[:-1], self.f, device=x.device, dtype=torch.float32)
         a = H.linear_fwd(h, S.p(self.w1), S.p(self.b1), epi=H.EPI_ACT, act="silu", out_pre=u,
                          drop=env.drop(self.p, self.s1))
         y = H.linear_fwd(a, S.p(self.w2), S.p(self.b2), epi=H.EPI_RESID, resid=x, res_scale=0.5,
                          drop=env.drop(self.p, self.s2))
-        return y, Ctx(ln=ln_saved, h=h, u=u, a=a)
+        return y, Ctx(ln=ln_saved, h=h, u=u, a=a, stored=False)
 
     def dz_spec(self):
         """(scale, Drop, bias gradient): what turns the gradient of this sub-module's output into the gradient dz of its
@@ -193,6 +213,18 @@ class FeedForward:
         (the return value is then (dx, next dz))."""
         S, env = self.S, self.env
         fused = dz is not None
+        if c.stored:
+            bf = torch.bfloat16
+            if not fused:  # (not reached from ConformerLayer.bwd, which always hands dz down)
+                dz = H.cast_bf16(H.axpby(dy, None, 0.5, 0.0, env.drop(self.p, self.s2)))
+            with env.side(dz, c.a):
+                H.linear_bwd_weight(dz, c.a, S.g(self.w2), bias_grad=None if fused else S.g(self.b2))
+            du = H.linear_bwd_data(dz, S.pb(self.w2), epi=H.EPI_DACT, act="silu", aux=c.u,
+                                   drop=env.drop(self.p, self.s1), out_dtype=bf)
+            with env.side(du, c.h):
+                H.linear_bwd_weight(du, c.h, S.g(self.w1), bias_grad=S.g(self.b1))
+            dh = H.linear_bwd_data(du, S.pb(self.w1), out_dtype=bf)
+            return self.ln.bwd(dh, c.ln, dx_add=dy, nxt=nxt, dz_dtype=bf)
         if not fused:
             dz = H.axpby(dy, None, 0.5, 0.0, env.drop(self.p, self.s2))
         with env.side(dz, c.a):
@@ -212,7 +244,8 @@ class SelfAttention:
 
     HEAD_DIMS = (16, 32, 64, 128)  # what the attention kernels are built for (fs2hip_attention_fwd refuses the rest)
 
-    def __init__(self, S, env: Env, prefix, d, heads, p):
+    def __init__(self, S, env: Env, prefix, d, heads, p, dims_ok=False):
+        self.dims_ok = dims_ok
         if heads <= 0 or d % heads or d // heads not in self.HEAD_DIMS:
             raise ValueError(f"Conformer attention: input_dim {d} / heads {heads} gives a head dimension of "
                              f"{d / max(heads, 1):g}; this build has attention kernels for head dimensions {self.HEAD_DIMS}")
@@ -225,15 +258,23 @@ class SelfAttention:
         S.add(self.wo, (d, d), "id", P.init_linear_weight)
         S.add(self.bo, (d,), "id", P.init_zeros)
         self.sa, self.so = env.new_site(), env.new_site()
+        self.d = d
 
     def fwd(self, x, lens):
         S, env = self.S, self.env
         B, T, _ = x.shape
+        if env.stored and self.dims_ok:
+            h, ln_saved = self.ln.fwd(x, torch.bfloat16)
+            qkv = H.linear_fwd(h, S.pb(self.wi), S.p(self.bi))  # fp32: the attention kernels' input
+            o, lse = H.attention_fwd(qkv, lens, B, T, self.heads, env.drop(self.p, self.sa))
+            ob = H.cast_bf16(o)
+            y = H.linear_fwd(ob, S.pb(self.wo), S.p(self.bo), epi=H.EPI_RESID, resid=x, drop=env.drop(self.p, self.so))
+            return y, Ctx(ln=ln_saved, h=h, qkv=qkv, o=o, ob=ob, lse=lse, lens=lens, stored=True)
         h, ln_saved = self.ln.fwd(x)
         qkv = H.linear_fwd(h, S.p(self.wi), S.p(self.bi))
         o, lse = H.attention_fwd(qkv, lens, B, T, self.heads, env.drop(self.p, self.sa))
         y = H.linear_fwd(o, S.p(self.wo), S.p(self.bo), epi=H.EPI_RESID, resid=x, drop=env.drop(self.p, self.so))
-        return y, Ctx(ln=ln_saved, h=h, qkv=qkv, o=o, lse=lse, lens=lens)
+        return y, Ctx(ln=ln_saved, h=h, qkv=qkv, o=o, lse=lse, lens=lens, stored=False)
 
     def dz_spec(self):
         return 1.0, self.env.drop(self.p, self.so), self.S.g(self.bo)
@@ -242,6 +283,18 @@ class SelfAttention:
         S, env = self.S, self.env
         B, T, _ = dy.shape
         fused = dz is not None
+        if c.stored:
+            bf = torch.bfloat16
+            if not fused:
+                dz = H.cast_bf16(H.axpby(dy, None, 1.0, 0.0, env.drop(self.p, self.so)))
+            with env.side(dz, c.ob):
+                H.linear_bwd_weight(dz, c.ob, S.g(self.wo), bias_grad=None if fused else S.g(self.bo))
+            do = H.linear_bwd_data(dz, S.pb(self.wo))  # fp32: the attention kernels' input
+            dqkv = H.cast_bf16(H.attention_bwd(c.qkv, c.lens, c.o, do, c.lse, B, T, self.heads, env.drop(self.p, self.sa)))
+            with env.side(dqkv, c.h):
+                H.linear_bwd_weight(dqkv, c.h, S.g(self.wi), bias_grad=S.g(self.bi))
+            dh = H.linear_bwd_data(dqkv, S.pb(self.wi), out_dtype=bf)
+            return self.ln.bwd(dh, c.ln, dx_add=dy, nxt=nxt, dz_dtype=bf)
         if not fused:
             d_o = env.drop(self.p, self.so)
             dz = H.axpby(dy, None, 1.0, 0.0, d_o) if d_o.p > 0 else dy
@@ -264,7 +317,8 @@ class ConvModule:
 
     KERNEL_SIZES = (3, 5, 7, 9, 15, 31)  # depthwise-convolution widths the kernels are instantiated for
 
-    def __init__(self, S, env: Env, prefix, d, k, p):
+    def __init__(self, S, env: Env, prefix, d, k, p, dims_ok=False):
+        self.dims_ok = dims_ok
         if k not in self.KERNEL_SIZES:
             raise ValueError(f"Conformer convolution module: depthwise kernel size {k}; this build carries {self.KERNEL_SIZES}")
         self.S, self.env, self.p, self.k, self.d = S, env, p, k, d
@@ -285,13 +339,22 @@ class ConvModule:
     def fwd(self, x):
         S, env = self.S, self.env
         B, T, _ = x.shape
-        h, ln_saved = self.ln.fwd(x)
-        g2 = H.linear_fwd(h, S.p(self.w1), S.p(self.b1))
+        stored = env.stored and self.dims_ok
+        if stored:
+            h, ln_saved = self.ln.fwd(x, torch.bfloat16)
+            g2 = H.linear_fwd(h, S.pb(self.w1), S.p(self.b1))  # fp32: GLU + depthwise convolution + BN statistics
+        else:
+            h, ln_saved = self.ln.fwd(x)
+            g2 = H.linear_fwd(h, S.p(self.w1), S.p(self.b1))
         c, parts = H.dwconv_fwd(g2, S.p(self.wd), S.p(self.bd), B, T, glu=True, stats=env.training)
         stats = self.bn.stats(parts, env.training)
-        s = H.bn_act_fwd(c, stats, "silu")
-        y = H.linear_fwd(s, S.p(self.w2), S.p(self.b2), epi=H.EPI_RESID, resid=x, drop=env.drop(self.p, self.site))
-        return y, Ctx(ln=ln_saved, h=h, g2=g2, c=c, stats=stats, s=s)
+        if stored:
+            s = H.bn_act_fwd(c, stats, "silu", bf16_only=True)
+            y = H.linear_fwd(s, S.pb(self.w2), S.p(self.b2), epi=H.EPI_RESID, resid=x, drop=env.drop(self.p, self.site))
+        else:
+            s = H.bn_act_fwd(c, stats, "silu")
+            y = H.linear_fwd(s, S.p(self.w2), S.p(self.b2), epi=H.EPI_RESID, resid=x, drop=env.drop(self.p, self.site))
+        return y, Ctx(ln=ln_saved, h=h, g2=g2, c=c, stats=stats, s=s, stored=stored)
 
     def dz_spec(self):
         return 1.0, self.env.drop(self.p, self.site), self.S.g(self.b2)
@@ -300,6 +363,20 @@ class ConvModule:
         S, env = self.S, self.env
         B, T, _ = dy.shape
         fused = dz is not None
+        gg, gb = self.bn.grads()
+        if c.stored:
+            bf = torch.bfloat16
+            if not fused:
+                dz = H.cast_bf16(H.axpby(dy, None, 1.0, 0.0, env.drop(self.p, self.site)))
+            with env.side(dz, c.s):
+                H.linear_bwd_weight(dz, c.s, S.g(self.w2), bias_grad=None if fused else S.g(self.b2))
+            ds = H.linear_bwd_data(dz, S.pb(self.w2))
+            dc = H.bn_act_bwd(ds, c.c, c.stats, gg, gb, "silu", training=env.training)
+            dg2 = H.dwconv_bwd(dc, c.g2, S.p(self.wd), S.g(self.wd), S.g(self.bd), B, T, glu=True, out_dtype=bf)
+            with env.side(dg2, c.h):
+                H.linear_bwd_weight(dg2, c.h, S.g(self.w1), bias_grad=S.g(self.b1))
+            dh = H.linear_bwd_data(dg2, S.pb(self.w1), out_dtype=bf)
+            return self.ln.bwd(dh, c.ln, dx_add=dy, nxt=nxt, dz_dtype=bf)
         if not fused:
             d_o = env.drop(self.p, self.site)
             dz = H.axpby(dy, None, 1.0, 0.0, d_o) if d_o.p > 0 else dy
@@ -308,7 +385,6 @@ class ConvModule:
             if not fused:
                 H.colsum_grad(dz, S.g(self.b2))
         ds = H.linear_bwd_data(dz, S.p(self.w2))
-        gg, gb = self.bn.grads()
         dc = H.bn_act_bwd(ds, c.c, c.stats, gg, gb, "silu", training=env.training)
         dg2 = H.dwconv_bwd(dc, c.g2, S.p(self.wd), S.g(self.wd), S.g(self.bd), B, T, glu=True)
         with env.side(dg2, c.h):
@@ -320,10 +396,13 @@ class ConvModule:
 
 class ConformerLayer:
     def __init__(self, S, env, prefix, d, f, heads, k, p):
-        self.ffn1 = FeedForward(S, env, prefix + "ffn1.", d, f, p)
-        self.attn = SelfAttention(S, env, prefix, d, heads, p)
-        self.conv = ConvModule(S, env, prefix + "conv_module.", d, k, p)
-        self.ffn2 = FeedForward(S, env, prefix + "ffn2.", d, f, p)
+        # bf16 operand storage (Env.stored) is decided for the whole layer: the gradient a sub-module's LayerNorm
+        # backward hands to the sub-module below has that sub-module's operand type
+        ok = d % 8 == 0 and f % 8 == 0
+        self.ffn1 = FeedForward(S, env, prefix + "ffn1.", d, f, p, ok)
+        self.attn = SelfAttention(S, env, prefix, d, heads, p, ok)
+        self.conv = ConvModule(S, env, prefix + "conv_module.", d, k, p, ok)
+        self.ffn2 = FeedForward(S, env, prefix + "ffn2.", d, f, p, ok)
         self.final = LayerNorm(S, prefix + "final_layer_norm.", d)
 
     def fwd(self, x, lens):
@@ -338,7 +417,7 @@ class ConformerLayer:
         c1, c2, c3, c4, c5 = c
         # every LayerNorm backward also makes the dropout-masked, scaled gradient (and the bias gradient) the
         # sub-module below starts from
-        d, dz = self.final.bwd(dy, c5, nxt=self.ffn2.dz_spec())
+        d, dz = self.final.bwd(dy, c5, nxt=self.ffn2.dz_spec(), dz_dtype=torch.bfloat16 if c4.stored else torch.float32)
         d, dz = self.ffn2.bwd(d, c4, dz, nxt=self.conv.dz_spec())
         d, dz = self.conv.bwd(d, c3, dz, nxt=self.attn.dz_spec())
         d, dz = self.attn.bwd(d, c2, dz, nxt=self.ffn1.dz_spec())
@@ -659,28 +738,26 @@ class PostNet:
             S.add(b, (chans[i + 1],), "id", P.init_bias_for(chans[i] * k))
             self.convs.append((w, b, BatchNorm(S, q + "1.", chans[i + 1]), env.new_site()))
 
-    def _stored(self):
-        """bf16-mixed with operand storage: a convolution whose input (forward) or output gradient (backward) has a
-        channel count that fills whole K-tiles per tap reads it as bf16 from memory -- the BatchNorm kernel that
-        produces it writes the bf16 copy in the same pass; the weights are cast when they are used."""
-        return H.GEMM_BF16 == 1 and H.BF16_STORAGE
-
     def fwd(self, x):
+        """bf16 operand storage (``Env.stored``; needs T >= 64 for the weight-gradient form): every 512-channel
+        activation exists only as the bf16 tensor the next convolution reads -- written by the BatchNorm + tanh +
+        dropout kernel -- and the convolutions read the weights from the bf16 mirror.  The first convolution's input
+        (80 mel bins: not whole 64-deep K-tiles per tap) stays on the fp32-operand core."""
         S, env = self.S, self.env
         B, T, _ = x.shape
+        stored = env.stored and T >= 64
         saved = []
-        xb = None  # bf16 copy of x, when the layer that produced it was asked for one
         for i, (w, b, bn, site) in enumerate(self.convs):
-            if xb is not None:
-                raw = H.linear_fwd(xb.view(B * T, -1), H.cast_bf16(S.p(w)), S.p(b), taps=self.k, T=T).view(B, T, -1)
+            if x.dtype == torch.bfloat16:
+                raw = H.linear_fwd(x.view(B * T, -1), S.pb(w), S.p(b), taps=self.k, T=T).view(B, T, -1)
             else:
                 raw = H.linear_fwd(x, S.p(w), S.p(b), taps=self.k, T=T)
             stats = bn.stats(H.colstats(raw) if env.training else None, env.training)
             act = "tanh" if i < self.n - 1 else None
-            want_b = self._stored() and i + 1 < self.n and raw.shape[-1] % 64 == 0
-            out = H.bn_act_fwd(raw, stats, act, env.drop(self.dropout_p, site), bf16_copy=want_b)
+            want_b = stored and i + 1 < self.n and raw.shape[-1] % 64 == 0
+            out = H.bn_act_fwd(raw, stats, act, env.drop(self.dropout_p, site), bf16_only=want_b)
             saved.append((x, raw, stats))
-            x, xb = out if want_b else (out, None)
+            x = out
         return x, saved
 
     def bwd(self, dy, saved, need_dx=True):
@@ -692,16 +769,30 @@ class PostNet:
             gg, gb = bn.grads()
             act = "tanh" if i < self.n - 1 else None
             need = i > 0 or need_dx
-            want_b = need and self._stored() and raw.shape[-1] % 64 == 0
-            draw = H.bn_act_bwd(dy, raw, stats, gg, gb, act, env.drop(self.dropout_p, site), training=env.training,
-                                bf16_copy=want_b)
-            draw, draw_b = draw if want_b else (draw, None)
-            with env.side(draw, x):
-                H.linear_bwd_weight(draw, x, S.g(w), taps=self.k, T=T)
-                H.colsum_grad(draw, S.g(b))
-            if need and draw_b is not None:
-                wt = H.transpose_cast_bf16(S.p(w))  # [taps, Cout, Cin] -> per tap [Cin, Cout] in bf16
-                dy = H.linear_bwd_data(draw_b.view(B * T, -1), wt, taps=self.k, T=T).view(B, T, -1)
+            cout = raw.shape[-1]
+            drop = env.drop(self.dropout_p, site)
+            # the bf16 forms follow what the forward pass kept: a layer whose input (or whose successor's input) is
+            # bf16 takes its output gradient as bf16 from the BatchNorm backward kernel
+            nxt_b = i + 1 < self.n and saved[i + 1][0].dtype == torch.bfloat16   # this layer's output was bf16-only
+            x_b = x.dtype == torch.bfloat16
+            if not (nxt_b or x_b):
+                draw = H.bn_act_bwd(dy, raw, stats, gg, gb, act, drop, training=env.training)
+                with env.side(draw, x):
+                    H.linear_bwd_weight(draw, x, S.g(w), taps=self.k, T=T)
+                    H.colsum_grad(draw, S.g(b))
+                if need:
+                    dy = H.linear_bwd_data(draw, S.p(w), taps=self.k, T=T)
+                continue
+            dgrad_b = need and cout % 64 == 0 and x.shape[-1] % 8 == 0
+            if need and not dgrad_b:
+                draw, draw_b = H.bn_act_bwd(dy, raw, stats, gg, gb, act, drop, training=env.training, bf16_copy=True)
+            else:
+                draw, draw_b = None, H.bn_act_bwd(dy, raw, stats, gg, gb, act, drop, training=env.training, bf16_only=True)
+            xb = x if x_b else H.cast_bf16(x)  # (first layer: the 80-bin input, cast for the weight gradient only)
+            with env.side(draw_b, xb):
+                H.linear_bwd_weight(draw_b.view(B * T, -1), xb.view(B * T, -1), S.g(w), taps=self.k, T=T, bias_grad=S.g(b))
+            if need and dgrad_b:
+                dy = H.linear_bwd_data(draw_b.view(B * T, -1), S.pb(w), taps=self.k, T=T).view(B, T, -1)
             elif need:
                 dy = H.linear_bwd_data(draw, S.p(w), taps=self.k, T=T)
         return dy

@@ -61,3 +61,17 @@ class GradSync:
     @property
     def grad_scale(self) -> float:
         return 1.0 / self.world
+
+
+def share_tile_table(src: int = 0, process_group=None) -> int:
+    """Every rank adopts rank ``src``'s tuned GEMM tiles (``hip.tile_table``): the same tiles mean the same summation
+    order on every rank, so ranks fed identical data produce identical bits (debugging) and no rank runs a tile that
+    lost the timing race elsewhere.  Returns the number of signatures in the table."""
+    from . import hip as H
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
+        return len(H.tile_table())
+    box = [H.tile_table() if dist.get_rank(process_group) == src else None]
+    dist.broadcast_object_list(box, src=src, group=process_group)
+    if dist.get_rank(process_group) != src:
+        H.load_tile_table(box[0])
+    return len(box[0])

@@ -101,7 +101,7 @@ class Entry:
 
 
 class ParamStore:
-    ALIGN = 4  # floats (16 B) so that every view is float4-addressable
+    ALIGN = 8  # elements: every view starts 16-byte aligned in the fp32 buffers AND in the bf16 mirror of the weights
 
     def __init__(self):
         self.entries: "OrderedDict[str, Entry]" = OrderedDict()
@@ -163,7 +163,22 @@ class ParamStore:
             self.buffers[n] = self.bn_counters[i]
         self.device = torch.device(device)
         self._pviews, self._gviews = {}, {}
+        self.flat_bf16, self._bviews = None, {}
         return self
+
+    # ---- bf16 mirror of the weights ("bf16-mixed" with operand storage): ONE cast pass over the flat buffer per step;
+    # the GEMMs read weights from it in every orientation, so no per-layer casts and no transposed copies exist ----
+    def refresh_bf16(self):
+        from . import hip as H
+        if self.flat_bf16 is None:
+            self.flat_bf16 = torch.empty(self.total, device=self.flat.device, dtype=torch.bfloat16)
+        H.cast_bf16(self.flat, out=self.flat_bf16)
+
+    def pb(self, name):
+        v = self._bviews.get(name)
+        if v is None:
+            v = self._bviews[name] = self._view(self.flat_bf16, name)
+        return v
 
     def _view(self, base, name):
         e = self.entries[name]

@@ -109,7 +109,18 @@ typedef struct {
                        shapes those cores refuse run in fp32.  3: bf16 operand STORAGE -- A and B point to bf16
                        (k-contiguous rows: a_kcontig = b_kcontig = 1; lda, ldb, R, b_tap_stride in bf16 elements, all
                        multiples of 8, tap widths multiples of 64; no split-K), C, bias and the epilogue tensors stay
-                       fp32; tiles 4..9 */
+                       fp32; tiles 4..9.  4: the bf16-storage core (gemm_bf16.hip; tiles 20..23) -- A and B point to bf16 in
+                       ANY of the three orientations (forward a_kcontig = b_kcontig = 1; data gradient a_kcontig = 1 with
+                       the weight as stored, b_kcontig = 0; weight gradient both 0, split-K allowed), lda / ldb / R /
+                       b_tap_stride / c_tap_stride in elements; R, lda, ldb multiples of 8, the row count of a
+                       reduction-major operand a multiple of 8, Nc and ldc multiples of 4; tap widths multiples of 64
+                       (shift_operand = 0) / T >= 64 (shift_operand = 1); bias, resid and split-K slabs fp32 */
+  int io_bf16;   /* operand_bf16 == 4 only.  bit 0: C and out_pre are bf16 (ldc / ldpre in elements; the activation of
+                    FS2_EPI_ACT is applied to the ROUNDED pre-activation, i.e. to what the backward pass reads back);
+                    bit 1: aux is bf16 */
+  float* colsum; /* operand_bf16 == 4, weight gradient (a_kcontig = b_kcontig = 0) only, or NULL: receives the column
+                    sums of A over the reduction -- the bias gradient dY^T . 1 of the layer whose weight gradient this
+                    launch computes -- as colsum[split][Mc] partial sums (splitk rows; the caller adds them) */
 } Fs2GemmArgs;
 #define FS2_SPLITK_COUNTERS 4096
 
@@ -159,6 +170,18 @@ int fs2hip_layernorm_bwd_dz(const float* dy, const float* x, const float* gamma,
                             const float* rstd, const float* dx_add, float* dx, float* dz, float dz_scale,
                             float drop_p, unsigned long long drop_seed, const unsigned long long* drop_step,
                             float* partial, int M, int C, void* stream);
+/* bf16 on either side of a LayerNorm ("bf16-mixed" with bf16 activation storage: the normalised activations and the
+ * gradients between GEMMs exist only as the bf16 operands those GEMMs read).
+ *   fwd_b: y is bf16.
+ *   bwd_x: flags bit 0: dy is bf16 (the result of a data-gradient GEMM); bit 1: dz is bf16.  dz == NULL: no second
+ *          output and partial is [nblk][2][C]; else [nblk][3][C] (the column sums are those of the rounded dz).
+ *          dx_add, dx stay fp32 (the residual stream).  The caller finishes the partial sums. */
+int fs2hip_layernorm_fwd_b(const float* x, const float* gamma, const float* beta, void* y_bf16,
+                           float* mean, float* rstd, int M, int C, float eps, void* stream);
+int fs2hip_layernorm_bwd_x(const void* dy, const float* x, const float* gamma, const float* mean,
+                           const float* rstd, const float* dx_add, float* dx, void* dz, float dz_scale,
+                           float drop_p, unsigned long long drop_seed, const unsigned long long* drop_step,
+                           float* partial, int M, int C, int flags, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Multi-head self-attention with key-padding mask (flash style; fp32 MFMA: v_mfma_f32_32x32x2_f32 for
@@ -198,6 +221,9 @@ int fs2hip_dwconv_fwd(const float* x, int ldx, const float* w, const float* bias
                       int B, int T, int C, int K, int glu, int stats, void* stream);
 int fs2hip_dwconv_bwd(const float* dy, const float* x, int ldx, const float* w, float* dx, float* partial,
                       float* dw, float* dbias, int B, int T, int C, int K, int glu, void* stream);
+/* the same with dx written as bf16 when dx_bf16 != 0 (layout and leading dimension of x) */
+int fs2hip_dwconv_bwd_b(const float* dy, const float* x, int ldx, const float* w, void* dx, int dx_bf16, float* partial,
+                        float* dw, float* dbias, int B, int T, int C, int K, int glu, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * BatchNorm1d over the channels of [M][C] (+ activation + dropout), fs2/layers.py:204-212 and
@@ -224,8 +250,9 @@ int fs2hip_bn_act_bwd(const float* dout, const float* y, const float* stats, flo
                       float* dgamma, float* dbeta, float* dy, int M, int C, int act, float drop_p,
                       unsigned long long drop_seed, const unsigned long long* drop_step, int training,
                       void* stream);
-/* The same two with a second, bf16 copy of the output (out_bf16 / dy_bf16, [M][C] bf16, may be NULL) for a consuming GEMM
- * that reads bf16 operands from memory (Fs2GemmArgs.operand_bf16 == 3): the PostNet convolutions in "bf16-mixed". */
+/* The same two with a bf16 form of the output (out_bf16 / dy_bf16, [M][C] bf16) for a consuming GEMM that reads bf16
+ * operands from memory (Fs2GemmArgs.operand_bf16 == 4).  Either output pointer may be NULL (not both): with out / dy
+ * NULL the tensor exists only in bf16. */
 int fs2hip_bn_act_fwd_b(const float* y, const float* stats, float* out, void* out_bf16, int M, int C, int act,
                         float drop_p, unsigned long long drop_seed, const unsigned long long* drop_step, void* stream);
 int fs2hip_bn_act_bwd_b(const float* dout, const float* y, const float* stats, float* partial, float* coef,
@@ -260,8 +287,12 @@ int fs2hip_length_regulate_fwd(const float* x, const int* dur, const float* pose
                                void* stream);
 int fs2hip_length_regulate_bwd(const float* dy, const int* cum, float* dx, int B, int Ts, int Tm, int D,
                                void* stream);
-/* cum [B][Ts] inclusive cumulative durations, out_lens [B] = min(total, Tm) (the first half of the forward) */
-int fs2hip_duration_cumsum(const int* dur, int* cum, int* out_lens, int B, int Ts, int Tm, void* stream);
+/* cum [B][Ts] inclusive cumulative durations, out_lens [B] = min(total, Tm) (the first half of the forward).
+ * expect_lens / mismatch (both or neither) + optional bad_count: the consistency check of the aligner's durations,
+ * fs2/variance_adaptor.py:289-305 -- mismatch[b] = (total of utterance b != expect_lens[b]); each mismatch also adds 1
+ * to *bad_count, a persistent device word the host polls instead of the per-utterance flags (no sync in a step). */
+int fs2hip_duration_cumsum(const int* dur, int* cum, int* out_lens, const int* expect_lens, int* mismatch,
+                           int* bad_count, int B, int Ts, int Tm, void* stream);
 
 /* predictor head (fs2/variance_adaptor.py:53-62): out[m] = (x[m,:].w + b) * (t < lens[b]) */
 int fs2hip_rowdot_fwd(const float* x, const float* w, const float* bias, const int* lens, float* out, int M,
@@ -301,6 +332,9 @@ int fs2hip_transpose_cast_bf16(const float* src, int rows, int cols, int ld_src,
 int fs2hip_axpby(const float* x, const float* y, float* out, long long n, float a, float b, float drop_p,
                  unsigned long long drop_seed, const unsigned long long* drop_step, void* stream);
 int fs2hip_add_rowvec(const float* x, const float* e, float* out, int B, int T, int D, void* stream);
+/* x *= *scalar (scalar in device memory; a no-op pass when it is exactly 1): the upstream gradient that autograd hands
+ * to the node behind FastSpeech2.training_step's loss (fs2/model.py:384-390 returns the loss Lightning differentiates) */
+int fs2hip_scale_dev(float* x, long long n, const float* scalar, void* stream);
 /* out = dy * act'(aux) (aux = activation output for ReLU, input otherwise); bool mask t < lens[b]
  * (fs2/utils/heavy.py:11-15); out[0] = sum of n loss slots (fs2/loss.py:125) */
 int fs2hip_dact_mul(const float* dy, const float* aux, float* out, long long n, int act, void* stream);

@@ -338,7 +338,7 @@ def dump_ckpt(out_dir: Path):
     ref.train()
     opt, sched, losses = reference_train_steps(ref, batch, 3)
     ckpt = {"epoch": 0, "global_step": 3, "pytorch-lightning_version": "2.6.1",
-            "state_dict": ref.state_dict(), "loops": {}, "callbacks": {},
+            "state_dict": ref.state_dict(), "callbacks": {},  # (no "loops": Lightning would index an empty dict for "fit_loop")
             "optimizer_states": [opt.state_dict()], "lr_schedulers": [sched.state_dict()],
             "hyper_parameters": {"config": ref.config, "stats": ref.stats, "lang2id": ref.lang2id,
                                  "speaker2id": ref.speaker2id}}

@@ -51,6 +51,7 @@ def test_reference_written_checkpoint_loads_and_resumes(golden_dir):
         assert np.abs(out[k].cpu().numpy() - want).max() < 1e-4 * max(1.0, np.abs(want).max()), k
     # resume: optimizer moments / step / schedule from torch's own state dicts
     opt = model.configure_optimizers()[0][0]
+    model.configure_gradient_clipping(opt, 1.0, "norm")  # Trainer(gradient_clip_val=1.0), fs2/cli/train.py:38
     step, epoch = model.restore_training_state(ckpt, opt)
     assert (step, epoch) == (3, 0) and opt.record()["step"] == 3
     before = {k: v.clone() for k, v in model.state_dict().items()}
@@ -84,6 +85,7 @@ def three_steps_from_seeded_weights(golden_dir):
     model.load_state_dict(O.seeded_state_dict(model.state_dict()))
     model.train()
     opt = model.configure_optimizers()[0][0]
+    model.configure_gradient_clipping(opt, 1.0, "norm")  # Trainer(gradient_clip_val=1.0), fs2/cli/train.py:38
     losses = []
     for _ in range(3):
         losses.append(float(model.training_step(batch)))

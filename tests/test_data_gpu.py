@@ -48,6 +48,7 @@ def _model(cfg):
     m = FastSpeech2(cfg, Stats(**C.STATS), lang2id=C.LANG2ID, speaker2id=C.SPEAKER2ID)
     m.postnet.dropout_p = 0.0
     m.configure_optimizers()
+    m.configure_gradient_clipping(m.optimizer, 1.0, "norm")
     return m
 
 

@@ -9,7 +9,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _rank(rank, world, port, q):
+def _rank(rank, world, port, q, variant="plain"):
     import torch.distributed as dist
     from fastspeech2_lightning_amd.config import Stats
     from fastspeech2_lightning_amd.model import FastSpeech2
@@ -18,13 +18,21 @@ def _rank(rank, world, port, q):
 
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-    config = C.small_config(learn_alignment=False)
-    model = FastSpeech2(config, Stats(**C.STATS), seed=1)  # same seed: same initial weights on both ranks
+    align, gst = variant == "learn_alignment", variant == "gst"
+    # gst: BASELINE.json configs[4]'s model family -- multi-speaker (+ multilingual) + GST reference encoder (80 mel bins)
+    # (the style-token layer emits 256 dims, so that case is the golden's d = 256, 1-layer configuration)
+    config = C.build("e2e_gst_multispeaker_train")[0] if gst else C.small_config(learn_alignment=align)
+    model = FastSpeech2(config, Stats(**C.STATS), lang2id=C.LANG2ID if gst else None,
+                        speaker2id=C.SPEAKER2ID if gst else None, seed=1)  # same seed: same initial weights on both ranks
     model.postnet.dropout_p = 0.0
     model.train()
     from oracle import fs2_oracle as O
     batches = [O.synthetic_batch(B=3, ts_lo=6, ts_hi=12, n_symbols=C.N_SYMBOLS, n_mels=config.preprocessing.audio.n_mels,
-                                 seed=100 + r, dur_hi=4) for r in range(world)]
+                                 seed=100 + r, dur_hi=9 if gst else 4, learn_alignment=align) for r in range(world)]
+    if gst:
+        for r, b in enumerate(batches):
+            b["speaker_id"] = torch.tensor([r, 1, 0], dtype=torch.int32) % len(C.SPEAKER2ID)
+            b["language_id"] = torch.tensor([0, r, 1], dtype=torch.int32) % len(C.LANG2ID)
     # reference: both batches locally, no exchange
     local = []
     for b in batches:
@@ -46,7 +54,11 @@ def _rank(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_bucketed_exchange_world2_on_one_gpu():
+@pytest.mark.parametrize("variant", ["plain", "learn_alignment", "gst"])
+def test_bucketed_exchange_world2_on_one_gpu(variant):
+    """``learn_alignment``: the aligner's backward and the forward-sum loss run on the side stream and meet the main
+    chain at the text embedding's bucket; ``gst``: the style encoder's parameter gradients are produced on the side
+    stream beside the encoder's backward -- both must be complete when their bucket is handed to the all-reduce."""
     import torch.multiprocessing as mp
 
     with socket.socket() as s:
@@ -54,7 +66,7 @@ def test_bucketed_exchange_world2_on_one_gpu():
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_rank, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_rank, args=(r, 2, port, q, variant)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]

@@ -83,6 +83,7 @@ def test_train_step_with_dropout_on_matches_oracle_with_the_same_masks(p_conf, p
     model.train(); oracle.train()
     model.postnet.dropout_p = oracle.postnet.dropout_p = p_post
     opt = model.configure_optimizers()[0][0]
+    model.configure_gradient_clipping(opt, 1.0, "norm")  # Trainer(gradient_clip_val=1.0), fs2/cli/train.py:38
     seen0, loss0 = compare_step(model, oracle, batch, "step 0")
     # the masks are really on, with the right keep fraction
     for name, keep in seen0.items():

@@ -154,3 +154,83 @@ def test_configs4_bf16_mixed_gst_multispeaker_long_utterances():
         g, w = got[k].cpu(), dict(oracle.named_parameters())[k].grad
         assert float((g - w).norm() / w.norm()) < 0.15, k
     assert torch.equal(out["tgt_mask"].cpu(), ref["tgt_mask"])
+
+
+def test_configs1_full_size_learned_alignment_vs_oracle():
+    """The reference's DEFAULT model (``learn_alignment=True``, fs2/config/__init__.py:139-142) at the benchmark's size
+    -- batch 32, Tm = 648, tuned tiles, dropout on with the kernels' masks, epoch 10 so that the binarisation loss is on
+    (fs2/loss.py:117-122): the aligner's side-stream forward-sum loss, the one-wavefront-per-utterance alignment search
+    and the phone-averaged targets are what changes behaviour with size (fs2/variance_adaptor.py:249-305).
+    Durations from the alignment search must equal the oracle's exactly; losses 1e-4; gradients at the bounds of
+    ``test_configs1_full_size_train_step_vs_oracle`` (the aligner's projections contain ReLUs: its parameters and the
+    text embedding are in the ReLU-downstream group)."""
+    from fastspeech2_lightning_amd.model import FastSpeech2
+    config = FastSpeech2Config(model=dict(learn_alignment=True), text=default_symbols(64))
+    batch = synthetic_batch(B=32, ts_lo=96, ts_hi=128, n_symbols=64, n_mels=80, seed=1234, dur_hi=9, learn_alignment=True)
+    assert batch["mel"].shape[1] == 648 and batch["duration"].shape == (32, 648, 128)
+    torch.set_num_threads(max(torch.get_num_threads(), 16))
+    model = FastSpeech2(config, Stats(**DEFAULT_STATS), seed=1234)
+    oracle = O.FastSpeech2Oracle(config, Stats(**DEFAULT_STATS), n_symbols=64)
+    sd = O.seeded_state_dict(oracle.state_dict())
+    oracle.load_state_dict(sd)
+    model.load_state_dict(sd)
+    model.train(); oracle.train()
+    model.postnet.dropout_p = oracle.postnet.dropout_p = 0.5
+    DM.inject(model, oracle, 32, batch["text"].shape[1], 648)
+    epoch = 10
+    model.current_epoch_ = epoch
+    ref = oracle(batch)
+    ref_losses = oracle.loss(ref, batch, epoch)
+    ref_losses["total"].backward()
+    model.training_step(batch)
+    model.check_bad_data()
+    out = model.last_output
+    dur, dur_ref = out["duration_target"].cpu(), ref["duration_target"]
+    assert torch.equal(dur.to(dur_ref.dtype), dur_ref), int((dur.to(dur_ref.dtype) != dur_ref).sum())
+    assert torch.equal(out["attn_hard"].cpu(), ref["attn_hard"])
+    assert set(model.last_losses) >= {"attn_ctc", "attn_bin"} and float(ref_losses["attn_bin"]) != 0.0
+    for k, v in model.last_losses.items():
+        want = float(ref_losses[k])
+        assert abs(float(v) - want) < 1e-4 * max(1.0, abs(want)), (k, float(v), want)
+    mel, mel_ref = out["postnet_output"].cpu(), ref["postnet_output"].detach()
+    assert float(((mel - mel_ref) ** 2).mean()) < 1e-8
+    errs = grad_errors(model, oracle)
+    print(f"\n[learned alignment] gradient errors (worst tensor, max err / tensor max, group relative L2): {errs}")
+    assert errs["smooth"][1] < 2e-3 and errs["smooth"][2] < 1e-3, errs
+    assert errs["relu_downstream"][1] < 5e-2 and errs["relu_downstream"][2] < 5e-3, errs
+
+
+def test_configs2_bf16_mixed_batch64_full_size():
+    """BASELINE.json configs[2] as benchmarked (``bench.py --precision bf16-mixed --batch 64``): batch 64, Tm = 648,
+    default model, tuned tiles, dropout on with the kernels' masks, against the fp32 CPU oracle at the stated bf16
+    tolerances of ``test_bf16_mixed_train_step_within_the_reference_autocast_error``: mel MSE < 1e-3, total loss 0.1 %,
+    every loss term 1 %, all parameter gradients together 10 % relative L2; masks and lengths exact."""
+    from fastspeech2_lightning_amd.model import FastSpeech2
+    config = FastSpeech2Config(model=dict(learn_alignment=False), text=default_symbols(64))
+    batch = synthetic_batch(B=64, ts_lo=96, ts_hi=128, n_symbols=64, n_mels=80, seed=1234, dur_hi=9)  # bench.py --batch 64
+    B, Ts, Tm = batch["mel"].shape[0], batch["text"].shape[1], batch["mel"].shape[1]
+    torch.set_num_threads(max(torch.get_num_threads(), 16))
+    model = FastSpeech2(config, Stats(**DEFAULT_STATS), seed=1234, precision="bf16-mixed")
+    oracle = O.FastSpeech2Oracle(config, Stats(**DEFAULT_STATS), n_symbols=64)
+    sd = O.seeded_state_dict(oracle.state_dict())
+    oracle.load_state_dict(sd)
+    model.load_state_dict(sd)
+    model.train(); oracle.train()
+    model.postnet.dropout_p = oracle.postnet.dropout_p = 0.5
+    DM.inject(model, oracle, B, Ts, Tm)
+    ref = oracle(batch)
+    ref_losses = oracle.loss(ref, batch, 0)
+    ref_losses["total"].backward()
+    model.training_step(batch)
+    out = model.last_output
+    o, r = out["postnet_output"].cpu(), ref["postnet_output"].detach()
+    mse = float(((o - r) ** 2).mean())
+    lrel = {k: abs(float(v) - float(ref_losses[k])) / abs(float(ref_losses[k])) for k, v in model.last_losses.items()}
+    got = model.store.grad_state_dict()
+    num = sum(float((got[k].cpu() - p.grad).pow(2).sum()) for k, p in oracle.named_parameters() if p.grad is not None)
+    den = sum(float(p.grad.pow(2).sum()) for p in oracle.parameters() if p.grad is not None)
+    print(f"\n[bf16-mixed, batch 64] mel MSE {mse:.3e}, loss errors {lrel}, gradient relative L2 {(num / den) ** 0.5:.4f}")
+    assert mse < 1e-3, mse
+    assert all(v < 1e-2 for v in lrel.values()) and lrel["total"] < 1e-3, lrel
+    assert (num / den) ** 0.5 < 0.1, (num / den) ** 0.5
+    assert torch.equal(out["tgt_mask"].cpu(), ref["tgt_mask"]) and torch.equal(out["src_mask"].cpu(), ref["src_mask"])

@@ -1,0 +1,170 @@
+"""The module under the reference's own call sites (boundary row (b)): Lightning's AUTOMATIC optimization
+-- ``configure_optimizers`` -> ``optimizer.step(closure)`` where the closure is ``zero_grad`` / ``training_step`` /
+``loss.backward()`` / ``configure_gradient_clipping`` -- restated here in a few lines (Lightning is not in the image),
+must reproduce the native loop's five steps (``fs2l train`` / ``bench.py``: flat gradient buffer read directly) to
+1e-6 and cost at most 2 % per step.
+
+reference: ``fs2/model.py:384-390`` (``training_step`` returns the loss, Lightning differentiates it),
+``fs2/model.py:530-549`` (``torch.optim.AdamW`` + ``NoamLR``, interval "step"), ``fs2/cli/train.py:33-41``
+(``gradient_clip_val=1.0``)."""
+import time
+
+import pytest
+import torch
+
+from fastspeech2_lightning_amd.config import Stats
+from oracle import cases as C
+from oracle import fs2_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(seed=3):
+    from fastspeech2_lightning_amd.model import FastSpeech2
+    config = C.small_config(learn_alignment=False)
+    config.training.optimizer.learning_rate = 1e-2
+    config.training.optimizer.warmup_steps = 3
+    model = FastSpeech2(config, Stats(**C.STATS), seed=seed)
+    model.train()
+    batch = O.synthetic_batch(B=4, ts_lo=6, ts_hi=12, n_symbols=C.N_SYMBOLS, n_mels=config.preprocessing.audio.n_mels,
+                              seed=11, dur_hi=4)
+    return model, batch
+
+
+def native_steps(n):
+    model, batch = _model()
+    opt = model.configure_optimizers()[0][0]
+    model.configure_gradient_clipping(opt, 1.0, "norm")
+    losses = []
+    for _ in range(n):
+        with torch.no_grad():
+            losses.append(float(model.training_step(batch)))
+        opt.step()
+    return model, losses
+
+
+def automatic_optimization(model, batch, n, clip="hook", accumulate=1):
+    """Lightning's fit loop for one optimizer, automatic optimization, ``gradient_clip_val=1.0``."""
+    opts, scheds = model.configure_optimizers()
+    opt, sched = opts[0], scheds[0]
+    assert isinstance(opt, torch.optim.Optimizer)
+    assert isinstance(sched["scheduler"], torch.optim.lr_scheduler.LRScheduler) and sched["interval"] == "step"
+    assert [p for g in opt.param_groups for p in g["params"]] == list(model.parameters())
+    losses, lrs = [], []
+    for i in range(n):
+        def closure():
+            opt.zero_grad()
+            total = 0.0
+            for _ in range(accumulate):
+                loss = model.training_step(batch, i)
+                assert loss.requires_grad and loss.grad_fn is not None and loss.dim() == 0
+                (loss / accumulate if accumulate > 1 else loss).backward()
+                total += float(loss.detach())
+            if clip == "hook":      # LightningModule.configure_gradient_clipping(optimizer, gradient_clip_val, algorithm)
+                model.configure_gradient_clipping(opt, 1.0, "norm")
+            else:                   # what the default hook does: clip_grad_norm_ over the optimizer's parameters
+                torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+            return total / accumulate
+        losses.append(opt.step(closure))
+        lrs.append(opt.param_groups[0]["lr"])
+        sched["scheduler"].step()
+    return opt, sched["scheduler"], losses, lrs
+
+
+@pytest.mark.parametrize("clip", ["hook", "torch"])
+def test_automatic_optimization_reproduces_the_native_steps(clip):
+    ref_model, ref_losses = native_steps(5)
+    model, batch = _model()
+    opt, sched, losses, lrs = automatic_optimization(model, batch, 5, clip)
+    for a, b in zip(losses, ref_losses):
+        assert abs(a - b) <= 1e-6 * max(1.0, abs(b)), (losses, ref_losses)
+    w, w_ref = model.store.flat, ref_model.store.flat
+    # torch's clip multiplies the gradient in place (one more rounding per element than the fused coefficient)
+    tol = 1e-6 if clip == "hook" else 2e-6
+    assert float((w - w_ref).abs().max()) <= tol * float(w_ref.abs().max()), float((w - w_ref).abs().max())
+    # the scheduler object mirrors the device-resident schedule (what LearningRateMonitor and the checkpoint see)
+    o = model.config.training.optimizer
+    assert lrs == pytest.approx([o.learning_rate * O.noam_scale(k, o.warmup_steps) for k in range(5)])
+    assert sched.last_epoch == 5 and opt.record()["step"] == 5
+    assert abs(opt.record()["lr"] - o.learning_rate * O.noam_scale(4, o.warmup_steps)) < 1e-9
+    # param.grad is the flat gradient buffer itself: nothing was copied
+    p = model.flat_param
+    assert p.grad is not None and p.grad.data_ptr() == model.store.grad.data_ptr()
+
+
+def test_gradient_accumulation_and_loss_scaling():
+    """``accumulate_grad_batches=2``: Lightning divides the loss (upstream gradient 1/2) and calls ``zero_grad`` every
+    second batch only.  The same batch twice must give the single-batch gradient, i.e. the same five steps."""
+    ref_model, ref_losses = native_steps(3)
+    model, batch = _model()
+    _, _, losses, _ = automatic_optimization(model, batch, 3, "hook", accumulate=2)
+    assert losses == pytest.approx(ref_losses, rel=1e-5)
+    w, w_ref = model.store.flat, ref_model.store.flat
+    assert float((w - w_ref).abs().max()) <= 1e-5 * float(w_ref.abs().max())
+
+
+def test_optimizer_and_scheduler_state_dicts_are_torch_adamw_and_noamlr():
+    model, batch = _model()
+    opt, sched, _, _ = automatic_optimization(model, batch, 2)
+    sd = opt.state_dict()
+    names = model.reference_parameter_names()
+    assert set(sd) == {"state", "param_groups"} and sd["param_groups"][0]["params"] == list(range(len(names)))
+    name = "mel_linear.weight"
+    st = sd["state"][names.index(name)]
+    assert float(st["step"]) == 2.0 and st["exp_avg"].shape == model.state_dict()[name].shape
+    ssd = sched.state_dict()
+    assert ssd["last_epoch"] == 2 and ssd["warmup_steps"] == 3 and ssd["base_lrs"] == [1e-2]
+    # a fresh model resumes from them through the same two objects (what Lightning's checkpoint connector does)
+    other, _ = _model(seed=4)
+    other.load_state_dict(model.state_dict())
+    o_opts, o_scheds = other.configure_optimizers()
+    o_opts[0].load_state_dict(sd)
+    o_scheds[0]["scheduler"].load_state_dict(ssd)
+    assert o_opts[0].record()["step"] == 2 and o_scheds[0]["scheduler"].last_epoch == 2
+    assert torch.equal(other.store.adam_m, model.store.adam_m) and torch.equal(other.store.adam_v, model.store.adam_v)
+
+
+def test_cost_of_the_autograd_hand_over():
+    """<= 2 % per step over the native loop (same model, same batch, interleaved rounds, medians)."""
+    from fastspeech2_lightning_amd.synthetic import DEFAULT_STATS, default_symbols, synthetic_batch
+    from fastspeech2_lightning_amd.config import FastSpeech2Config
+    from fastspeech2_lightning_amd.model import FastSpeech2
+    config = FastSpeech2Config(model=dict(learn_alignment=False), text=default_symbols(64))
+    model = FastSpeech2(config, Stats(**DEFAULT_STATS), seed=1)
+    model.train()
+    batch = model.prepare_batch(synthetic_batch(B=16, ts_lo=96, ts_hi=128, n_symbols=64, n_mels=80, seed=1234, dur_hi=9))
+    opts, scheds = model.configure_optimizers()
+    opt, sched = opts[0], scheds[0]["scheduler"]
+    model.configure_gradient_clipping(opt, 1.0, "norm")
+
+    def native():
+        with torch.no_grad():
+            model.training_step(batch)
+        opt.step()
+
+    def automatic():
+        def closure():
+            opt.zero_grad()
+            loss = model.training_step(batch)
+            loss.backward()
+            model.configure_gradient_clipping(opt, 1.0, "norm")
+            return loss
+        opt.step(closure)
+        sched.step()
+
+    def timed(fn, n=10):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    for _ in range(3):
+        native(); automatic()
+    a, b = [], []
+    for _ in range(5):
+        a.append(timed(native)); b.append(timed(automatic))
+    a, b = sorted(a)[2], sorted(b)[2]
+    print(f"\nnative {a * 1e3:.3f} ms/step, automatic optimization {b * 1e3:.3f} ms/step (+{(b / a - 1) * 100:.2f} %)")
+    assert b <= 1.02 * a + 1e-4, (a, b)

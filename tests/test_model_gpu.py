@@ -286,6 +286,7 @@ def test_five_optimizer_steps_track_the_oracle(learn_alignment):
     ref_opt = torch.optim.AdamW(oracle.parameters(), o.learning_rate, betas=tuple(o.betas), eps=o.eps,
                                 weight_decay=o.weight_decay)
     opt = model.configure_optimizers()[0][0]
+    model.configure_gradient_clipping(opt, 1.0, "norm")  # Trainer(gradient_clip_val=1.0), fs2/cli/train.py:38
     first = last = None
     for k in range(1, 6):
         for grp in ref_opt.param_groups:
@@ -351,6 +352,7 @@ def test_five_optimizer_steps_in_bf16_mixed_stay_close_to_fp32():
     ref_opt = torch.optim.AdamW(oracle.parameters(), o.learning_rate, betas=tuple(o.betas), eps=o.eps,
                                 weight_decay=o.weight_decay)
     opt = model.configure_optimizers()[0][0]
+    model.configure_gradient_clipping(opt, 1.0, "norm")  # Trainer(gradient_clip_val=1.0), fs2/cli/train.py:38
     totals = []
     for k in range(1, 6):
         for grp in ref_opt.param_groups:

@@ -17,6 +17,7 @@ torch.cuda.set_device(0)
 model = FastSpeech2(bench.make_config(), Stats(**DEFAULT_STATS), device="cuda:0", seed=1234, precision=prec)
 model.train()
 opt = model.configure_optimizers()[0][0]
+model.configure_gradient_clipping(opt, 1.0, "norm")  # Trainer(gradient_clip_val=1.0), fs2/cli/train.py:38
 batch = model.prepare_batch(synthetic_batch(B=32, ts_lo=96, ts_hi=128, n_symbols=64, n_mels=80, seed=1234, dur_hi=9))
 marks = {}
 for i in range(steps):

@@ -15,6 +15,7 @@ model = FastSpeech2(config, Stats(**DEFAULT_STATS), device="cuda:0", seed=1234)
 model.train()
 model.env.side_enabled = side
 opt = model.configure_optimizers()[0][0]
+model.configure_gradient_clipping(opt, 1.0, "norm")  # Trainer(gradient_clip_val=1.0), fs2/cli/train.py:38
 batch = model.prepare_batch(synthetic_batch(B=32, ts_lo=96, ts_hi=128, n_symbols=64, n_mels=80, seed=1234, dur_hi=9))
 
 

@@ -3,7 +3,7 @@
 Usage (on the GPU box, separate passes as MI355X_MICROARCH.md prescribes):
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d OUT/fetch -- python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-graph --no-roofline
   rocprofv3 --pmc WRITE_SIZE ... -d OUT/write -- (same)
-  python tools/pmc_traffic.py OUT/fetch OUT/write N_GEMM_PER_STEP
+  python tools/pmc_traffic.py OUT/fetch OUT/write N_GEMM_PER_STEP [the bench.py flags of the profiled command]
 
 Only the LAST step's GEMM dispatches are used (earlier ones include the tile autotuner's timing launches).
 gfx950 corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 64 B per 128-B request for wide coalesced
@@ -30,9 +30,12 @@ def main():
     fetch_dir, write_dir, n = sys.argv[1], sys.argv[2], int(sys.argv[3])
     fetch_kib, nf = last_step(fetch_dir, "FETCH_SIZE", n)
     write_kib, nw = last_step(write_dir, "WRITE_SIZE", n)
-    from bench import kernel_source_hash  # the figure is only valid for the kernel sources it was measured on
+    # the figure is only valid for the kernel sources AND the configuration it was measured on: both are stamped,
+    # and bench.py reports it only for a run whose stamp matches
+    from bench import build_parser, config_signature, kernel_source_hash
     out = {
         "kernel_source_hash": kernel_source_hash(),
+        "config": config_signature(build_parser().parse_args(sys.argv[4:])),
         "launches": nf,
         "fetch_bytes_per_launch_raw": fetch_kib * 1024 / nf,
         "fetch_bytes_per_launch_corrected": 2 * fetch_kib * 1024 / nf,

@@ -8,19 +8,19 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out
 python3 bench.py "$@" > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err || exit 1
 echo "bench done: $(python3 -c "import json;d=json.load(open('$O/${TAG}_bench.json'));print(d['ms_per_step'], d['value'], d['roofline']['frac'], (d.get('split_fp32') or {}).get('ms_per_step'))")"
-COMMON="--steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-split-line"
+COMMON="--steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-extra-legs"
 rm -rf $O/${TAG}_kt
 FS2_SIDE_STREAM=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_kt -- python3 bench.py $COMMON "$@" > $O/${TAG}_kt.log 2>&1 || exit 1
 cp $O/${TAG}_kt/*/*_kernel_stats.csv $O/${TAG}_one_stream_kernel_stats.csv
 python3 tools/step_breakdown.py $O/${TAG}_kt/*/*_kernel_trace.csv 5 > $O/${TAG}_one_stream_step_breakdown.txt
 head -12 $O/${TAG}_one_stream_step_breakdown.txt
 NGEMM=$(python3 -c "import json;print(json.load(open('$O/${TAG}_bench.json'))['roofline']['launches_per_step'])")
-PM="--steps 2 --warmup 2 --no-cpu-baseline --no-roofline --no-split-line"
+PM="--steps 2 --warmup 2 --no-cpu-baseline --no-roofline --no-extra-legs"
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $O/${TAG}_pmc_$c
   FS2_SIDE_STREAM=0 timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/${TAG}_pmc_$c -- python3 bench.py $PM "$@" > $O/${TAG}_pmc_$c.log 2>&1 || exit 1
 done
-python3 tools/pmc_traffic.py $O/${TAG}_pmc_FETCH_SIZE $O/${TAG}_pmc_WRITE_SIZE $NGEMM > $O/${TAG}_gemm_traffic.json
+python3 tools/pmc_traffic.py $O/${TAG}_pmc_FETCH_SIZE $O/${TAG}_pmc_WRITE_SIZE $NGEMM "$@" > $O/${TAG}_gemm_traffic.json
 cat $O/${TAG}_gemm_traffic.json
 for c in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
   rm -rf $O/${TAG}_pmc_$c
