@@ -78,10 +78,26 @@ def test_automatic_optimization_reproduces_the_native_steps(clip):
     opt, sched, losses, lrs = automatic_optimization(model, batch, 5, clip)
     for a, b in zip(losses, ref_losses):
         assert abs(a - b) <= 1e-6 * max(1.0, abs(b)), (losses, ref_losses)
-    w, w_ref = model.store.flat, ref_model.store.flat
-    # torch's clip multiplies the gradient in place (one more rounding per element than the fused coefficient)
-    tol = 1e-6 if clip == "hook" else 2e-6
-    assert float((w - w_ref).abs().max()) <= tol * float(w_ref.abs().max()), float((w - w_ref).abs().max())
+    if clip == "hook":
+        w, w_ref = model.store.flat, ref_model.store.flat
+        assert float((w - w_ref).abs().max()) <= 1e-6 * float(w_ref.abs().max()), float((w - w_ref).abs().max())
+    else:
+        # torch's clip_grad_norm_ rounds its coefficient differently (last bit), so weights differ by ~1e-7 after a
+        # step -- and a parameter whose TRUE gradient is zero (a bias in front of a BatchNorm: depthwise-conv and
+        # PostNet conv biases) has only rounding noise for a gradient, which Adam normalises to steps of +-lr whose
+        # sign is chaotic.  Those tensors are held to "moved by at most the five learning rates"; everything else to 2e-6.
+        sd, sd_ref, g = model.state_dict(), ref_model.state_dict(), ref_model.store.grad_state_dict()
+        gmax = max(float(v.abs().max()) for v in g.values())
+        lr_sum = sum(lrs)
+        checked = 0
+        for k, v in g.items():
+            d = float((sd[k] - sd_ref[k]).abs().max())
+            if float(v.abs().max()) < 1e-5 * gmax:
+                assert d <= 2.0 * lr_sum, (k, d)
+            else:
+                assert d <= 2e-6 * max(1.0, float(sd_ref[k].abs().max())), (k, d)
+                checked += 1
+        assert checked > 100
     # the scheduler object mirrors the device-resident schedule (what LearningRateMonitor and the checkpoint see)
     o = model.config.training.optimizer
     assert lrs == pytest.approx([o.learning_rate * O.noam_scale(k, o.warmup_steps) for k in range(5)])
