@@ -188,6 +188,7 @@ extern "C" int fs2hip_version(void) { return 1; }
 
 extern "C" int fs2hip_gemm(const Fs2GemmArgs* args, void* stream) {
   GemmP p;
+  p.staged = 0;
   p.a = *args;
   Fs2GemmArgs& a = p.a;
   if (a.Mc <= 0 || a.Nc <= 0 || a.R <= 0) return FS2HIP_EINVAL;
@@ -227,6 +228,12 @@ extern "C" int fs2hip_gemm(const Fs2GemmArgs* args, void* stream) {
         return FS2HIP_EINVAL;
     }
     a.counters = nullptr;
+    {
+      const int per16 = (a.io_bf16 & 1) ? 8 : 4;  // elements per 16 bytes of the results
+      p.staged = a.splitk > 1 ? (a.Nc % 4 == 0)
+                              : ((a.ldc % per16) == 0 && (a.c_tap_stride % per16) == 0 &&
+                                 (!a.out_pre || (a.ldpre % per16) == 0));
+    }
     p.drop = fs2_make_drop(a.drop_p, a.drop_seed, a.drop_step);
     const int nzb = (a.shift_operand == 1 ? a.taps : 1) * a.splitk;
     int tb = a.tile;

@@ -8,6 +8,7 @@ struct GemmP {
   int tiles_m;     // number of tiles along Mc
   int tiles_n;     // number of tiles along Nc
   int r_chunk;     // split-K chunk (multiple of the core's BK)
+  int staged;      // bf16-storage core: every output row starts 16-byte aligned (whole-row stores through LDS)
   Fs2Drop drop;
 };
 
@@ -234,7 +235,8 @@ int fs2_gemm2_launch(GemmP& p, int tile, int nz, hipStream_t s);
 // persistent v2 core (gemm2p.hip); tile: 10 = 64x64, 11 = 128x64, 12 = 128x128 (all 2-stage); 13 / 14 = 128x128 /
 // 128x64 with the last partial round of tiles cut along the reduction
 int fs2_gemm2p_launch(GemmP& p, int tile, int nz, hipStream_t s);
-// bf16-storage core (gemm_bf16.hip); tile: 20 = 128x128 (2 stages), 21 = 128x128 (3), 22 = 128x64 (2), 23 = 64x64 (3)
+// bf16-storage core (gemm_bf16.hip / gemm_bf16p.hip); tile: 20 = 128x128, 22 = 128x64, 23 = 64x64, 24 / 25 = persistent
+// 128x128 / 128x64
 int fs2_gemmb_launch(GemmP& p, int tile, int nz, hipStream_t s);
 // finishes the reduction-split tail tiles of a persistent launch (reduce.hip)
 int fs2_tail_fixup(const float* ws, int S, long long slab, float* C, int ldc, const float* bias, float alpha, int m0,

@@ -109,7 +109,7 @@ typedef struct {
                        shapes those cores refuse run in fp32.  3: bf16 operand STORAGE -- A and B point to bf16
                        (k-contiguous rows: a_kcontig = b_kcontig = 1; lda, ldb, R, b_tap_stride in bf16 elements, all
                        multiples of 8, tap widths multiples of 64; no split-K), C, bias and the epilogue tensors stay
-                       fp32; tiles 4..9.  4: the bf16-storage core (gemm_bf16.hip; tiles 20..23) -- A and B point to bf16 in
+                       fp32; tiles 4..9.  4: the bf16-storage core (gemm_bf16.hip, gemm_bf16p.hip; tiles 20, 22..25) -- A and B point to bf16 in
                        ANY of the three orientations (forward a_kcontig = b_kcontig = 1; data gradient a_kcontig = 1 with
                        the weight as stored, b_kcontig = 0; weight gradient both 0, split-K allowed), lda / ldb / R /
                        b_tap_stride / c_tap_stride in elements; R, lda, ldb multiples of 8, the row count of a
