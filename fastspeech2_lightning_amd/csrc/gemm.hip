@@ -273,6 +273,7 @@ extern "C" int fs2hip_gemm(const Fs2GemmArgs* args, void* stream) {
     }
   }
   if (a.splitk > 1 && (a.a_kcontig || a.b_kcontig || !a.workspace)) return FS2HIP_EINVAL;
+  if (a.colsum && (a.a_kcontig || a.b_kcontig)) return FS2HIP_EINVAL;  // the bias gradient belongs to a weight gradient
   if (a.splitk <= 1) a.counters = nullptr;
   // (one arrival counter per output tile and tap; the smallest tile is 64 x 64)
   if (a.counters && (long long)a.taps * ((a.Mc + 63) / 64) * ((a.Nc + 63) / 64) > FS2_SPLITK_COUNTERS) return FS2HIP_EINVAL;
@@ -301,14 +302,14 @@ extern "C" int fs2hip_gemm(const Fs2GemmArgs* args, void* stream) {
                         ((long long)((a.Mc + 127) / 128) * ((a.Nc + 127) / 128) * nz < 384);
     // conv taps that core v2 cannot keep uniform per K-tile run on its generic-decode kernel (tile 7 only)
     const bool odd_taps = a.taps > 1 && (a.shift_operand == 0 ? (p.Rper % 32) != 0 : a.T < 32);
-    tile = v2_ok ? (odd_taps ? (v1_ok && !a.operand_bf16 ? 3 : 7) : (narrow ? 5 : 4)) : (narrow ? 2 : 1);  // (core v1 is fp32 only)
+    tile = v2_ok ? (odd_taps ? (v1_ok && !a.operand_bf16 && !a.colsum ? 3 : 7) : (narrow ? 5 : 4)) : (narrow ? 2 : 1);  // (core v1 is fp32 only)
   }
   if (a.operand_bf16 == 3 && (tile < 4 || tile > 9)) return FS2HIP_EINVAL;  // the one-tile-per-workgroup direct-to-LDS core only
   if (tile >= 4) {
     if (!v2_ok) return FS2HIP_EINVAL;
     return tile >= 10 ? fs2_gemm2p_launch(p, tile, nz, s) : fs2_gemm2_launch(p, tile, nz, s);
   }
-  if (!v1_ok) return FS2HIP_EINVAL;
+  if (!v1_ok || a.colsum) return FS2HIP_EINVAL;  // (the register-staged core does not sum columns)
   if (tile == 3) {
     p.tiles_n = (a.Nc + 63) / 64;
     dim3 grid(((a.Mc + 63) / 64) * p.tiles_n, 1, nz);

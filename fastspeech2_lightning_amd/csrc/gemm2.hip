@@ -90,6 +90,12 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmP p) {
   rda.setup(wm * (BM / 2), l31, h);
   rdb.setup(wn * (BN / 2), l31, h);
 
+  // bias gradient beside a weight gradient (Fs2GemmArgs.colsum): wavefronts of the first tile column, first tap slice
+  float cs[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) cs[i] = 0.f;
+  const bool do_cs = !AKC && !BKC && a.colsum != nullptr && tile_n == 0 && tapz == 0 && wn == 0;
+
   for (int kt = 0; kt < NST - 1 && kt < nkt; ++kt) issue(kt, kt);
   int stage = 0;
   for (int kt = 0; kt < nkt; ++kt) {
@@ -100,10 +106,11 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmP p) {
     else wait_vmcnt_barrier<0>();
     if (kt + NST - 1 < nkt) issue(kt + NST - 1, stage == 0 ? NST - 1 : stage - 1);  // the stage read in iteration kt-1
     const unsigned sa = lds0 + stage * (STAGE * 4), sb = sa + A_TILE * 4;
-    compute_ktile_any<BF, BM, BN, AKC, BKC>(acc, rda, rdb, sa, sb);
+    compute_ktile_any<BF, BM, BN, AKC, BKC>(acc, rda, rdb, sa, sb, cs, do_cs);
     stage = stage + 1 == NST ? 0 : stage + 1;
   }
   gemm_epilogue<BM, BN>(p, acc, m0, n0, wm, wn, lane, split, tapz);
+  if (do_cs) colsum_store<BM>(a, cs, m0, wm, lane, split);
 }
 
 // fp32 or bf16-operand instance of one kernel shape

@@ -329,11 +329,21 @@ __device__ __forceinline__ void frag_read(Frag<T, KC>& f, const RdAddr<ROWS, KC>
 }
 
 
+// Column sums of a reduction-major A operand (the bias gradient dY^T . 1 of the layer whose weight gradient the launch
+// computes, Fs2GemmArgs.colsum): the lane already holds four reduction steps of its row per group -- four adds per row
+// block and group beside sixteen MFMAs, in the wavefronts of the first tile column only.
+template <int TM, bool KC>
+__device__ __forceinline__ void colsum_group(float (&cs)[TM], const Frag<TM, KC>& f) {
+#pragma unroll
+  for (int i = 0; i < TM; ++i) cs[i] += (f.get(i, 0) + f.get(i, 1)) + (f.get(i, 2) + f.get(i, 3));
+}
+
 // MFMAs of one K-tile (BK2 = 32 deep) from the LDS stage at byte addresses sa (A image) / sb (B image).
 // LDS reads run one reduction group (8 deep) ahead of the MFMAs that consume them (two register sets).
 template <int BM, int BN, bool AKC, bool BKC>
 __device__ __forceinline__ void compute_ktile(f32x16 (&acc)[BM / 64][BN / 64], const RdAddr<BM, AKC>& rda,
-                                              const RdAddr<BN, BKC>& rdb, unsigned sa, unsigned sb) {
+                                              const RdAddr<BN, BKC>& rdb, unsigned sa, unsigned sb,
+                                              float (&cs)[BM / 64], bool do_cs) {
   constexpr int TM = BM / 64, TN = BN / 64;
     Frag<TM, AKC> fa[2];
     Frag<TN, BKC> fb[2];
@@ -351,6 +361,7 @@ __device__ __forceinline__ void compute_ktile(f32x16 (&acc)[BM / 64][BN / 64], c
     }                                                                                                      \
     fa[G & 1].pin_all();                                                                                   \
     fb[G & 1].pin_all();                                                                                   \
+    if (!AKC && do_cs) colsum_group<TM, AKC>(cs, fa[G & 1]);                                               \
     _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                          \
     _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                         \
     _Pragma("unroll") for (int jn = 0; jn < TN; ++jn)                                                      \
@@ -379,7 +390,8 @@ __device__ __forceinline__ bf16x8 frag_bf16(const Frag<T, KC>& lo, const Frag<T,
 
 template <int BM, int BN, bool AKC, bool BKC>
 __device__ __forceinline__ void compute_ktile_bf16(f32x16 (&acc)[BM / 64][BN / 64], const RdAddr<BM, AKC>& rda,
-                                                   const RdAddr<BN, BKC>& rdb, unsigned sa, unsigned sb) {
+                                                   const RdAddr<BN, BKC>& rdb, unsigned sa, unsigned sb,
+                                                   float (&cs)[BM / 64], bool do_cs) {
   constexpr int TM = BM / 64, TN = BN / 64;
   Frag<TM, AKC> fa[4];
   Frag<TN, BKC> fb[4];
@@ -399,6 +411,10 @@ __device__ __forceinline__ void compute_ktile_bf16(f32x16 (&acc)[BM / 64][BN / 6
     fa[2 * P + 1].pin_all();                                                                                 \
     fb[2 * P].pin_all();                                                                                     \
     fb[2 * P + 1].pin_all();                                                                                 \
+    if (!AKC && do_cs) {                                                                                     \
+      colsum_group<TM, AKC>(cs, fa[2 * P]);                                                                  \
+      colsum_group<TM, AKC>(cs, fa[2 * P + 1]);                                                              \
+    }                                                                                                        \
     bf16x8 ua[TM], ub[TN];                                                                                   \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) ua[i] = frag_bf16(fa[2 * P], fa[2 * P + 1], i);           \
     _Pragma("unroll") for (int jn = 0; jn < TN; ++jn) ub[jn] = frag_bf16(fb[2 * P], fb[2 * P + 1], jn);      \
@@ -452,7 +468,8 @@ __device__ __forceinline__ Planes frag_split3(const Frag<T, KC>& lo, const Frag<
 
 template <int BM, int BN, bool AKC, bool BKC>
 __device__ __forceinline__ void compute_ktile_split(f32x16 (&acc)[BM / 64][BN / 64], const RdAddr<BM, AKC>& rda,
-                                                    const RdAddr<BN, BKC>& rdb, unsigned sa, unsigned sb) {
+                                                    const RdAddr<BN, BKC>& rdb, unsigned sa, unsigned sb,
+                                                    float (&cs)[BM / 64], bool do_cs) {
   constexpr int TM = BM / 64, TN = BN / 64;
   Frag<TM, AKC> fa[4];
   Frag<TN, BKC> fb[4];
@@ -470,6 +487,7 @@ __device__ __forceinline__ void compute_ktile_split(f32x16 (&acc)[BM / 64][BN / 
   for (int g = 0; g < 4; ++g) {
     fa[g].pin_all();
     fb[g].pin_all();
+    if (!AKC && do_cs) colsum_group<TM, AKC>(cs, fa[g]);
   }
   // The cut of the second half of the K-tile is issued between the MFMAs of the first half (the bf16 matrix pipe
   // and the vector ALUs run side by side, but a wavefront issues in order: a block of 170 vector instructions in
@@ -548,13 +566,26 @@ __device__ __forceinline__ void compute_ktile_bf16s(f32x16 (&acc)[BM / 64][BN / 
 // BF: 0 = fp32 MFMA, 1 = operands rounded to bf16 ("bf16-mixed"), 2 = three-plane split ("32-split"), 3 = bf16 in memory
 template <int BF, int BM, int BN, bool AKC, bool BKC>
 __device__ __forceinline__ void compute_ktile_any(f32x16 (&acc)[BM / 64][BN / 64], const RdAddr<BM, AKC>& rda,
-                                                  const RdAddr<BN, BKC>& rdb, unsigned sa, unsigned sb) {
+                                                  const RdAddr<BN, BKC>& rdb, unsigned sa, unsigned sb,
+                                                  float (&cs)[BM / 64], bool do_cs) {
   if constexpr (BF == 3) {
     static_assert(AKC && BKC, "bf16 storage: k-contiguous operands only");
     compute_ktile_bf16s<BM, BN>(acc, rda, rdb, sa, sb);
-  } else if constexpr (BF == 2) compute_ktile_split<BM, BN, AKC, BKC>(acc, rda, rdb, sa, sb);
-  else if constexpr (BF == 1) compute_ktile_bf16<BM, BN, AKC, BKC>(acc, rda, rdb, sa, sb);
-  else compute_ktile<BM, BN, AKC, BKC>(acc, rda, rdb, sa, sb);
+  } else if constexpr (BF == 2) compute_ktile_split<BM, BN, AKC, BKC>(acc, rda, rdb, sa, sb, cs, do_cs);
+  else if constexpr (BF == 1) compute_ktile_bf16<BM, BN, AKC, BKC>(acc, rda, rdb, sa, sb, cs, do_cs);
+  else compute_ktile<BM, BN, AKC, BKC>(acc, rda, rdb, sa, sb, cs, do_cs);
+}
+
+// after the epilogue of a unit: the two halves of a wavefront hold the sums over different reduction steps of the same
+// rows; lanes 0..31 of the wavefronts of the first tile column write colsum[split][Mc]
+template <int BM>
+__device__ __forceinline__ void colsum_store(const Fs2GemmArgs& a, float (&cs)[BM / 64], int m0, int wm, int lane, int split) {
+#pragma unroll
+  for (int i = 0; i < BM / 64; ++i) {
+    const float t = cs[i] + __shfl_xor(cs[i], 32, 64);
+    const int m = m0 + wm * (BM / 2) + 32 * i + lane;
+    if (lane < 32 && m < a.Mc) a.colsum[(long long)split * a.Mc + m] = t;
+  }
 }
 
 }  // namespace

@@ -17,7 +17,7 @@
 namespace {
 
 struct Unit {
-  int m0, n0, tapz, split, r_begin, r_end, nkt, shift_z;
+  int m0, n0, tapz, split, r_begin, r_end, nkt, shift_z, tile_n;
   int slice;  // >= 0: a reduction slice of a tail tile (raw partial sums into the workspace slab `slice`)
 };
 
@@ -63,6 +63,7 @@ __device__ __forceinline__ Unit decode_unit(const GemmP& p, const Hybrid& hy, in
   const int tile_m = t / p.tiles_n, tile_n = t - tile_m * p.tiles_n;
   q.m0 = tile_m * BM;
   q.n0 = tile_n * BN;
+  q.tile_n = tile_n;
   q.nkt = q.r_end > q.r_begin ? (q.r_end - q.r_begin + BK2 - 1) / BK2 : 0;
   q.shift_z = q.tapz * a.tap_mul + a.tap_add;
   return q;
@@ -133,12 +134,16 @@ __global__ __launch_bounds__(256) void gemm2p_kernel(GemmP p, Hybrid hy, int nun
   for (int u_c = blockIdx.x; u_c < nunits; u_c += G) {
     const Unit uc = decode_unit(p, hy, u_c, nunits, tiles, BM, BN);
     clear();
-    compute_ktile_any<BF, BM, BN, AKC, BKC>(acc, rda, rdb, lds0 + stage * (STAGE * 4), lds0 + stage * (STAGE * 4) + A_TILE * 4);
+    float cs[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) cs[i] = 0.f;
+    const bool do_cs = !AKC && !BKC && a.colsum != nullptr && uc.tile_n == 0 && uc.tapz == 0 && wn == 0;
+    compute_ktile_any<BF, BM, BN, AKC, BKC>(acc, rda, rdb, lds0 + stage * (STAGE * 4), lds0 + stage * (STAGE * 4) + A_TILE * 4, cs, do_cs);
     stage ^= 1;
     for (int kt = 1; kt < uc.nkt; ++kt) {
       wait_vmcnt_barrier<0>();  // this K-tile has landed for everybody; the other stage is no longer read
       produce(stage ^ 1);
-      compute_ktile_any<BF, BM, BN, AKC, BKC>(acc, rda, rdb, lds0 + stage * (STAGE * 4), lds0 + stage * (STAGE * 4) + A_TILE * 4);
+      compute_ktile_any<BF, BM, BN, AKC, BKC>(acc, rda, rdb, lds0 + stage * (STAGE * 4), lds0 + stage * (STAGE * 4) + A_TILE * 4, cs, do_cs);
       stage ^= 1;
     }
     if (u_c + G < nunits) {  // first K-tile of the next unit: its sync and the following DMA go ahead of the
@@ -150,6 +155,7 @@ __global__ __launch_bounds__(256) void gemm2p_kernel(GemmP p, Hybrid hy, int nun
                                      wm, wn, lane);
     else
       gemm_epilogue<BM, BN>(p, acc, uc.m0, uc.n0, wm, wn, lane, uc.split, uc.tapz);
+    if (do_cs) colsum_store<BM>(a, cs, uc.m0, wm, lane, uc.split);
   }
 }
 
@@ -220,7 +226,7 @@ int launch_persistent(GemmP& p, int nz, hipStream_t s) {
     // only where a separate pass can finish the tiles: one reduction range, rows of every tensor the epilogue touches
     // addressable as float4
     auto vec_ok = [](const float* ptr, int ld) { return ((uintptr_t)ptr % 16) == 0 && (ld % 4) == 0; };
-    if (nz != 1 || a.splitk != 1 || (a.Nc % 4) || !a.workspace || !vec_ok(a.C, a.ldc) ||
+    if (nz != 1 || a.splitk != 1 || a.colsum || (a.Nc % 4) || !a.workspace || !vec_ok(a.C, a.ldc) ||
         (a.bias && ((uintptr_t)a.bias % 16)) || (a.out_pre && (a.epi != FS2_EPI_ACT || !vec_ok(a.out_pre, a.ldpre))) ||
         (a.epi == FS2_EPI_RESID && !vec_ok(a.resid, a.ldr)) || (a.epi == FS2_EPI_DACT && !vec_ok(a.aux, a.ldaux)) ||
         a.epi < FS2_EPI_STORE || a.epi > FS2_EPI_DACT)

@@ -606,9 +606,9 @@ def linear_bwd_weight(dy, x, out, *, taps=1, T=0, n_valid=None, bias_grad=None):
     """dw[N, K] = dy[M, N]^T @ x[M, K]  (or dw[taps, N, Kper] for the k-tap conv).
     Written into ``out`` (a view of the flat gradient buffer).  ``n_valid``: only the first
     n_valid columns of dy produce output rows (dy's row length may be padded to a multiple of 4).
-    bf16 ``dy`` and ``x`` (operand storage): both are read as stored (reduction-major operands of the bf16 core), and
     ``bias_grad`` [N], when given, receives dy's column sums from the same launch (second stage at the next
-    ``flush_grad_reductions()``) -- the separate column-sum pass over dy disappears."""
+    ``flush_grad_reductions()``): the separate column-sum pass over dy disappears.
+    bf16 ``dy`` and ``x`` (operand storage): both are read as stored (reduction-major operands of the bf16 core)."""
     stored = dy.dtype == torch.bfloat16
     _chk(dy, dy.dtype if stored else torch.float32, name="dy"); _chk(x, dy.dtype if stored else torch.float32, name="x")
     _chk(out, name="out")
@@ -619,19 +619,18 @@ def linear_bwd_weight(dy, x, out, *, taps=1, T=0, n_valid=None, bias_grad=None):
     _req(taps == 1 or (T > 0 and M % T == 0), "linear_bwd_weight: rows must be a multiple of T")
     _req(not stored or (lda % 8 == 0 and K % 8 == 0 and N % 8 == 0 and (taps == 1 or T >= 64)),
          "linear_bwd_weight: bf16 operands need row lengths that are multiples of 8 (convolutions: T >= 64)")
-    _req(bias_grad is None or stored, "linear_bwd_weight: the fused bias gradient is part of the bf16 core")
     S = pick_splitk(N, K, M, taps)
     kw = dict(A=_p(dy), B=_p(x), C=_p(out), Mc=N, Nc=K, R=M, lda=lda, ldb=K, ldc=K, a_kcontig=0, b_kcontig=0,
               taps=taps, T=T if taps > 1 else 0, tap_mul=1, tap_add=-((taps - 1) // 2),
               shift_operand=1 if taps > 1 else 0, c_tap_stride=N * K, splitk=S)
     if stored:
         kw.update(operand_bf16=4)
-        if bias_grad is not None:
-            _chk(bias_grad, name="bias_grad")
-            _req(bias_grad.numel() == N, "linear_bwd_weight: bias gradient size")
-            part = torch.empty(S * N, device=dy.device, dtype=torch.float32)
-            kw["colsum"] = _p(part)
-            _defer_reduction(part, S, N, N, bias_grad, N, None)
+    if bias_grad is not None:
+        _chk(bias_grad, name="bias_grad")
+        _req(bias_grad.numel() == N and n_valid is None, "linear_bwd_weight: bias gradient size")
+        part = torch.empty(S * N, device=dy.device, dtype=torch.float32)
+        kw["colsum"] = _p(part)
+        _defer_reduction(part, S, N, N, bias_grad, N, None)
     if S > 1:
         n = taps * N * K
         ws = _workspace(S * n, dy.device)

@@ -579,8 +579,7 @@ class FastSpeech2(_Base):
             d_post = g["postnet"]
             d_out = H.axpby(d_out, d_post)
             d_out = H.axpby(d_out, self.postnet.bwd(d_post, c["post"]))
-        H.linear_bwd_weight(d_out, c["dec_out"], S.g("mel_linear.weight"))
-        H.colsum_grad(d_out, S.g("mel_linear.bias"))
+        H.linear_bwd_weight(d_out, c["dec_out"], S.g("mel_linear.weight"), bias_grad=S.g("mel_linear.bias"))
         d = H.linear_bwd_data(d_out, S.p("mel_linear.weight"))
         self._bucket_done(self._bucket_head)                              # mel head + PostNet
         d = self.decoder.bwd(d, c["dec"], layer_done=self._bucket_done)   # one bucket per decoder layer but the first

@@ -228,13 +228,10 @@ class FeedForward:
         if not fused:
             dz = H.axpby(dy, None, 0.5, 0.0, env.drop(self.p, self.s2))
         with env.side(dz, c.a):
-            H.linear_bwd_weight(dz, c.a, S.g(self.w2))
-            if not fused:
-                H.colsum_grad(dz, S.g(self.b2))
+            H.linear_bwd_weight(dz, c.a, S.g(self.w2), bias_grad=None if fused else S.g(self.b2))
         du = H.linear_bwd_data(dz, S.p(self.w2), epi=H.EPI_DACT, act="silu", aux=c.u, drop=env.drop(self.p, self.s1))
         with env.side(du, c.h):
-            H.linear_bwd_weight(du, c.h, S.g(self.w1))
-            H.colsum_grad(du, S.g(self.b1))
+            H.linear_bwd_weight(du, c.h, S.g(self.w1), bias_grad=S.g(self.b1))
         dh = H.linear_bwd_data(du, S.p(self.w1))
         return self.ln.bwd(dh, c.ln, dx_add=dy, nxt=nxt)
 
@@ -299,14 +296,11 @@ class SelfAttention:
             d_o = env.drop(self.p, self.so)
             dz = H.axpby(dy, None, 1.0, 0.0, d_o) if d_o.p > 0 else dy
         with env.side(dz, c.o):
-            H.linear_bwd_weight(dz, c.o, S.g(self.wo))
-            if not fused:
-                H.colsum_grad(dz, S.g(self.bo))
+            H.linear_bwd_weight(dz, c.o, S.g(self.wo), bias_grad=None if fused else S.g(self.bo))
         do = H.linear_bwd_data(dz, S.p(self.wo))
         dqkv = H.attention_bwd(c.qkv, c.lens, c.o, do, c.lse, B, T, self.heads, env.drop(self.p, self.sa))
         with env.side(dqkv, c.h):
-            H.linear_bwd_weight(dqkv, c.h, S.g(self.wi))
-            H.colsum_grad(dqkv, S.g(self.bi))
+            H.linear_bwd_weight(dqkv, c.h, S.g(self.wi), bias_grad=S.g(self.bi))
         dh = H.linear_bwd_data(dqkv, S.p(self.wi))
         return self.ln.bwd(dh, c.ln, dx_add=dy, nxt=nxt)
 
@@ -381,15 +375,12 @@ class ConvModule:
             d_o = env.drop(self.p, self.site)
             dz = H.axpby(dy, None, 1.0, 0.0, d_o) if d_o.p > 0 else dy
         with env.side(dz, c.s):
-            H.linear_bwd_weight(dz, c.s, S.g(self.w2))
-            if not fused:
-                H.colsum_grad(dz, S.g(self.b2))
+            H.linear_bwd_weight(dz, c.s, S.g(self.w2), bias_grad=None if fused else S.g(self.b2))
         ds = H.linear_bwd_data(dz, S.p(self.w2))
         dc = H.bn_act_bwd(ds, c.c, c.stats, gg, gb, "silu", training=env.training)
         dg2 = H.dwconv_bwd(dc, c.g2, S.p(self.wd), S.g(self.wd), S.g(self.bd), B, T, glu=True)
         with env.side(dg2, c.h):
-            H.linear_bwd_weight(dg2, c.h, S.g(self.w1))
-            H.colsum_grad(dg2, S.g(self.b1))
+            H.linear_bwd_weight(dg2, c.h, S.g(self.w1), bias_grad=S.g(self.b1))
         dh = H.linear_bwd_data(dg2, S.p(self.w1))
         return self.ln.bwd(dh, c.ln, dx_add=dy, nxt=nxt)
 
@@ -513,13 +504,11 @@ class VariancePredictor:
             d = L["ln"].bwd(d, ln_saved)
             d = H.dact_mul(d, r, "relu")
             if self.depthwise:
-                H.linear_bwd_weight(d, c, S.g(L["wp"]))
-                H.colsum_grad(d, S.g(L["bp"]))
+                H.linear_bwd_weight(d, c, S.g(L["wp"]), bias_grad=S.g(L["bp"]))
                 dc = H.linear_bwd_data(d, S.p(L["wp"]))
                 d = H.dwconv_bwd(dc, x, S.p(L["wd"]), S.g(L["wd"]), S.g(L["bd"]), B, T)
             else:
-                H.linear_bwd_weight(d, x, S.g(L["wc"]), taps=self.k, T=T)
-                H.colsum_grad(d, S.g(L["bc"]))
+                H.linear_bwd_weight(d, x, S.g(L["wc"]), taps=self.k, T=T, bias_grad=S.g(L["bc"]))
                 d = H.linear_bwd_data(d, S.p(L["wc"]), taps=self.k, T=T)
         return d
 
@@ -580,19 +569,19 @@ class Aligner:
         g = lambda key: (S.g(self.names[key][0]), S.g(self.names[key][1]))  # noqa: E731
         # query branch (the mel input needs no gradient)
         gw, gb = g("q4")
-        H.linear_bwd_weight(dq, c.q2, gw); H.colsum_grad(dq, gb)
+        H.linear_bwd_weight(dq, c.q2, gw, bias_grad=gb)
         d = H.linear_bwd_data(dq, self._w("q4")[0], epi=H.EPI_DACT, act="relu", aux=c.q2)
         gw, gb = g("q2")
-        H.linear_bwd_weight(d, c.q1, gw); H.colsum_grad(d, gb)
+        H.linear_bwd_weight(d, c.q1, gw, bias_grad=gb)
         d = H.linear_bwd_data(d, self._w("q2")[0], epi=H.EPI_DACT, act="relu", aux=c.q1)
         gw, gb = g("q0")
-        H.linear_bwd_weight(d, c.mel, gw, taps=3, T=Tm); H.colsum_grad(d, gb)
+        H.linear_bwd_weight(d, c.mel, gw, taps=3, T=Tm, bias_grad=gb)
         # key branch
         gw, gb = g("k2")
-        H.linear_bwd_weight(dk, c.k1, gw); H.colsum_grad(dk, gb)
+        H.linear_bwd_weight(dk, c.k1, gw, bias_grad=gb)
         d = H.linear_bwd_data(dk, self._w("k2")[0], epi=H.EPI_DACT, act="relu", aux=c.k1)
         gw, gb = g("k0")
-        H.linear_bwd_weight(d, c.text_emb, gw, taps=3, T=Ts); H.colsum_grad(d, gb)
+        H.linear_bwd_weight(d, c.text_emb, gw, taps=3, T=Ts, bias_grad=gb)
         return H.linear_bwd_data(d, self._w("k0")[0], taps=3, T=Ts)
 
 
@@ -682,7 +671,7 @@ class StyleEncoder:
         B, Hh, Ww, C = c.shape
         g = lambda name: (S.g(self.lin[name][0]), S.g(self.lin[name][1]))  # noqa: E731
         gw, gb = g("out")
-        H.linear_bwd_weight(d_style, c.ctx, gw); H.colsum_grad(d_style, gb)
+        H.linear_bwd_weight(d_style, c.ctx, gw, bias_grad=gb)
         dctx = H.linear_bwd_data(d_style, self._lw("out")[0])
         dq, dkp, dvp = H.gst_attn_bwd(dctx, c.q, c.k, c.v, c.p, self.HEADS)
         NT, Fd = c.k.shape
@@ -691,14 +680,14 @@ class StyleEncoder:
         H.colsum(dkp.view(B, NT * Fd), dk.view(-1))
         H.colsum(dvp.view(B, NT * Fd), dv.view(-1))
         gw, gb = g("k")
-        H.linear_bwd_weight(dk, c.tk, gw); H.colsum_grad(dk, gb)
+        H.linear_bwd_weight(dk, c.tk, gw, bias_grad=gb)
         dtk = H.linear_bwd_data(dk, self._lw("k")[0])
         gw, gb = g("v")
-        H.linear_bwd_weight(dv, c.tk, gw); H.colsum_grad(dv, gb)
+        H.linear_bwd_weight(dv, c.tk, gw, bias_grad=gb)
         dtk = H.axpby(dtk, H.linear_bwd_data(dv, self._lw("v")[0]))
         H.axpby(H.dact_mul(dtk, S.p(self.embs), "tanh"), None, 1.0, 0.0, out=S.g(self.embs))
         gw, gb = g("q")
-        H.linear_bwd_weight(dq, c.hs[Hh], gw); H.colsum_grad(dq, gb)
+        H.linear_bwd_weight(dq, c.hs[Hh], gw, bias_grad=gb)
         dh = H.linear_bwd_data(dq, self._lw("q")[0])
         # GRU backward through time
         dgi = torch.empty(B * Hh, 3 * U, device=dh.device, dtype=torch.float32)
@@ -706,10 +695,8 @@ class StyleEncoder:
         for t in range(Hh - 1, -1, -1):
             _, dhprev = H.gru_gate_bwd(dh, c.gates[t], c.hs[t], dgi.view(-1)[t * 3 * U:], Hh * 3 * U, U, dgh=dgh_all[t])
             dh = H.axpby(dhprev, H.linear_bwd_data(dgh_all[t], S.p(self.whh)))
-        H.linear_bwd_weight(dgh_all.view(Hh * B, 3 * U), c.hs[:Hh].reshape(Hh * B, U), S.g(self.whh))
-        H.colsum_grad(dgh_all.view(Hh * B, 3 * U), S.g(self.bhh))
-        H.linear_bwd_weight(dgi, c.feat, S.g(self.wih))
-        H.colsum_grad(dgi, S.g(self.bih))
+        H.linear_bwd_weight(dgh_all.view(Hh * B, 3 * U), c.hs[:Hh].reshape(Hh * B, U), S.g(self.whh), bias_grad=S.g(self.bhh))
+        H.linear_bwd_weight(dgi, c.feat, S.g(self.wih), bias_grad=S.g(self.bih))
         d = H.linear_bwd_data(dgi, S.p(self.wih)).view(B, Hh, Ww, C)
         for i in range(len(self.convs) - 1, -1, -1):
             w, bn, ch = self.convs[i]
@@ -778,8 +765,7 @@ class PostNet:
             if not (nxt_b or x_b):
                 draw = H.bn_act_bwd(dy, raw, stats, gg, gb, act, drop, training=env.training)
                 with env.side(draw, x):
-                    H.linear_bwd_weight(draw, x, S.g(w), taps=self.k, T=T)
-                    H.colsum_grad(draw, S.g(b))
+                    H.linear_bwd_weight(draw, x, S.g(w), taps=self.k, T=T, bias_grad=S.g(b))
                 if need:
                     dy = H.linear_bwd_data(draw, S.p(w), taps=self.k, T=T)
                 continue

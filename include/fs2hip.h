@@ -118,9 +118,10 @@ typedef struct {
   int io_bf16;   /* operand_bf16 == 4 only.  bit 0: C and out_pre are bf16 (ldc / ldpre in elements; the activation of
                     FS2_EPI_ACT is applied to the ROUNDED pre-activation, i.e. to what the backward pass reads back);
                     bit 1: aux is bf16 */
-  float* colsum; /* operand_bf16 == 4, weight gradient (a_kcontig = b_kcontig = 0) only, or NULL: receives the column
-                    sums of A over the reduction -- the bias gradient dY^T . 1 of the layer whose weight gradient this
-                    launch computes -- as colsum[split][Mc] partial sums (splitk rows; the caller adds them) */
+  float* colsum; /* weight gradient (a_kcontig = b_kcontig = 0) only, or NULL: receives the column sums of A over the
+                    reduction -- the bias gradient dY^T . 1 of the layer whose weight gradient this launch computes -- as
+                    colsum[split][Mc] partial sums (splitk rows; the caller adds them).  Direct-to-LDS cores (tiles 4..12)
+                    and the bf16-storage core */
 } Fs2GemmArgs;
 #define FS2_SPLITK_COUNTERS 4096
 
