@@ -571,4 +571,27 @@ __device__ __forceinline__ void epilogue_dispatch_b(const GemmP& p, const f32x16
 #undef FS2_BEPI
 }
 
+// ---- work units of the persistent kernels (gemm_bf16p.hip, gemm_bf16q.hip): one output tile of one split-K / tap slice ----
+struct UnitB {
+  int m0, n0, tapz, split, r_begin, r_end, nkt, shift_z, tile_n;
+};
+__device__ __forceinline__ UnitB decode_unit_b(const GemmP& p, int u, int nunits, int tiles, int BM, int BN) {
+  const Fs2GemmArgs& a = p.a;
+  UnitB q;
+  const int uu = fs2_xcd_remap(u, nunits);
+  const int z = uu / tiles, t = uu - z * tiles;
+  const int ntap = a.shift_operand == 1 ? a.taps : 1;  // slice order (split, tap)
+  q.split = z / ntap;
+  q.tapz = z - q.split * ntap;
+  q.r_begin = q.split * p.r_chunk;
+  q.r_end = min(a.R, q.r_begin + p.r_chunk);
+  const int tile_m = t / p.tiles_n;
+  q.tile_n = t - tile_m * p.tiles_n;
+  q.m0 = tile_m * BM;
+  q.n0 = q.tile_n * BN;
+  q.nkt = q.r_end > q.r_begin ? (q.r_end - q.r_begin + BKE - 1) / BKE : 0;
+  q.shift_z = q.tapz * a.tap_mul + a.tap_add;
+  return q;
+}
+
 }  // namespace

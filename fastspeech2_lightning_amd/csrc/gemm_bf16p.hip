@@ -10,28 +10,6 @@ namespace {
 // next workgroup starts.  Here a launch fills every workgroup slot once and a workgroup walks the units u = blockIdx,
 // blockIdx + grid, ...; the K-tiles of all its units form ONE stream through the two LDS stages -- the first K-tiles of
 // the next unit are in flight under the last MFMAs and the whole epilogue of the current one (gemm2p.hip, same scheme).
-struct UnitB {
-  int m0, n0, tapz, split, r_begin, r_end, nkt, shift_z, tile_n;
-};
-__device__ __forceinline__ UnitB decode_unit_b(const GemmP& p, int u, int nunits, int tiles, int BM, int BN) {
-  const Fs2GemmArgs& a = p.a;
-  UnitB q;
-  const int uu = fs2_xcd_remap(u, nunits);
-  const int z = uu / tiles, t = uu - z * tiles;
-  const int ntap = a.shift_operand == 1 ? a.taps : 1;  // slice order (split, tap)
-  q.split = z / ntap;
-  q.tapz = z - q.split * ntap;
-  q.r_begin = q.split * p.r_chunk;
-  q.r_end = min(a.R, q.r_begin + p.r_chunk);
-  const int tile_m = t / p.tiles_n;
-  q.tile_n = t - tile_m * p.tiles_n;
-  q.m0 = tile_m * BM;
-  q.n0 = q.tile_n * BN;
-  q.nkt = q.r_end > q.r_begin ? (q.r_end - q.r_begin + BKE - 1) / BKE : 0;
-  q.shift_z = q.tapz * a.tap_mul + a.tap_add;
-  return q;
-}
-
 template <int BM, int BN, bool AKC, bool BKC, int TAPS, bool COLSUM>
 __global__ __launch_bounds__(256) void gemmbp_kernel(GemmP p, int nunits, int tiles) {
   constexpr int TM = BM / 64, TN = BN / 64;
