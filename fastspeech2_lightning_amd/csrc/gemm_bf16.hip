@@ -130,12 +130,12 @@ int launch_b(GemmP& p, int nz, hipStream_t s) {
 }  // namespace
 
 int fs2_gemmbp_launch(GemmP& p, int tile, int nz, hipStream_t s);  // gemm_bf16p.hip
-int fs2_gemmbq_launch(GemmP& p, int tile, int nz, hipStream_t s);  // gemm_bf16q.hip
 
 // tile ids of the bf16-storage core: 20 = 128x128 (2 stages, 2 workgroups / CU), 22 = 128x64 (2 stages, 3 / CU),
 // 23 = 64x64 (3 stages, 3 / CU); persistent (one K-tile stream per workgroup across its tiles): 24 = 128x128 (2 / CU),
-// 25 = 128x64 (3 / CU); deep-ring persistent (one workgroup per CU, NST - 1 K-tiles in flight, counted waits): 26 =
-// 128x128 (ring of 4), 27 = 128x64 (ring of 5)
+// 25 = 128x64 (3 / CU).  [A deep-ring form -- one workgroup per CU, a ring of 4-5 stages with counted waits across tile
+// boundaries and epilogues -- was built, is correct, and is slower on every shape (one wavefront per SIMD cannot overlap
+// DMA issue, LDS reads, MFMAs and the epilogue): kept as tools/probes/gemm_bf16_deep_ring.hip.txt, see DESIGN.md.]
 int fs2_gemmb_launch(GemmP& p, int tile, int nz, hipStream_t s) {
   const Fs2GemmArgs& a = p.a;
   const int chunk = (a.R + a.splitk - 1) / a.splitk;
@@ -146,8 +146,6 @@ int fs2_gemmb_launch(GemmP& p, int tile, int nz, hipStream_t s) {
     case 23: return launch_b<64, 64, 3>(p, nz, s);
     case 24:
     case 25: return fs2_gemmbp_launch(p, tile, nz, s);
-    case 26:
-    case 27: return fs2_gemmbq_launch(p, tile, nz, s);
     default: return FS2HIP_EINVAL;
   }
 }

@@ -11,7 +11,7 @@ import torch.nn.functional as F
 
 pytestmark = [pytest.mark.gpu, pytest.mark.tuned_tiles]
 
-TILES = [20, 22, 23, 24, 25, 26, 27, None]
+TILES = [20, 22, 23, 24, 25, None]
 
 
 @pytest.fixture(scope="module")
