@@ -26,10 +26,24 @@ def last_step(dirname, counter, n):
     return sum(float(r["Counter_Value"]) for r in rows), len(rows)
 
 
+def whole_step(dirname, counter):
+    """Sum over EVERY dispatch of the last step (the dispatches between the last two optimizer launches)."""
+    f = glob.glob(f"{dirname}/*/*_counter_collection.csv")[0]
+    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    marks = [i for i, r in enumerate(rows) if "adamw" in r["Kernel_Name"]]
+    if len(marks) < 2:
+        return None, 0
+    sel = rows[marks[-2] + 1:marks[-1] + 1]
+    return sum(float(r["Counter_Value"]) for r in sel), len(sel)
+
+
 def main():
     fetch_dir, write_dir, n = sys.argv[1], sys.argv[2], int(sys.argv[3])
     fetch_kib, nf = last_step(fetch_dir, "FETCH_SIZE", n)
     write_kib, nw = last_step(write_dir, "WRITE_SIZE", n)
+    wf, nwf = whole_step(fetch_dir, "FETCH_SIZE")
+    ww, _ = whole_step(write_dir, "WRITE_SIZE")
     # the figure is only valid for the kernel sources AND the configuration it was measured on: both are stamped,
     # and bench.py reports it only for a run whose stamp matches
     from bench import build_parser, config_signature, kernel_source_hash
@@ -41,6 +55,9 @@ def main():
         "fetch_bytes_per_launch_corrected": 2 * fetch_kib * 1024 / nf,
         "write_bytes_per_launch": write_kib * 1024 / nw,
         "hbm_bytes_per_launch": (2 * fetch_kib + write_kib) * 1024 / nf,
+        "whole_step": None if wf is None else {
+            "launches": nwf, "fetch_bytes_corrected": 2 * wf * 1024, "write_bytes": ww * 1024,
+            "hbm_bytes": (2 * wf + ww) * 1024},
         "note": "last benchmark step only; FETCH_SIZE doubled (gfx950 counts 64 B per 128-B request); L2-side "
                 "counters, Infinity-Cache hits included",
     }
