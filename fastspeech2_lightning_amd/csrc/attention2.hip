@@ -1129,7 +1129,9 @@ __global__ __launch_bounds__(256, 1) void attn2_bwd_dkv_kernel(Attn2Args p, cons
 bool fs2_attn2_supported(int HD, int operand_bf16) { return (operand_bf16 >= 0 && operand_bf16 <= 2) && (HD == 64 || HD == 128); }
 
 int fs2_attn2_fwd(const Attn2Args& a, float* o, float* lse, hipStream_t s) {
-  if ((double)a.B * a.H * a.T * a.T >= 4294967296.0) return FS2HIP_EINVAL;  // 32-bit dropout element index
+  // 32-bit dropout element index; the mask's rows are padded to an even length (one hash serves two neighbouring keys),
+  // so the index stride is T + (T & 1) -- the same bound in the forward and the backward launcher
+  if ((double)a.B * a.H * a.T * (a.T + (a.T & 1)) >= 4294967296.0) return FS2HIP_EINVAL;
   dim3 grid(((a.T + 63) / 64) * a.H * a.B);
 #define FS2_ATTN2_FWD(HD_, DROP_)                                                                 \
   if (a.planes == 3) attn2_fwd_kernel<HD_, DROP_, 3><<<grid, dim3(256), 0, s>>>(a, o, lse);         \
@@ -1149,7 +1151,7 @@ int fs2_attn2_fwd(const Attn2Args& a, float* o, float* lse, hipStream_t s) {
 // {lse', delta'} pair per row and head plus one pair of slack, so it is only used when the caller passes `aux`.
 int fs2_attn2_bwd(const Attn2Args& a, const float* o, const float* dout, const float* lse, float* aux, float* dqkv,
                   hipStream_t s) {
-  if ((double)a.B * a.H * a.T * (a.T + 1) >= 4294967296.0) return FS2HIP_EINVAL;
+  if ((double)a.B * a.H * a.T * (a.T + (a.T & 1)) >= 4294967296.0) return FS2HIP_EINVAL;
   const float dscale = a.drop.on ? a.drop.scale : 1.f;
   attn2_prep_kernel<<<dim3((a.B * a.T + 3) / 4), dim3(256), 0, s>>>(dout, o, lse, reinterpret_cast<float2*>(aux), a.B, a.T,
                                                                      a.H, a.HD, log2f(dscale), 1.f / dscale);

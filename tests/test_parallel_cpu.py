@@ -147,3 +147,54 @@ def test_bench_launches_its_own_ranks_for_gpus_n():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line == {"dry_run": True, "n_gpus": 2, "steps": 5, "warmup": 3}
+
+
+def _tiles_rank(rank, world, port, q):
+    import torch.distributed as dist
+    from fastspeech2_lightning_amd import hip as H
+    from fastspeech2_lightning_amd.parallel import share_tile_table
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    H._TILE_CACHE.clear()
+    key = (20736, 1024, 256, 1, 1, 1, 0, 1, 1, 0, 0, 17, 0)
+    H._TILE_CACHE[key] = 7 if rank == 0 else 12          # each rank "tuned" its own tile ...
+    if rank == 1:
+        H._TILE_CACHE[(4096, 256, 256, 1, 1, 1, 0, 1, 0, 0, 0, 17, 0)] = 9
+    n = share_tile_table(0)
+    q.put((rank, n, H._TILE_CACHE[key]))
+    dist.destroy_process_group()
+
+
+def test_every_rank_adopts_rank_zero_tile_table():
+    """Data parallel: the same GEMM tiles -- hence the same summation order -- on every rank."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_tiles_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res == [(0, 1, 7), (1, 1, 7)]
+
+
+def test_a_failing_rank_stops_the_others():
+    """``--devices N`` / ``bench.py --gpus N`` poll every rank; the first non-zero exit terminates the
+    siblings (which would otherwise sit in a collective until the process-group timeout) and is what is reported."""
+    import subprocess
+    import sys
+    import time
+    from fastspeech2_lightning_amd.cli import wait_ranks
+    procs = [subprocess.Popen([sys.executable, "-c", "import time; time.sleep(60)"]),
+             subprocess.Popen([sys.executable, "-c", "import sys, time; time.sleep(0.5); sys.exit(3)"])]
+    t0 = time.time()
+    rc = wait_ranks(procs)
+    assert rc == 3 and time.time() - t0 < 30
+    assert all(p.poll() is not None for p in procs)
+    ok = [subprocess.Popen([sys.executable, "-c", "pass"]) for _ in range(2)]
+    assert wait_ranks(ok) == 0
