@@ -189,6 +189,8 @@ extern "C" int fs2hip_version(void) { return 1; }
 extern "C" int fs2hip_gemm(const Fs2GemmArgs* args, void* stream) {
   GemmP p;
   p.staged = 0;
+  static const int env_probe = getenv("FS2_GEMM_PROBE") ? atoi(getenv("FS2_GEMM_PROBE")) : 0;
+  p.probe = env_probe;
   p.a = *args;
   Fs2GemmArgs& a = p.a;
   if (a.Mc <= 0 || a.Nc <= 0 || a.R <= 0) return FS2HIP_EINVAL;

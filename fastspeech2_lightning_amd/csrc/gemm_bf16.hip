@@ -56,6 +56,7 @@ __global__ __launch_bounds__(256) void gemmb_kernel(GemmP p) {
   setup_pieces_b<BN, BKC, false, TAPS>(pb, p, n0, r_begin, tid);
   st.begin(p, r_begin, r_end, shift_z);
   auto issue = [&](int stage) {
+    if (p.probe & 2) return;
     char* At = lds + stage * STAGE;
     st.template issue<BM, BN>(p, At, At + A_BYTES, pa, pb, wave, tid);
   };
@@ -75,12 +76,13 @@ __global__ __launch_bounds__(256) void gemmb_kernel(GemmP p) {
     else b_wait_vmcnt_barrier<0>();
     if (kt + NST - 1 < nkt) issue(stage == 0 ? NST - 1 : stage - 1);  // the stage read in iteration kt - 1
     const unsigned sa = lds0 + stage * STAGE, sb = sa + A_BYTES;
-    compute_ktile_b<BM, BN, AKC, BKC, COLSUM>(acc, cs, rda, rdb, sa, sb, do_cs);
+    if (!(p.probe & 1)) compute_ktile_b<BM, BN, AKC, BKC, COLSUM>(acc, cs, rda, rdb, sa, sb, do_cs);
     stage = stage + 1 == NST ? 0 : stage + 1;
   }
   // the stages are free once every wavefront has left the last K-tile: each takes a region of them for its stores
   static_assert(4 * Stager<(BN / 2) * 4>::BYTES <= NST * STAGE, "staging regions fit in the ring");
   __builtin_amdgcn_s_barrier();
+  if (p.probe & 4) return;
   epilogue_dispatch_b<BM, BN, true>(p, acc, m0, n0, wm, wn, lane, split, tapz, lds + wave * Stager<(BN / 2) * 4>::BYTES);
   if (COLSUM && do_cs && wn == 0 && lane < 32) {  // every row of cs[i] is the same sum: take the lane's first register
 #pragma unroll
@@ -142,6 +144,8 @@ int fs2_gemmb_launch(GemmP& p, int tile, int nz, hipStream_t s) {
   p.r_chunk = ((chunk + BKE - 1) / BKE) * BKE;
   switch (tile) {
     case 20: return launch_b<128, 128, 2>(p, nz, s);
+    case 21: return launch_b<128, 64, 3>(p, nz, s);  // 72 KiB: 2 workgroups / CU, two K-tiles in flight each
+    case 26: return launch_b<64, 64, 2>(p, nz, s);   // 32 KiB: 5 workgroups / CU
     case 22: return launch_b<128, 64, 2>(p, nz, s);
     case 23: return launch_b<64, 64, 3>(p, nz, s);
     case 24:

@@ -8,6 +8,8 @@ struct GemmP {
   int tiles_m;     // number of tiles along Mc
   int tiles_n;     // number of tiles along Nc
   int r_chunk;     // split-K chunk (multiple of the core's BK)
+  int probe;       // measurement aid (FS2_GEMM_PROBE, bf16-storage one-tile kernels): bit 0 skip the MFMA phase, bit 1 skip
+                   // the DMA, bit 2 skip the epilogue -- wrong results, timing only
   int staged;      // bf16-storage core: every output row starts 16-byte aligned (whole-row stores through LDS)
   Fs2Drop drop;
 };

@@ -286,7 +286,7 @@ def get_precision() -> str:
     return {0: "32-true", 1: "bf16-mixed", 2: "32-split"}[int(GEMM_BF16)]
 
 
-GEMM_TILES_B = (20, 22, 23, 24, 25)  # bf16-storage core (operand_bf16 == 4): 128x128, 128x64, 64x64;
+GEMM_TILES_B = (20, 21, 22, 23, 24, 25, 26)  # bf16-storage core (operand_bf16 == 4): 128x128, 128x64, 64x64;
 #                                      24 / 25: persistent 128x128 / 128x64
 GEMM_TILES = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)  # 1-3: register-staged BK=16 core; 4-9: direct-to-LDS BK=32 core;
 #                                                      10-12: persistent direct-to-LDS core; 13-15: + split tail
