@@ -23,6 +23,17 @@ def sources() -> list[Path]:
     return sorted(CSRC.glob("*.hip"))
 
 
+def _deps(depfile: Path) -> list[Path]:
+    """Headers of this repo that a source included when it was last compiled (the compiler's -MD output); without a
+    depfile every header counts."""
+    every = list(CSRC.glob("*.h")) + list(INCLUDE.glob("*.h"))
+    if not depfile.exists():
+        return every
+    words = depfile.read_text().replace("\\\n", " ").split()
+    mine = [Path(w) for w in words[1:] if w.endswith(".h") and (str(CSRC) in w or str(INCLUDE) in w)]
+    return mine or every
+
+
 def needs_build() -> bool:
     if not LIB.exists():
         return True
@@ -40,13 +51,13 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     procs = []
     for src in sources():
         obj = obj_dir / (src.stem + ".o")
-        hdrs = list(CSRC.glob("*.h")) + list(INCLUDE.glob("*.h"))
+        dep = obj_dir / (src.stem + ".d")
         stale = force or not obj.exists() or any(
-            d.stat().st_mtime > obj.stat().st_mtime for d in [src] + hdrs)
+            not d.exists() or d.stat().st_mtime > obj.stat().st_mtime for d in [src] + _deps(dep))
         objs.append(obj)
         if stale:
             cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", str(INCLUDE),
-                   "-I", str(CSRC), "-c", str(src), "-o", str(obj)]
+                   "-I", str(CSRC), "-MD", "-MF", str(dep), "-c", str(src), "-o", str(obj)]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -17,3 +17,9 @@ bool fs2_attn2_supported(int HD, int operand_bf16);
 int fs2_attn2_fwd(const Attn2Args& a, float* o, float* lse, hipStream_t s);
 int fs2_attn2_bwd(const Attn2Args& a, const float* o, const float* dout, const float* lse, float* delta, float* dqkv,
                   hipStream_t s);
+
+// bf16-storage family (attention_bf16.hip): qkv / o / dout / dqkv are bf16 tensors of the same shapes; `a.qkv` is unused
+bool fs2_attnb_supported(int HD);
+int fs2_attnb_fwd(const Attn2Args& a, const void* qkv, void* o, float* lse, hipStream_t s);
+int fs2_attnb_bwd(const Attn2Args& a, const void* qkv, const void* o, const void* dout, const float* lse, float* aux,
+                  void* dqkv, hipStream_t s);

@@ -66,6 +66,9 @@ SIGNATURES = {
     "fs2hip_dwconv_bwd_b": "ppippipppiiiiip",
     "fs2hip_attention_fwd": "ppppiiiifQpip",
     "fs2hip_attention_bwd": "pppppppiiiifQpip",
+    "fs2hip_attention_fwd_b": "ppppiiiifQpp",
+    "fs2hip_attention_bwd_b": "pppppppiiiifQpp",
+    "fs2hip_attention_b_supported": "i",
     "fs2hip_dwconv_blocks": "ii",
     "fs2hip_dwconv_part_rows": "",
     "fs2hip_dwconv_fwd": "pippppiiiiiip",
@@ -818,6 +821,41 @@ def attention_bwd(qkv, lens, o, dout, lse, B, T, H, drop: Drop = NO_DROP):
     delta = torch.empty(2 * lse.numel() + 4, device=lse.device, dtype=torch.float32)  # scratch: see fs2hip.h
     _ok(lib().fs2hip_attention_bwd(_p(qkv), _p(lens), _p(o), _p(dout), _p(lse), _p(delta), _p(dqkv), B, T, H, D // H,
                                    drop.p, drop.seed, drop.step_ptr, int(GEMM_BF16), _stream()), "attention_bwd")
+    return dqkv
+
+
+def attention_b_supported(HD: int) -> bool:
+    """True when the bf16-storage attention kernels take this head dimension."""
+    return bool(lib().fs2hip_attention_b_supported(int(HD)))
+
+
+def attention_fwd_b(qkv, lens, B, T, H, drop: Drop = NO_DROP):
+    """Attention on bf16 tensors (precision "bf16-mixed" with bf16 activation storage): qkv bf16 [B*T][3D] -> o bf16,
+    lse fp32.  Same dropout mask as ``attention_fwd`` for the same ``drop``."""
+    _chk(qkv, torch.bfloat16, "qkv"); _chk(lens, torch.int32, "lens")
+    D = qkv.shape[-1] // 3
+    _req(_rows(qkv) == B * T and qkv.shape[-1] == 3 * D and D % H == 0 and lens.numel() == B,
+         "attention_fwd_b: shape mismatch")
+    _req(attention_b_supported(D // H), "attention_fwd_b: head dimension not supported by the bf16-storage kernels")
+    o = torch.empty(B, T, D, device=qkv.device, dtype=torch.bfloat16)
+    lse = torch.empty(B, H, T, device=qkv.device, dtype=torch.float32)
+    _ok(lib().fs2hip_attention_fwd_b(_p(qkv), _p(lens), _p(o), _p(lse), B, T, H, D // H, drop.p, drop.seed,
+                                     drop.step_ptr, _stream()), "attention_fwd_b")
+    return o, lse
+
+
+def attention_bwd_b(qkv, lens, o, dout, lse, B, T, H, drop: Drop = NO_DROP):
+    for n, t in (("qkv", qkv), ("o", o), ("dout", dout)):
+        _chk(t, torch.bfloat16, n)
+    _chk(lse, name="lse"); _chk(lens, torch.int32, "lens")
+    D = qkv.shape[-1] // 3
+    _req(_rows(qkv) == B * T and o.numel() == B * T * D and dout.numel() == B * T * D and lse.numel() == B * H * T
+         and lens.numel() == B, "attention_bwd_b: shape mismatch")
+    _req(attention_b_supported(D // H), "attention_bwd_b: head dimension not supported by the bf16-storage kernels")
+    dqkv = torch.empty_like(qkv)
+    aux = torch.empty(2 * lse.numel() + 4, device=lse.device, dtype=torch.float32)  # {lse', delta'} per row and head
+    _ok(lib().fs2hip_attention_bwd_b(_p(qkv), _p(lens), _p(o), _p(dout), _p(lse), _p(aux), _p(dqkv), B, T, H, D // H,
+                                     drop.p, drop.seed, drop.step_ptr, _stream()), "attention_bwd_b")
     return dqkv
 
 

@@ -260,9 +260,17 @@ class SelfAttention:
     def fwd(self, x, lens):
         S, env = self.S, self.env
         B, T, _ = x.shape
-        if env.stored and self.dims_ok:
+        if env.stored and self.dims_ok and H.attention_b_supported(self.d // self.heads):
+            # bf16 end to end: the projection writes bf16 q | k | v, the attention kernels read and write bf16
+            bf = torch.bfloat16
+            h, ln_saved = self.ln.fwd(x, bf)
+            qkv = H.linear_fwd(h, S.pb(self.wi), S.p(self.bi), out_dtype=bf)
+            ob, lse = H.attention_fwd_b(qkv, lens, B, T, self.heads, env.drop(self.p, self.sa))
+            y = H.linear_fwd(ob, S.pb(self.wo), S.p(self.bo), epi=H.EPI_RESID, resid=x, drop=env.drop(self.p, self.so))
+            return y, Ctx(ln=ln_saved, h=h, qkv=qkv, o=None, ob=ob, lse=lse, lens=lens, stored=True)
+        if env.stored and self.dims_ok:  # other head dims: the fp32-storage attention kernels between two casts
             h, ln_saved = self.ln.fwd(x, torch.bfloat16)
-            qkv = H.linear_fwd(h, S.pb(self.wi), S.p(self.bi))  # fp32: the attention kernels' input
+            qkv = H.linear_fwd(h, S.pb(self.wi), S.p(self.bi))
             o, lse = H.attention_fwd(qkv, lens, B, T, self.heads, env.drop(self.p, self.sa))
             ob = H.cast_bf16(o)
             y = H.linear_fwd(ob, S.pb(self.wo), S.p(self.bo), epi=H.EPI_RESID, resid=x, drop=env.drop(self.p, self.so))
@@ -286,8 +294,12 @@ class SelfAttention:
                 dz = H.cast_bf16(H.axpby(dy, None, 1.0, 0.0, env.drop(self.p, self.so)))
             with env.side(dz, c.ob):
                 H.linear_bwd_weight(dz, c.ob, S.g(self.wo), bias_grad=None if fused else S.g(self.bo))
-            do = H.linear_bwd_data(dz, S.pb(self.wo))  # fp32: the attention kernels' input
-            dqkv = H.cast_bf16(H.attention_bwd(c.qkv, c.lens, c.o, do, c.lse, B, T, self.heads, env.drop(self.p, self.sa)))
+            if c.o is None:
+                do = H.linear_bwd_data(dz, S.pb(self.wo), out_dtype=bf)
+                dqkv = H.attention_bwd_b(c.qkv, c.lens, c.ob, do, c.lse, B, T, self.heads, env.drop(self.p, self.sa))
+            else:
+                do = H.linear_bwd_data(dz, S.pb(self.wo))  # fp32: the attention kernels' input
+                dqkv = H.cast_bf16(H.attention_bwd(c.qkv, c.lens, c.o, do, c.lse, B, T, self.heads, env.drop(self.p, self.sa)))
             with env.side(dqkv, c.h):
                 H.linear_bwd_weight(dqkv, c.h, S.g(self.wi), bias_grad=S.g(self.bi))
             dh = H.linear_bwd_data(dqkv, S.pb(self.wi), out_dtype=bf)

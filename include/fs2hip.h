@@ -206,6 +206,20 @@ int fs2hip_attention_bwd(const float* qkv, const int* lens, const float* o, cons
                          float drop_p, unsigned long long drop_seed,
                          const unsigned long long* drop_step, int operand_bf16, void* stream);
 
+/* The same attention on tensors that ARE bf16 in memory (precision "bf16-mixed" with bf16 activation
+ * storage; torch.autocast(bfloat16) around nn.MultiheadAttention, call sites fs2/model.py:193, :241):
+ * qkv, o, dout, dqkv are bf16 with the shapes above, lse and the scratch `aux` (2*B*H*T + 4 floats)
+ * are fp32.  Head dims for which fs2hip_attention_b_supported() returns 1 (128).  The dropout keep
+ * mask is the one fs2hip_attention_fwd generates for the same (drop_p, drop_seed, drop_step). */
+int fs2hip_attention_b_supported(int HD);
+int fs2hip_attention_fwd_b(const void* qkv, const int* lens, void* o, float* lse, int B, int T, int H,
+                           int HD, float drop_p, unsigned long long drop_seed,
+                           const unsigned long long* drop_step, void* stream);
+int fs2hip_attention_bwd_b(const void* qkv, const int* lens, const void* o, const void* dout,
+                           const float* lse, float* aux, void* dqkv, int B, int T, int H, int HD,
+                           float drop_p, unsigned long long drop_seed,
+                           const unsigned long long* drop_step, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Depthwise Conv1d over time on (B, T, C), 'same' padding, K in {3,5,7,9,15,31}; w is [K][C].
  * glu = 1: the input has 2C columns (value | gate) and a = value * sigmoid(gate) is formed on
