@@ -158,6 +158,44 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __re
   }
 }
 
+// Many split-K finishes in one launch.  The weight gradients are only read by the optimizer / the data-parallel bucket
+// exchange, so their slab sums need not follow each GEMM as a launch of their own (87 per bf16-mixed step, 5.6 us each,
+// most of it launch and drain): job blockIdx.y is summed by the workgroups of its grid row.
+struct SlabJobs {
+  Fs2SlabJob j[FS2_REDUCE_MAX_JOBS];
+};
+__global__ __launch_bounds__(256) void reduce_slabs_multi_kernel(SlabJobs jobs) {
+  const Fs2SlabJob& jb = jobs.j[blockIdx.y];
+  const float* __restrict__ slabs = jb.slabs;
+  float* __restrict__ out = jb.out;
+  const long long n = jb.n, stride = jb.stride;
+  const int nslabs = jb.nslabs;
+  if (jb.vec) {
+    const long long n4 = n >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+      float4 s = reinterpret_cast<const float4*>(slabs)[i];
+      int k = 1;
+      for (; k + 1 < nslabs; k += 2) {
+        const float4 a = reinterpret_cast<const float4*>(slabs + k * stride)[i];
+        const float4 b = reinterpret_cast<const float4*>(slabs + (k + 1) * stride)[i];
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+      }
+      if (k < nslabs) {
+        const float4 a = reinterpret_cast<const float4*>(slabs + k * stride)[i];
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+      }
+      reinterpret_cast<float4*>(out)[i] = s;
+    }
+  } else {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+      float s = slabs[i];
+      for (int k = 1; k < nslabs; ++k) s += slabs[k * stride + i];
+      out[i] = s;
+    }
+  }
+}
+
 // C[m][n] = alpha * sum_s slab_s[m - m0][n] + bias[n] for the rows [m0, Mc) whose tiles a persistent GEMM cut
 // along the reduction (gemm2p.hip, tiles 13/14)
 __global__ __launch_bounds__(256) void tail_fixup_kernel(const float* __restrict__ ws, int S, long long slab,
@@ -234,6 +272,27 @@ extern "C" int fs2hip_reduce_slabs(const float* slabs, float* out, long long n, 
     reduce_slabs_kernel<true><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(slabs, out, n, nslabs, slab_stride);
   else
     reduce_slabs_kernel<false><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(slabs, out, n, nslabs, slab_stride);
+  FS2_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fs2hip_reduce_slabs_multi(const Fs2SlabJob* jobs, int njobs, void* stream) {
+  if (njobs <= 0) return 0;
+  if (!jobs || njobs > FS2_REDUCE_MAX_JOBS) return FS2HIP_EINVAL;
+  SlabJobs arg;
+  long long nmax = 0;
+  for (int i = 0; i < njobs; ++i) {
+    Fs2SlabJob j = jobs[i];
+    if (!j.slabs || !j.out || j.n <= 0 || j.nslabs < 1 || (j.nslabs > 1 && j.stride < j.n)) return FS2HIP_EINVAL;
+    // (the same summation order as fs2hip_reduce_slabs: slab 0, 1, 2, ... per element)
+    j.vec = (j.n % 4) == 0 && (j.stride % 4) == 0 && ((uintptr_t)j.slabs % 16) == 0 && ((uintptr_t)j.out % 16) == 0;
+    arg.j[i] = j;
+    nmax = j.n > nmax ? j.n : nmax;
+  }
+  long long blocks = (nmax / 4 + 255) / 256;
+  if (blocks > 256) blocks = 256;
+  if (blocks < 1) blocks = 1;
+  reduce_slabs_multi_kernel<<<dim3((unsigned)blocks, njobs), dim3(256), 0, (hipStream_t)stream>>>(arg);
   FS2_LAUNCH_CHECK();
   return 0;
 }

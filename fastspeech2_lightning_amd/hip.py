@@ -53,6 +53,7 @@ _T = {"p": C.c_void_p, "i": C.c_int, "f": C.c_float, "q": C.c_longlong, "Q": C.c
 SIGNATURES = {
     "fs2hip_version": "",
     "fs2hip_gemm": None,  # (const Fs2GemmArgs*, stream)
+    "fs2hip_reduce_slabs_multi": "pip",
     "fs2hip_reduce_slabs": "ppqiqp",
     "fs2hip_reduce_rows_multi": None,  # (const Fs2ReduceJob*, int, void*): set below
     "fs2hip_colsum_rows": "i",
@@ -144,6 +145,7 @@ def lib():
                 fn.argtypes = [_T[c] for c in sig]
         L.fs2hip_gemm.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
         L.fs2hip_reduce_rows_multi.argtypes = [C.POINTER(ReduceJob), C.c_int, C.c_void_p]
+        L.fs2hip_reduce_slabs_multi.argtypes = [C.POINTER(SlabJob), C.c_int, C.c_void_p]
         _lib = L
     return _lib
 
@@ -642,8 +644,14 @@ def linear_bwd_weight(dy, x, out, *, taps=1, T=0, n_valid=None, bias_grad=None):
         in_kernel = (not stored) and SPLITK_IN_KERNEL and taps * ((N + 63) // 64) * ((K + 63) // 64) <= SPLITK_COUNTERS
         if in_kernel:  # the last workgroup of every output tile sums the slabs: no second launch
             kw["counters"] = _p(splitk_counters(dy.device))
+        defer = _DEFER_SLABS and not in_kernel
+        if defer:  # a buffer of its own, summed with every other pending split at the next flush_grad_reductions()
+            ws = torch.empty(S * n, device=dy.device, dtype=torch.float32)
+            kw["workspace"] = _p(ws)
         _gemm(_algorithmic=n_valid is None, **kw)
-        if not in_kernel:
+        if defer:
+            _PENDING_SLABS.append((ws, out, n, S))
+        elif not in_kernel:
             _ok(lib().fs2hip_reduce_slabs(_p(ws), _p(out), n, S, n, _stream()), "reduce_slabs")
     else:
         _gemm(_algorithmic=n_valid is None, **kw)
@@ -674,10 +682,35 @@ class ReduceJob(C.Structure):  # mirrors Fs2ReduceJob (include/fs2hip.h)
                 ("rows", C.c_int), ("n", C.c_int), ("n0", C.c_int), ("pad_", C.c_int)]
 
 
+class SlabJob(C.Structure):  # mirrors Fs2SlabJob (include/fs2hip.h)
+    _fields_ = [("slabs", C.c_void_p), ("out", C.c_void_p), ("n", C.c_longlong), ("stride", C.c_longlong),
+                ("nslabs", C.c_int), ("vec", C.c_int)]
+
+
+#: split-K slab sets of weight-gradient GEMMs waiting for their sum.  Only while ``defer_slab_reductions(True)`` is in
+#: force (FastSpeech2.backward): direct callers of ``linear_bwd_weight`` get a finished gradient as before.
+_PENDING_SLABS = []
+_DEFER_SLABS = False
+
+
+def defer_slab_reductions(on: bool) -> bool:
+    """While on, ``linear_bwd_weight`` leaves its split-K slabs unsummed until ``flush_grad_reductions()`` (one launch
+    for up to ``REDUCE_MAX_JOBS`` weight gradients instead of one each).  Returns the previous setting."""
+    global _DEFER_SLABS
+    prev, _DEFER_SLABS = _DEFER_SLABS, bool(on) and os.environ.get("FS2_DEFER_SLABS", "1") != "0"
+    return prev
+
+
 def _defer_reduction(partial, rows, n, stride, out0, n0, out1):
     # never flushed from here: the caller may be on the side stream (modules.Env.side) while other partial sums
     # were produced on the main one; flush_grad_reductions() is called on the main stream after the join
     _PENDING_REDUCTIONS.append((partial, rows, n, stride, out0, n0, out1))
+
+
+def drop_pending_reductions():
+    """Forgets every pending second-stage sum (a backward pass that raised half way)."""
+    _PENDING_REDUCTIONS.clear()
+    _PENDING_SLABS.clear()
 
 
 def flush_grad_reductions():
@@ -693,6 +726,14 @@ def flush_grad_reductions():
             used.append(partial)
         _ok(lib().fs2hip_reduce_rows_multi(jobs, len(batch), _stream()), "reduce_rows_multi")
         del _PENDING_REDUCTIONS[:len(batch)]
+    while _PENDING_SLABS:
+        batch = _PENDING_SLABS[:REDUCE_MAX_JOBS]
+        jobs = (SlabJob * len(batch))()
+        for j, (ws, out, n, S) in zip(jobs, batch):
+            j.slabs, j.out, j.n, j.stride, j.nslabs, j.vec = _p(ws), _p(out), n, n, S, 0
+            used.append(ws)
+        _ok(lib().fs2hip_reduce_slabs_multi(jobs, len(batch), _stream()), "reduce_slabs_multi")
+        del _PENDING_SLABS[:len(batch)]
     return used
 
 

@@ -565,7 +565,14 @@ class FastSpeech2(_Base):
     def backward(self):
         """Fills ``store.grad`` with d(total loss)/d(parameters) for the last training forward + loss."""
         with torch.cuda.device(self.device_):
-            return self._backward()
+            prev = H.defer_slab_reductions(True)  # split-K finishes of the weight gradients: batched at the flushes
+            try:
+                return self._backward()
+            except BaseException:
+                H.drop_pending_reductions()  # (their outputs belong to a backward pass that did not finish)
+                raise
+            finally:
+                H.defer_slab_reductions(prev)
 
     def _backward(self):
         if self._ctx is None or self._loss_grads is None:

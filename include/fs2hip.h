@@ -145,6 +145,17 @@ int fs2hip_reduce_rows_multi(const Fs2ReduceJob* jobs, int njobs, void* stream);
 int fs2hip_reduce_slabs(const float* slabs, float* out, long long n, int nslabs,
                         long long slab_stride, void* stream);
 
+/* The same for up to FS2_REDUCE_MAX_JOBS independent slab sets in one launch (the split-K finishes of
+ * a whole backward pass: weight gradients are only read by the optimizer, fs2/model.py:530-549 via
+ * Lightning's optimizer step).  `vec` is set by the library. */
+typedef struct {
+  const float* slabs;
+  float* out;
+  long long n, stride;
+  int nslabs, vec;
+} Fs2SlabJob;
+int fs2hip_reduce_slabs_multi(const Fs2SlabJob* jobs, int njobs, void* stream);
+
 /* column sums of a [M][N] matrix (bias gradients): partial[gy][N] then reduce_slabs.
  * partial must hold fs2hip_colsum_rows(M) * N floats. */
 int fs2hip_colsum_rows(int M);
