@@ -176,15 +176,30 @@ __device__ __forceinline__ void store_bf16x4(void* dst, long long i4, float4 v) 
   reinterpret_cast<bn_bf16x4*>(dst)[i4] = __builtin_convertvector(f, bn_bf16x4);
 }
 
+// four consecutive elements starting at element index e (a multiple of 4) of a tensor that is fp32 (IB = false) or
+// bf16 (IB = true) in memory
+template <bool IB>
+__device__ __forceinline__ float4 bn_ld4(const void* p, long long e) {
+  if constexpr (IB) {
+    const uint2 u = *reinterpret_cast<const uint2*>((const unsigned short*)p + e);
+    return make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                       __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
+  } else {
+    return *reinterpret_cast<const float4*>((const float*)p + e);
+  }
+}
+
 // out_b (may be null): a bf16 copy of the output for a GEMM that takes bf16 operands from memory (operand_bf16 == 3)
-__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ y, const float* __restrict__ stats,
+// IB: y is a bf16 tensor (the depthwise convolution's bf16 result)
+template <bool IB>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const void* __restrict__ y, const float* __restrict__ stats,
                                                           float* __restrict__ out, void* __restrict__ out_b, long long n4,
                                                           int C, int act, Fs2Drop drop_in) {
   const Fs2Drop drop = fs2_resolve_drop(drop_in);
   const int c4n = C >> 2;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     const int c4 = (int)(i % c4n);
-    float4 v = reinterpret_cast<const float4*>(y)[i];
+    float4 v = bn_ld4<IB>(y, i * 4);
     float4 sc = reinterpret_cast<const float4*>(stats)[c4];
     float4 sh = reinterpret_cast<const float4*>(stats + C)[c4];
     float4 o;
@@ -203,7 +218,8 @@ __device__ __forceinline__ float dz_of(float dout, float v, float sc, float sh, 
 }
 
 // dz = dout * dropmask * act'(y*scale+shift) ; partial[blk][0][C] = sum dz, [1] = sum dz * xhat
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dout, const float* __restrict__ y,
+template <bool IB>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const void* __restrict__ dout, const void* __restrict__ y,
                                                              const float* __restrict__ stats, int M, int C, int act,
                                                              Fs2Drop drop_in, float* __restrict__ partial, WideMap wm) {
   const Fs2Drop drop = fs2_resolve_drop(drop_in);
@@ -232,15 +248,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         idx[u] = (long long)(r + u * wm.rpi) * C + c4 * 4;
-        v[u] = *reinterpret_cast<const float4*>(y + idx[u]);
-        d[u] = *reinterpret_cast<const float4*>(dout + idx[u]);
+        v[u] = bn_ld4<IB>(y, idx[u]);
+        d[u] = bn_ld4<IB>(dout, idx[u]);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) add(idx[u], v[u], d[u]);
     }
     for (; r < r1; r += wm.rpi) {
       const long long idx = (long long)r * C + c4 * 4;
-      add(idx, *reinterpret_cast<const float4*>(y + idx), *reinterpret_cast<const float4*>(dout + idx));
+      add(idx, bn_ld4<IB>(y, idx), bn_ld4<IB>(dout, idx));
     }
   }
   red[0][tid] = s1;
@@ -274,7 +290,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
 }
 
 // dy = scale * (dz - mean(dz) - xhat * mean(dz*xhat))   [training]   or scale * dz   [eval]
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ y,
+template <bool IB>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restrict__ dout, const void* __restrict__ y,
                                                             const float* __restrict__ stats, const float* __restrict__ coef,
                                                             float* __restrict__ dy, void* __restrict__ dy_b, long long n4,
                                                             int C, int act, Fs2Drop drop_in, int training) {
@@ -283,8 +300,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     const int c4 = (int)(i % c4n);
     const float4 sc = reinterpret_cast<const float4*>(stats)[c4], sh = reinterpret_cast<const float4*>(stats + C)[c4];
-    const float4 v = reinterpret_cast<const float4*>(y)[i];
-    const float4 d = reinterpret_cast<const float4*>(dout)[i];
+    const float4 v = bn_ld4<IB>(y, i * 4);
+    const float4 d = bn_ld4<IB>(dout, i * 4);
     float4 dz;
     dz.x = dz_of(d.x, v.x, sc.x, sh.x, act, drop, (unsigned long long)(i * 4 + 0));
     dz.y = dz_of(d.y, v.y, sc.y, sh.y, act, drop, (unsigned long long)(i * 4 + 1));
@@ -341,63 +358,73 @@ extern "C" int fs2hip_bn_finalize(const float* partial, int nparts, long long co
   return 0;
 }
 
-extern "C" int fs2hip_bn_act_fwd_b(const float* y, const float* stats, float* out, void* out_bf16, int M, int C, int act,
+extern "C" int fs2hip_bn_act_fwd_b(const void* y, const float* stats, float* out, void* out_bf16, int M, int C, int act,
                                    float drop_p, unsigned long long drop_seed, const unsigned long long* drop_step,
-                                   void* stream);
+                                   int in_bf16, void* stream);
 extern "C" int fs2hip_bn_act_fwd(const float* y, const float* stats, float* out, int M, int C, int act, float drop_p,
                                  unsigned long long drop_seed, const unsigned long long* drop_step, void* stream) {
-  return fs2hip_bn_act_fwd_b(y, stats, out, nullptr, M, C, act, drop_p, drop_seed, drop_step, stream);
+  return fs2hip_bn_act_fwd_b(y, stats, out, nullptr, M, C, act, drop_p, drop_seed, drop_step, 0, stream);
 }
 
-extern "C" int fs2hip_bn_act_fwd_b(const float* y, const float* stats, float* out, void* out_bf16, int M, int C, int act,
+// in_bf16: y is a bf16 tensor
+extern "C" int fs2hip_bn_act_fwd_b(const void* y, const float* stats, float* out, void* out_bf16, int M, int C, int act,
                                    float drop_p, unsigned long long drop_seed, const unsigned long long* drop_step,
-                                   void* stream) {
-  if (M <= 0 || C <= 0 || (C % 4) || ((uintptr_t)y % 16) || ((uintptr_t)out % 16) || ((uintptr_t)stats % 16) ||
-      ((uintptr_t)out_bf16 % 8) || (!out && !out_bf16))
+                                   int in_bf16, void* stream) {
+  if (M <= 0 || C <= 0 || (C % 4) || ((uintptr_t)y % (in_bf16 ? 8 : 16)) || ((uintptr_t)out % 16) ||
+      ((uintptr_t)stats % 16) || ((uintptr_t)out_bf16 % 8) || (!out && !out_bf16))
     return FS2HIP_EINVAL;
   const long long n4 = (long long)M * C / 4;
   long long blocks = (n4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  bn_act_fwd_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(y, stats, out, out_bf16, n4, C, act,
-                                                                                     fs2_make_drop(drop_p, drop_seed, drop_step));
+  const Fs2Drop drop = fs2_make_drop(drop_p, drop_seed, drop_step);
+  if (in_bf16)
+    bn_act_fwd_kernel<true><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(y, stats, out, out_bf16, n4, C, act, drop);
+  else
+    bn_act_fwd_kernel<false><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(y, stats, out, out_bf16, n4, C, act, drop);
   FS2_LAUNCH_CHECK();
   return 0;
 }
 
 // partial: [fs2hip_colstats_parts(M)][2][C]; coef: [2][C] scratch (16-byte aligned)
-extern "C" int fs2hip_bn_act_bwd_b(const float* dout, const float* y, const float* stats, float* partial, float* coef,
+extern "C" int fs2hip_bn_act_bwd_b(const void* dout, const void* y, const float* stats, float* partial, float* coef,
                                    float* dgamma, float* dbeta, float* dy, void* dy_bf16, int M, int C, int act,
                                    float drop_p, unsigned long long drop_seed, const unsigned long long* drop_step,
-                                   int training, void* stream);
+                                   int training, int in_bf16, void* stream);
 extern "C" int fs2hip_bn_act_bwd(const float* dout, const float* y, const float* stats, float* partial, float* coef,
                                  float* dgamma, float* dbeta, float* dy, int M, int C, int act, float drop_p,
                                  unsigned long long drop_seed, const unsigned long long* drop_step, int training,
                                  void* stream) {
   return fs2hip_bn_act_bwd_b(dout, y, stats, partial, coef, dgamma, dbeta, dy, nullptr, M, C, act, drop_p, drop_seed,
-                             drop_step, training, stream);
+                             drop_step, training, 0, stream);
 }
 
-extern "C" int fs2hip_bn_act_bwd_b(const float* dout, const float* y, const float* stats, float* partial, float* coef,
+// in_bf16: dout and y are bf16 tensors
+extern "C" int fs2hip_bn_act_bwd_b(const void* dout, const void* y, const float* stats, float* partial, float* coef,
                                    float* dgamma, float* dbeta, float* dy, void* dy_bf16, int M, int C, int act,
                                    float drop_p, unsigned long long drop_seed, const unsigned long long* drop_step,
-                                   int training, void* stream) {
+                                   int training, int in_bf16, void* stream) {
   if (((uintptr_t)dy_bf16 % 8) || (!dy && !dy_bf16)) return FS2HIP_EINVAL;
   WideMap wm;
   if (M <= 0 || C <= 0 || !wide_ok(C, wm)) return FS2HIP_EINVAL;
-  if (((uintptr_t)dout % 16) || ((uintptr_t)y % 16) || ((uintptr_t)stats % 16) || ((uintptr_t)partial % 16) ||
+  const int ia = in_bf16 ? 8 : 16;
+  if (((uintptr_t)dout % ia) || ((uintptr_t)y % ia) || ((uintptr_t)stats % 16) || ((uintptr_t)partial % 16) ||
       ((uintptr_t)coef % 16) || ((uintptr_t)dy % 16))
     return FS2HIP_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const Fs2Drop drop = fs2_make_drop(drop_p, drop_seed, drop_step);
   const int nparts = fs2hip_colstats_parts(M);
-  bn_bwd_reduce_kernel<<<dim3(nparts), dim3(256), 0, s>>>(dout, y, stats, M, C, act, drop, partial, wm);
+  if (in_bf16) bn_bwd_reduce_kernel<true><<<dim3(nparts), dim3(256), 0, s>>>(dout, y, stats, M, C, act, drop, partial, wm);
+  else bn_bwd_reduce_kernel<false><<<dim3(nparts), dim3(256), 0, s>>>(dout, y, stats, M, C, act, drop, partial, wm);
   FS2_LAUNCH_CHECK();
   bn_bwd_finalize_kernel<<<dim3((C + FIN_CH - 1) / FIN_CH), dim3(1024), 0, s>>>(partial, nparts, (long long)M, dgamma, dbeta, coef, C);
   FS2_LAUNCH_CHECK();
   const long long n4 = (long long)M * C / 4;
   long long blocks = (n4 + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  bn_bwd_apply_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(dout, y, stats, coef, dy, dy_bf16, n4, C, act, drop, training);
+  if (in_bf16)
+    bn_bwd_apply_kernel<true><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(dout, y, stats, coef, dy, dy_bf16, n4, C, act, drop, training);
+  else
+    bn_bwd_apply_kernel<false><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(dout, y, stats, coef, dy, dy_bf16, n4, C, act, drop, training);
   FS2_LAUNCH_CHECK();
   return 0;
 }

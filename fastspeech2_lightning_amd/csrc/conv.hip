@@ -10,11 +10,23 @@ namespace {
 
 constexpr int RUN = 16;  // consecutive time steps per thread
 
-// x: [B*T][ldx]; value at column c, gate (GLU) at column C + c
-template <int K, bool GLU, bool STATS>
-__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict__ x, int ldx,
+// element loads / stores of a tensor that is fp32 (XB = false) or bf16 (XB = true) in memory
+__device__ __forceinline__ unsigned short dw_bf16(float v) {
+  return __builtin_bit_cast(unsigned short, (__bf16)v);  // round to nearest even, NaN stays NaN
+}
+template <bool XB>
+__device__ __forceinline__ float dw_ld(const void* p, long long i) {
+  if constexpr (XB) return __builtin_bit_cast(float, (unsigned)((const unsigned short*)p)[i] << 16);
+  else return ((const float*)p)[i];
+}
+
+// x: [B*T][ldx]; value at column c, gate (GLU) at column C + c.  XB: x and y are bf16 tensors (precision "bf16-mixed"
+// with bf16 activation storage: what autocast hands a convolution); the statistics are those of the ROUNDED outputs,
+// which is what BatchNorm then normalises.
+template <int K, bool GLU, bool STATS, bool XB = false>
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const void* __restrict__ x, int ldx,
                                                           const float* __restrict__ w, const float* __restrict__ bias,
-                                                          float* __restrict__ y, float* __restrict__ partial, int B,
+                                                          void* __restrict__ y, float* __restrict__ partial, int B,
                                                           int T, int C) {
   constexpr int PAD = (K - 1) / 2, WIN = RUN + K - 1;
   __shared__ float red[4][2][64];
@@ -33,9 +45,9 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict
     int t = t0 - PAD + i;
     float v = 0.f;
     if (cok && t >= 0 && t < T) {
-      const float* row = x + ((long long)b * T + t) * ldx;
-      v = row[c];
-      if (GLU) v *= fs2_sigmoid(row[C + c]);
+      const long long row = ((long long)b * T + t) * ldx;
+      v = dw_ld<XB>(x, row + c);
+      if (GLU) v *= fs2_sigmoid(dw_ld<XB>(x, row + C + c));
     }
     a[i] = v;
   }
@@ -49,7 +61,13 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict
       float acc = bs;
 #pragma unroll
       for (int k = 0; k < K; ++k) acc = fmaf(wk[k], a[o + k], acc);
-      y[((long long)b * T + t) * C + c] = acc;
+      if constexpr (XB) {
+        const unsigned short r = dw_bf16(acc);
+        ((unsigned short*)y)[((long long)b * T + t) * C + c] = r;
+        acc = __builtin_bit_cast(float, (unsigned)r << 16);
+      } else {
+        ((float*)y)[((long long)b * T + t) * C + c] = acc;
+      }
       if (STATS) {
         if (o == 0) pivot = acc;
         const float d = acc - pivot;
@@ -85,11 +103,9 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict
 
 // dy [B*T][C]; x as in the forward; dx has the layout of x.  partial [blk][K+1][C]: dw taps, dbias.
 // DXB: dx is written as bf16 (the operand of the pointwise convolution's data- and weight-gradient GEMMs)
-__device__ __forceinline__ unsigned short dw_bf16(float v) {
-  return __builtin_bit_cast(unsigned short, (__bf16)v);  // round to nearest even, NaN stays NaN
-}
-template <int K, bool GLU, bool DXB = false>
-__global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+// XB: dy and x are bf16 tensors
+template <int K, bool GLU, bool DXB = false, bool XB = false>
+__global__ __launch_bounds__(256) void dwconv_bwd_kernel(const void* __restrict__ dy, const void* __restrict__ x,
                                                           int ldx, const float* __restrict__ w, void* __restrict__ dxv,
                                                           float* __restrict__ partial, int B, int T, int C) {
   constexpr int PAD = (K - 1) / 2, WIN = RUN + K - 1;
@@ -111,14 +127,14 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict
     int t = t0 - PAD + i;
     float v = 0.f, d = 0.f, vv = 0.f, sg = 0.f;
     if (cok && t >= 0 && t < T) {
-      const float* row = x + ((long long)b * T + t) * ldx;
-      vv = row[c];
+      const long long row = ((long long)b * T + t) * ldx;
+      vv = dw_ld<XB>(x, row + c);
       v = vv;
       if (GLU) {
-        sg = fs2_sigmoid(row[C + c]);
+        sg = fs2_sigmoid(dw_ld<XB>(x, row + C + c));
         v = vv * sg;
       }
-      d = dy[((long long)b * T + t) * C + c];
+      d = dw_ld<XB>(dy, ((long long)b * T + t) * C + c);
     }
     a[i] = v;
     g[i] = d;
@@ -177,13 +193,25 @@ extern "C" int fs2hip_dwconv_blocks(int B, int T) { return B * ((T + 4 * RUN - 1
 extern "C" int fs2hip_dwconv_part_rows(void) { return 4 * RUN; }
 
 #define DW_FWD(KK)                                                                                              \
-  if (glu && stats) dwconv_fwd_kernel<KK, true, true><<<grid, dim3(256), 0, s>>>(x, ldx, w, bias, y, partial, B, T, C); \
+  if (io_bf16) {                                                                                                \
+    if (!glu) return FS2HIP_EINVAL; /* bf16 tensors: the Conformer convolution module's GLU form only */         \
+    if (stats) dwconv_fwd_kernel<KK, true, true, true><<<grid, dim3(256), 0, s>>>(x, ldx, w, bias, y, partial, B, T, C); \
+    else dwconv_fwd_kernel<KK, true, false, true><<<grid, dim3(256), 0, s>>>(x, ldx, w, bias, y, partial, B, T, C);      \
+  } else if (glu && stats) dwconv_fwd_kernel<KK, true, true><<<grid, dim3(256), 0, s>>>(x, ldx, w, bias, y, partial, B, T, C); \
   else if (glu) dwconv_fwd_kernel<KK, true, false><<<grid, dim3(256), 0, s>>>(x, ldx, w, bias, y, partial, B, T, C);   \
   else if (stats) dwconv_fwd_kernel<KK, false, true><<<grid, dim3(256), 0, s>>>(x, ldx, w, bias, y, partial, B, T, C); \
   else dwconv_fwd_kernel<KK, false, false><<<grid, dim3(256), 0, s>>>(x, ldx, w, bias, y, partial, B, T, C);
 
+extern "C" int fs2hip_dwconv_fwd_b(const void* x, int ldx, const float* w, const float* bias, void* y, float* partial,
+                                   int B, int T, int C, int K, int glu, int stats, int io_bf16, void* stream);
 extern "C" int fs2hip_dwconv_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, float* partial,
                                  int B, int T, int C, int K, int glu, int stats, void* stream) {
+  return fs2hip_dwconv_fwd_b(x, ldx, w, bias, y, partial, B, T, C, K, glu, stats, 0, stream);
+}
+
+// io_bf16: x and y are bf16 tensors (GLU form only)
+extern "C" int fs2hip_dwconv_fwd_b(const void* x, int ldx, const float* w, const float* bias, void* y, float* partial,
+                                   int B, int T, int C, int K, int glu, int stats, int io_bf16, void* stream) {
   if (B <= 0 || T <= 0 || C <= 0 || ldx < (glu ? 2 * C : C)) return FS2HIP_EINVAL;
   if (stats && !partial) return FS2HIP_EINVAL;
   dim3 grid((C + 63) / 64, (T + 4 * RUN - 1) / (4 * RUN), B);
@@ -202,7 +230,10 @@ extern "C" int fs2hip_dwconv_fwd(const float* x, int ldx, const float* w, const 
 }
 
 #define DW_BWD(KK)                                                                                                \
-  if (dx_bf16) {                                                                                                  \
+  if (dx_bf16 & 2) {                                                                                              \
+    if (!glu || !(dx_bf16 & 1)) return FS2HIP_EINVAL; /* bf16 inputs: GLU form with a bf16 result only */          \
+    dwconv_bwd_kernel<KK, true, true, true><<<grid, dim3(256), 0, s>>>(dy, x, ldx, w, dx, partial, B, T, C);       \
+  } else if (dx_bf16) {                                                                                           \
     if (glu) dwconv_bwd_kernel<KK, true, true><<<grid, dim3(256), 0, s>>>(dy, x, ldx, w, dx, partial, B, T, C);    \
     else dwconv_bwd_kernel<KK, false, true><<<grid, dim3(256), 0, s>>>(dy, x, ldx, w, dx, partial, B, T, C);       \
   } else {                                                                                                        \
@@ -211,7 +242,7 @@ extern "C" int fs2hip_dwconv_fwd(const float* x, int ldx, const float* w, const 
   }
 
 // partial: [fs2hip_dwconv_blocks(B,T)][K+1][C]; dw [K][C], dbias [C] are finished here
-extern "C" int fs2hip_dwconv_bwd_b(const float* dy, const float* x, int ldx, const float* w, void* dx, int dx_bf16,
+extern "C" int fs2hip_dwconv_bwd_b(const void* dy, const void* x, int ldx, const float* w, void* dx, int dx_bf16,
                                    float* partial, float* dw, float* dbias, int B, int T, int C, int K, int glu,
                                    void* stream);
 extern "C" int fs2hip_dwconv_bwd(const float* dy, const float* x, int ldx, const float* w, float* dx, float* partial,
@@ -219,8 +250,8 @@ extern "C" int fs2hip_dwconv_bwd(const float* dy, const float* x, int ldx, const
   return fs2hip_dwconv_bwd_b(dy, x, ldx, w, dx, 0, partial, dw, dbias, B, T, C, K, glu, stream);
 }
 
-// dx_bf16: dx (layout of x, leading dimension ldx) is written as bf16
-extern "C" int fs2hip_dwconv_bwd_b(const float* dy, const float* x, int ldx, const float* w, void* dx, int dx_bf16,
+// dx_bf16 bit 0: dx (layout of x, leading dimension ldx) is written as bf16; bit 1: dy and x are bf16 tensors
+extern "C" int fs2hip_dwconv_bwd_b(const void* dy, const void* x, int ldx, const float* w, void* dx, int dx_bf16,
                                    float* partial, float* dw, float* dbias, int B, int T, int C, int K, int glu,
                                    void* stream) {
   if (B <= 0 || T <= 0 || C <= 0 || ldx < (glu ? 2 * C : C) || !partial) return FS2HIP_EINVAL;

@@ -73,6 +73,7 @@ SIGNATURES = {
     "fs2hip_dwconv_blocks": "ii",
     "fs2hip_dwconv_part_rows": "",
     "fs2hip_dwconv_fwd": "pippppiiiiiip",
+    "fs2hip_dwconv_fwd_b": "pippppiiiiiiip",
     "fs2hip_dwconv_bwd": "ppipppppiiiiip",
     "fs2hip_colstats_parts": "i",
     "fs2hip_colstats_part_rows": "i",
@@ -80,8 +81,8 @@ SIGNATURES = {
     "fs2hip_bn_finalize": "piqiippppffipip",
     "fs2hip_bn_act_fwd": "pppiiifQpp",
     "fs2hip_bn_act_bwd": "ppppppppiiifQpip",
-    "fs2hip_bn_act_fwd_b": "ppppiiifQpp",
-    "fs2hip_bn_act_bwd_b": "pppppppppiiifQpip",
+    "fs2hip_bn_act_fwd_b": "ppppiiifQpip",
+    "fs2hip_bn_act_bwd_b": "pppppppppiiifQpiip",
     "fs2hip_posenc_table": "ppiip",
     "fs2hip_add_posenc": "ppppiiip",
     "fs2hip_embedding_fwd": "pppiiip",
@@ -913,25 +914,32 @@ class StatParts:
 
 
 def dwconv_fwd(x, w, bias, B, T, *, glu=False, stats=False):
-    """x [B*T, C or 2C] -> y [B, T, C]; w [K, C].  Returns (y, StatParts or None)."""
-    _chk(x, name="x"); _chk(w, name="w")
+    """x [B*T, C or 2C] -> y [B, T, C]; w [K, C].  Returns (y, StatParts or None).  A bf16 ``x`` (GLU form; bf16
+    activation storage) gives a bf16 ``y`` whose statistics are those of the rounded values."""
+    xb = x.dtype == torch.bfloat16
+    _chk(x, x.dtype if xb else torch.float32, "x"); _chk(w, name="w")
+    _req(glu or not xb, "dwconv_fwd: bf16 tensors are taken in the GLU form only")
     K, Cc = w.shape
     ldx = x.shape[-1]
     _req(_rows(x) == B * T and ldx == (2 * Cc if glu else Cc), "dwconv_fwd: shape mismatch")
     if bias is not None:
         _chk(bias, name="bias")
         _req(bias.numel() == Cc, "dwconv_fwd: bias size")
-    y = torch.empty(B, T, Cc, device=x.device, dtype=torch.float32)
+    y = torch.empty(B, T, Cc, device=x.device, dtype=x.dtype)
     nparts = lib().fs2hip_dwconv_blocks(B, T)
     partial = torch.empty(nparts, 2, Cc, device=x.device, dtype=torch.float32) if stats else None
-    _ok(lib().fs2hip_dwconv_fwd(_p(x), ldx, _p(w), _p(bias), _p(y), _p(partial), B, T, Cc, K, int(glu), int(stats),
-                                _stream()), "dwconv_fwd")
+    _ok(lib().fs2hip_dwconv_fwd_b(_p(x), ldx, _p(w), _p(bias), _p(y), _p(partial), B, T, Cc, K, int(glu), int(stats),
+                                  int(xb), _stream()), "dwconv_fwd")
     return y, (StatParts(partial, nparts, lib().fs2hip_dwconv_part_rows(), T, B * T) if stats else None)
 
 
 def dwconv_bwd(dy, x, w, dw, dbias, B, T, *, glu=False, out_dtype=torch.float32):
-    """Returns dx (layout of x; ``out_dtype`` fp32 or bf16); writes dw [K, C] and dbias [C]."""
-    _chk(dy, name="dy"); _chk(x, name="x"); _chk(w, name="w"); _chk(dw, name="dw")
+    """Returns dx (layout of x; ``out_dtype`` fp32 or bf16); writes dw [K, C] and dbias [C].  ``dy`` and ``x`` may both
+    be bf16 tensors (GLU form, bf16 result)."""
+    xb = x.dtype == torch.bfloat16
+    _chk(dy, x.dtype if xb else torch.float32, "dy"); _chk(x, x.dtype if xb else torch.float32, "x")
+    _chk(w, name="w"); _chk(dw, name="dw")
+    _req(not xb or (glu and out_dtype == torch.bfloat16), "dwconv_bwd: bf16 inputs need the GLU form and a bf16 result")
     K, Cc = w.shape
     ldx = x.shape[-1]
     _req(_rows(x) == B * T and ldx == (2 * Cc if glu else Cc) and dy.numel() == B * T * Cc and dw.numel() == K * Cc,
@@ -942,7 +950,7 @@ def dwconv_bwd(dy, x, w, dw, dbias, B, T, *, glu=False, out_dtype=torch.float32)
     dx = torch.empty(x.shape, device=x.device, dtype=out_dtype)
     nblk = lib().fs2hip_dwconv_blocks(B, T)
     ws = _workspace(nblk * (K + 1) * Cc, x.device)
-    _ok(lib().fs2hip_dwconv_bwd_b(_p(dy), _p(x), ldx, _p(w), _p(dx), int(out_dtype == torch.bfloat16), _p(ws), _p(dw),
+    _ok(lib().fs2hip_dwconv_bwd_b(_p(dy), _p(x), ldx, _p(w), _p(dx), int(out_dtype == torch.bfloat16) | (2 if xb else 0), _p(ws), _p(dw),
                                   _p(dbias), B, T, Cc, K, int(glu), _stream()), "dwconv_bwd")
     return dx
 
@@ -981,14 +989,15 @@ def bn_finalize(parts: Optional[StatParts], gamma, beta, running_mean, running_v
 
 def bn_act_fwd(y, stats, act=None, drop: Drop = NO_DROP, bf16_copy=False, bf16_only=False):
     """``bf16_copy``: returns (out, out as bf16) -- the form a bf16-operand GEMM (``linear_fwd`` on bf16 tensors) reads;
-    ``bf16_only``: returns the bf16 form alone (no fp32 tensor is written)."""
-    _chk(y, name="y"); _chk(stats, name="stats")
+    ``bf16_only``: returns the bf16 form alone (no fp32 tensor is written).  ``y`` itself may be bf16."""
+    yb = y.dtype == torch.bfloat16
+    _chk(y, y.dtype if yb else torch.float32, "y"); _chk(stats, name="stats")
     M, Cc = _rows(y), y.shape[-1]
     _req(stats.numel() == 4 * Cc, "bn_act_fwd: stats size")
-    out = None if bf16_only else torch.empty_like(y)
+    out = None if bf16_only else torch.empty(y.shape, device=y.device, dtype=torch.float32)
     out_b = torch.empty(y.shape, device=y.device, dtype=torch.bfloat16) if (bf16_copy or bf16_only) else None
     _ok(lib().fs2hip_bn_act_fwd_b(_p(y), _p(stats), _p(out), _p(out_b), M, Cc, _ACT[act], drop.p, drop.seed,
-                                  drop.step_ptr, _stream()), "bn_act_fwd")
+                                  drop.step_ptr, int(yb), _stream()), "bn_act_fwd")
     if bf16_only:
         return out_b
     return (out, out_b) if bf16_copy else out
@@ -996,7 +1005,9 @@ def bn_act_fwd(y, stats, act=None, drop: Drop = NO_DROP, bf16_copy=False, bf16_o
 
 def bn_act_bwd(dout, y, stats, dgamma, dbeta, act=None, drop: Drop = NO_DROP, training=True, bf16_copy=False,
                bf16_only=False):
-    for n, t in (("dout", dout), ("y", y), ("stats", stats), ("dgamma", dgamma), ("dbeta", dbeta)):
+    yb = y.dtype == torch.bfloat16  # then dout is bf16 as well (bf16 activation storage)
+    _chk(dout, y.dtype if yb else torch.float32, "dout"); _chk(y, y.dtype if yb else torch.float32, "y")
+    for n, t in (("stats", stats), ("dgamma", dgamma), ("dbeta", dbeta)):
         _chk(t, name=n)
     M, Cc = _rows(y), y.shape[-1]
     _req(dout.shape == y.shape and stats.numel() == 4 * Cc and dgamma.numel() == Cc and dbeta.numel() == Cc,
@@ -1004,10 +1015,10 @@ def bn_act_bwd(dout, y, stats, dgamma, dbeta, act=None, drop: Drop = NO_DROP, tr
     nparts = lib().fs2hip_colstats_parts(M)
     ws = _workspace(nparts * 2 * Cc + 2 * Cc, y.device)
     coef_ptr = ws.data_ptr() + 4 * nparts * 2 * Cc
-    dy = None if bf16_only else torch.empty_like(y)
+    dy = None if bf16_only else torch.empty(y.shape, device=y.device, dtype=torch.float32)
     dy_b = torch.empty(y.shape, device=y.device, dtype=torch.bfloat16) if (bf16_copy or bf16_only) else None
     _ok(lib().fs2hip_bn_act_bwd_b(_p(dout), _p(y), _p(stats), _p(ws), coef_ptr, _p(dgamma), _p(dbeta), _p(dy), _p(dy_b),
-                                  M, Cc, _ACT[act], drop.p, drop.seed, drop.step_ptr, int(training), _stream()),
+                                  M, Cc, _ACT[act], drop.p, drop.seed, drop.step_ptr, int(training), int(yb), _stream()),
         "bn_act_bwd")
     if bf16_only:
         return dy_b

@@ -347,8 +347,10 @@ class ConvModule:
         B, T, _ = x.shape
         stored = env.stored and self.dims_ok
         if stored:
+            # value | gate, the depthwise convolution's result and the gradients that retrace them are bf16 tensors (what
+            # autocast hands these convolutions); the BatchNorm statistics are fp32 sums over the rounded values
             h, ln_saved = self.ln.fwd(x, torch.bfloat16)
-            g2 = H.linear_fwd(h, S.pb(self.w1), S.p(self.b1))  # fp32: GLU + depthwise convolution + BN statistics
+            g2 = H.linear_fwd(h, S.pb(self.w1), S.p(self.b1), out_dtype=torch.bfloat16)
         else:
             h, ln_saved = self.ln.fwd(x)
             g2 = H.linear_fwd(h, S.p(self.w1), S.p(self.b1))
@@ -376,8 +378,8 @@ class ConvModule:
                 dz = H.cast_bf16(H.axpby(dy, None, 1.0, 0.0, env.drop(self.p, self.site)))
             with env.side(dz, c.s):
                 H.linear_bwd_weight(dz, c.s, S.g(self.w2), bias_grad=None if fused else S.g(self.b2))
-            ds = H.linear_bwd_data(dz, S.pb(self.w2))
-            dc = H.bn_act_bwd(ds, c.c, c.stats, gg, gb, "silu", training=env.training)
+            ds = H.linear_bwd_data(dz, S.pb(self.w2), out_dtype=bf)
+            dc = H.bn_act_bwd(ds, c.c, c.stats, gg, gb, "silu", training=env.training, bf16_only=True)
             dg2 = H.dwconv_bwd(dc, c.g2, S.p(self.wd), S.g(self.wd), S.g(self.bd), B, T, glu=True, out_dtype=bf)
             with env.side(dg2, c.h):
                 H.linear_bwd_weight(dg2, c.h, S.g(self.w1), bias_grad=S.g(self.b1))

@@ -247,8 +247,13 @@ int fs2hip_dwconv_fwd(const float* x, int ldx, const float* w, const float* bias
                       int B, int T, int C, int K, int glu, int stats, void* stream);
 int fs2hip_dwconv_bwd(const float* dy, const float* x, int ldx, const float* w, float* dx, float* partial,
                       float* dw, float* dbias, int B, int T, int C, int K, int glu, void* stream);
-/* the same with dx written as bf16 when dx_bf16 != 0 (layout and leading dimension of x) */
-int fs2hip_dwconv_bwd_b(const float* dy, const float* x, int ldx, const float* w, void* dx, int dx_bf16, float* partial,
+/* bf16 tensors (precision "bf16-mixed" with bf16 activation storage; what torch.autocast hands the convolution
+ * module of torchaudio's ConformerLayer, call sites fs2/model.py:193, :241), GLU form only:
+ *   fwd_b, io_bf16 != 0: x and y are bf16 (the BatchNorm statistics are those of the rounded y);
+ *   bwd_b, dx_bf16 bit 0: dx is written as bf16 (layout and leading dimension of x); bit 1: dy and x are bf16. */
+int fs2hip_dwconv_fwd_b(const void* x, int ldx, const float* w, const float* bias, void* y, float* partial,
+                        int B, int T, int C, int K, int glu, int stats, int io_bf16, void* stream);
+int fs2hip_dwconv_bwd_b(const void* dy, const void* x, int ldx, const float* w, void* dx, int dx_bf16, float* partial,
                         float* dw, float* dbias, int B, int T, int C, int K, int glu, void* stream);
 
 /* ------------------------------------------------------------------------------------
@@ -279,11 +284,14 @@ int fs2hip_bn_act_bwd(const float* dout, const float* y, const float* stats, flo
 /* The same two with a bf16 form of the output (out_bf16 / dy_bf16, [M][C] bf16) for a consuming GEMM that reads bf16
  * operands from memory (Fs2GemmArgs.operand_bf16 == 4).  Either output pointer may be NULL (not both): with out / dy
  * NULL the tensor exists only in bf16. */
-int fs2hip_bn_act_fwd_b(const float* y, const float* stats, float* out, void* out_bf16, int M, int C, int act,
-                        float drop_p, unsigned long long drop_seed, const unsigned long long* drop_step, void* stream);
-int fs2hip_bn_act_bwd_b(const float* dout, const float* y, const float* stats, float* partial, float* coef,
+/* in_bf16 != 0: the inputs (y; dout and y) are bf16 tensors as well. */
+int fs2hip_bn_act_fwd_b(const void* y, const float* stats, float* out, void* out_bf16, int M, int C, int act,
+                        float drop_p, unsigned long long drop_seed, const unsigned long long* drop_step, int in_bf16,
+                        void* stream);
+int fs2hip_bn_act_bwd_b(const void* dout, const void* y, const float* stats, float* partial, float* coef,
                         float* dgamma, float* dbeta, float* dy, void* dy_bf16, int M, int C, int act, float drop_p,
-                        unsigned long long drop_seed, const unsigned long long* drop_step, int training, void* stream);
+                        unsigned long long drop_seed, const unsigned long long* drop_step, int training, int in_bf16,
+                        void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Positional table / embeddings / bucketize  (fs2/layers.py:123-140, fs2/model.py:183-193,

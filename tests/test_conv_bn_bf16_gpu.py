@@ -1,0 +1,62 @@
+"""bf16 tensors through the Conformer convolution module's memory-bound kernels (depthwise convolution with GLU,
+BatchNorm + SiLU, their backward passes): the bf16-storage variants read bf16 inputs and must give what the fp32 kernels
+give on the same VALUES -- bit for bit where the output type is the same, within one bf16 rounding where the bf16
+variant rounds its result."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def H():
+    from fastspeech2_lightning_amd import hip
+    hip.lib()
+    return hip
+
+
+def bf16_close(a, b, ulps=1.01):
+    """|a - b| <= ulps * 2^-8 * |b| (one bf16 rounding), elementwise, plus a tiny absolute floor."""
+    return bool(((a - b).abs() <= ulps * 2.0 ** -8 * b.abs() + 1e-30).all())
+
+
+@pytest.mark.parametrize("B,T,C,K", [(3, 77, 256, 9), (2, 648, 256, 9), (2, 130, 64, 31), (1, 40, 192, 7)])
+def test_depthwise_conv_glu_on_bf16_tensors(H, B, T, C, K):
+    g = torch.Generator().manual_seed(T + K)
+    x = torch.randn(B * T, 2 * C, generator=g).bfloat16().cuda()
+    w = (0.3 * torch.randn(K, C, generator=g)).cuda()
+    bias = (0.1 * torch.randn(C, generator=g)).cuda()
+    y32, parts32 = H.dwconv_fwd(x.float(), w, bias, B, T, glu=True, stats=True)
+    yb, partsb = H.dwconv_fwd(x, w, bias, B, T, glu=True, stats=True)
+    assert yb.dtype == torch.bfloat16 and torch.equal(yb, y32.bfloat16())
+    # the statistics are those of the rounded outputs: feed them back through the fp32 statistics kernel
+    gam, bet = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+    st_b = H.bn_finalize(partsb, gam, bet, None, None)
+    st_r = H.bn_finalize(H.colstats(yb.float().view(B * T, C)), gam, bet, None, None)
+    assert (st_b[2] - st_r[2]).abs().max().item() < 1e-5 and ((st_b[3] - st_r[3]).abs() / st_r[3]).max().item() < 1e-5
+    dy = torch.randn(B, T, C, generator=g).bfloat16().cuda()
+    dw32, db32 = torch.empty(K, C, device="cuda"), torch.empty(C, device="cuda")
+    dwb, dbb = torch.empty(K, C, device="cuda"), torch.empty(C, device="cuda")
+    dx32 = H.dwconv_bwd(dy.float(), x.float(), w, dw32, db32, B, T, glu=True, out_dtype=torch.bfloat16)
+    dxb = H.dwconv_bwd(dy, x, w, dwb, dbb, B, T, glu=True, out_dtype=torch.bfloat16)
+    assert torch.equal(dxb, dx32) and torch.equal(dwb, dw32) and torch.equal(dbb, db32)
+
+
+@pytest.mark.parametrize("M,C,act,p", [(41472, 256, "silu", 0.0), (1000, 512, "tanh", 0.3), (77, 64, "silu", 0.0)])
+def test_batchnorm_activation_on_bf16_tensors(H, M, C, act, p):
+    g = torch.Generator().manual_seed(M)
+    y = (1.5 * torch.randn(M, C, generator=g) + 0.3).bfloat16().cuda()
+    dout = torch.randn(M, C, generator=g).bfloat16().cuda()
+    gamma, beta = (1 + 0.1 * torch.randn(C, generator=g)).cuda(), (0.1 * torch.randn(C, generator=g)).cuda()
+    stats = H.bn_finalize(H.colstats(y.float()), gamma, beta, None, None)
+    drop = H.Drop(p, 11) if p > 0 else H.NO_DROP
+    o32 = H.bn_act_fwd(y.float(), stats, act, drop, bf16_only=True)
+    ob = H.bn_act_fwd(y, stats, act, drop, bf16_only=True)
+    assert torch.equal(o32, ob)
+    dg32, db32, dgb, dbb = (torch.empty(C, device="cuda") for _ in range(4))
+    d32 = H.bn_act_bwd(dout.float(), y.float(), stats, dg32, db32, act, drop, bf16_only=True)
+    db_ = H.bn_act_bwd(dout, y, stats, dgb, dbb, act, drop, bf16_only=True)
+    assert torch.equal(d32, db_) and torch.equal(dg32, dgb) and torch.equal(db32, dbb)
+    d32f = H.bn_act_bwd(dout.float(), y.float(), stats, dg32, db32, act, drop)
+    dbf = H.bn_act_bwd(dout, y, stats, dgb, dbb, act, drop)
+    assert dbf.dtype == torch.float32 and torch.equal(d32f, dbf)
