@@ -30,7 +30,7 @@ def load(dirname, counter):
 
 busy, active = load(sys.argv[1], "SQ_VALU_MFMA_BUSY_CYCLES"), load(sys.argv[2], "GRBM_GUI_ACTIVE")
 res = {}
-for fam, pat in (("gemm (gemm2 / gemm2p / gemm kernels)", r"^gemm"), ("attention (fwd / dQ / dK-dV)", r"^attn2?_(fwd|bwd)"),
+for fam, pat in (("gemm (gemm2 / gemm2p / gemm kernels)", r"^gemm"), ("attention (fwd / dQ / dK-dV)", r"^attn[2b]?_(fwd|bwd)"),
                  ("whole step", r".")):
     b = sum(v for k, v in busy.items() if re.search(pat, k))
     a = sum(v for k, v in active.items() if re.search(pat, k))
