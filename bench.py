@@ -316,11 +316,11 @@ def log_gemm_breakdown(prof):
             f"tile={tile} {kind[7:]} x{n:3d}: {t:7.3f} ms  {f / t / 1e9:6.1f} TFLOP/s")
 
 
-def committed_traffic(args):
+def committed_traffic(sig):
     """HBM-side bytes per GEMM launch come from two separate rocprofv3 --pmc passes over this same command
     (tools/pmc_traffic.py): they cannot be collected from inside the process, so the committed figure carries the hash
     of the kernel sources and the configuration it was measured on, and is only reported while both match."""
-    want, tree = config_signature(args), kernel_source_hash()
+    want, tree = (sig if isinstance(sig, dict) else config_signature(sig)), kernel_source_hash()
     reason = "no profiles/*gemm_traffic.json for this configuration"
     for tfile in sorted((REPO / "profiles").glob("r*_gemm_traffic.json"), reverse=True):
         t = json.loads(tfile.read_text())
@@ -339,7 +339,9 @@ def committed_traffic(args):
     return None, reason
 
 
-def roofline_of(args, precision, prof, ov):
+def roofline_of(sig, precision, prof, ov):
+    """``sig``: the configuration (argparse namespace or config_signature dict) whose committed counter profile supplies
+    ``traffic``; None: no such profile exists for this leg."""
     g = gemm_numbers(prof, ov)
     tf, gbs = g.pop("_tflops"), g.pop("_gbs")
     if precision == "bf16-mixed":
@@ -351,7 +353,8 @@ def roofline_of(args, precision, prof, ov):
              if hbm_bound else
              {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
               "frac": round(tf / PEAK_BF16_MFMA_TFLOPS, 4)})
-        r.update(traffic=None, flop_per_byte=round(intensity, 1), achieved_tflops=round(tf, 2), achieved_gbs=round(gbs, 1),
+        traffic, source = committed_traffic(sig) if sig is not None else (None, "no counter profile for this leg")
+        r.update(traffic=traffic, traffic_source=source, flop_per_byte=round(intensity, 1), achieved_tflops=round(tf, 2), achieved_gbs=round(gbs, 1),
                  frac_of_bf16_mfma_peak=round(tf / PEAK_BF16_MFMA_TFLOPS, 4), frac_of_hbm_peak=round(gbs / PEAK_HBM_GBS, 4),
                  kernel="gemm family on v_mfma_f32_32x32x16_bf16, fp32 accumulate")
         r.update(g)
@@ -360,8 +363,8 @@ def roofline_of(args, precision, prof, ov):
     # 32-split: six bf16 MFMA products per algorithmic product -> the pipe's ceiling for fp32-accurate flops
     peak = round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1) if split_main else PEAK_FP32_MFMA_TFLOPS
     r = {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4)}
-    if args is not None:
-        r["traffic"], r["traffic_source"] = committed_traffic(args)
+    if sig is not None:
+        r["traffic"], r["traffic_source"] = committed_traffic(sig)
     else:
         r["traffic"] = None
     r["kernel"] = ("gemm2_kernel / gemm2p_kernel family, 32-split instances (6 x v_mfma_f32_32x32x16_bf16 per 32x32x16 block; "
@@ -388,7 +391,10 @@ def extra_leg(name, precision, batch_size, learn_alignment, steps, local, want_r
         prof, ov = gemm_profile(rig)
         if os.environ.get("FS2_BENCH_GEMM_BREAKDOWN"):
             log_gemm_breakdown(prof)
-        out["roofline"] = roofline_of(None, precision, prof, ov)
+        # (only the un-split precisions have a counter profile of their own: tools/profile_round.sh)
+        sig = None if precision == "32-split" else {"precision": precision, "batch": batch_size, "gst": False,
+                                                    "learn_alignment": bool(learn_alignment)}
+        out["roofline"] = roofline_of(sig, precision, prof, ov)
     log(f"{name}: {dt * 1e3:.2f} ms/step, {rig.frames / dt:,.0f} mel-frames/s")
     del rig
     torch.cuda.empty_cache()
