@@ -24,11 +24,25 @@ struct WideMap {
   int tpr, rpi;
 };
 
+// four consecutive elements starting at element index e (a multiple of 4) of a tensor that is fp32 (IB = false) or
+// bf16 (IB = true) in memory
+template <bool IB>
+__device__ __forceinline__ float4 bn_ld4(const void* p, long long e) {
+  if constexpr (IB) {
+    const uint2 u = *reinterpret_cast<const uint2*>((const unsigned short*)p + e);
+    return make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                       __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
+  } else {
+    return *reinterpret_cast<const float4*>((const float*)p + e);
+  }
+}
+
 // Per-stripe (mean, M2 = sum of squared deviations) per channel.  Sums are taken of d = y - pivot with the stripe's
 // first row as the pivot, so M2 = sum d^2 - (sum d)^2 / n subtracts two numbers of the size of the variance, not of
 // the squared mean (a plain E[y^2] - E[y]^2 in fp32 loses the variance of a channel whose |mean| >> std; torch's
 // BatchNorm is Welford).  bn_finalize merges the stripes with Chan's formula in fp64.
-__global__ __launch_bounds__(256) void colstats_wide_kernel(const float* __restrict__ y, int M, int C,
+template <bool IB>
+__global__ __launch_bounds__(256) void colstats_wide_kernel(const void* __restrict__ y, int M, int C,
                                                              float* __restrict__ partial, WideMap wm) {
   __shared__ float4 red[2][256];
   const int tid = threadIdx.x;
@@ -37,7 +51,7 @@ __global__ __launch_bounds__(256) void colstats_wide_kernel(const float* __restr
   const int r0 = blockIdx.x * rows, r1 = min(M, r0 + rows);
   float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0), pv = make_float4(0, 0, 0, 0);
   if (rl < wm.rpi) {
-    pv = *reinterpret_cast<const float4*>(y + (long long)r0 * C + c4 * 4);
+    pv = bn_ld4<IB>(y, (long long)r0 * C + c4 * 4);
     auto add = [&](float4 v) {
       v.x -= pv.x; v.y -= pv.y; v.z -= pv.z; v.w -= pv.w;
       s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
@@ -47,11 +61,11 @@ __global__ __launch_bounds__(256) void colstats_wide_kernel(const float* __restr
     for (; r + 3 * wm.rpi < r1; r += 4 * wm.rpi) {  // four rows' loads in flight per thread, added in row order
       float4 v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(y + (long long)(r + u * wm.rpi) * C + c4 * 4);
+      for (int u = 0; u < 4; ++u) v[u] = bn_ld4<IB>(y, (long long)(r + u * wm.rpi) * C + c4 * 4);
 #pragma unroll
       for (int u = 0; u < 4; ++u) add(v[u]);
     }
-    for (; r < r1; r += wm.rpi) add(*reinterpret_cast<const float4*>(y + (long long)r * C + c4 * 4));
+    for (; r < r1; r += wm.rpi) add(bn_ld4<IB>(y, (long long)r * C + c4 * 4));
   }
   red[0][tid] = s1;
   red[1][tid] = s2;
@@ -176,19 +190,6 @@ __device__ __forceinline__ void store_bf16x4(void* dst, long long i4, float4 v) 
   reinterpret_cast<bn_bf16x4*>(dst)[i4] = __builtin_convertvector(f, bn_bf16x4);
 }
 
-// four consecutive elements starting at element index e (a multiple of 4) of a tensor that is fp32 (IB = false) or
-// bf16 (IB = true) in memory
-template <bool IB>
-__device__ __forceinline__ float4 bn_ld4(const void* p, long long e) {
-  if constexpr (IB) {
-    const uint2 u = *reinterpret_cast<const uint2*>((const unsigned short*)p + e);
-    return make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
-                       __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
-  } else {
-    return *reinterpret_cast<const float4*>((const float*)p + e);
-  }
-}
-
 // out_b (may be null): a bf16 copy of the output for a GEMM that takes bf16 operands from memory (operand_bf16 == 3)
 // IB: y is a bf16 tensor (the depthwise convolution's bf16 result)
 template <bool IB>
@@ -218,7 +219,7 @@ __device__ __forceinline__ float dz_of(float dout, float v, float sc, float sh, 
 }
 
 // dz = dout * dropmask * act'(y*scale+shift) ; partial[blk][0][C] = sum dz, [1] = sum dz * xhat
-template <bool IB>
+template <bool IB, bool DB>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const void* __restrict__ dout, const void* __restrict__ y,
                                                              const float* __restrict__ stats, int M, int C, int act,
                                                              Fs2Drop drop_in, float* __restrict__ partial, WideMap wm) {
@@ -249,14 +250,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const void* __restri
       for (int u = 0; u < 4; ++u) {
         idx[u] = (long long)(r + u * wm.rpi) * C + c4 * 4;
         v[u] = bn_ld4<IB>(y, idx[u]);
-        d[u] = bn_ld4<IB>(dout, idx[u]);
+        d[u] = bn_ld4<DB>(dout, idx[u]);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) add(idx[u], v[u], d[u]);
     }
     for (; r < r1; r += wm.rpi) {
       const long long idx = (long long)r * C + c4 * 4;
-      add(idx, bn_ld4<IB>(y, idx), bn_ld4<IB>(dout, idx));
+      add(idx, bn_ld4<IB>(y, idx), bn_ld4<DB>(dout, idx));
     }
   }
   red[0][tid] = s1;
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
 }
 
 // dy = scale * (dz - mean(dz) - xhat * mean(dz*xhat))   [training]   or scale * dz   [eval]
-template <bool IB>
+template <bool IB, bool DB>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restrict__ dout, const void* __restrict__ y,
                                                             const float* __restrict__ stats, const float* __restrict__ coef,
                                                             float* __restrict__ dy, void* __restrict__ dy_b, long long n4,
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restric
     const int c4 = (int)(i % c4n);
     const float4 sc = reinterpret_cast<const float4*>(stats)[c4], sh = reinterpret_cast<const float4*>(stats + C)[c4];
     const float4 v = bn_ld4<IB>(y, i * 4);
-    const float4 d = bn_ld4<IB>(dout, i * 4);
+    const float4 d = bn_ld4<DB>(dout, i * 4);
     float4 dz;
     dz.x = dz_of(d.x, v.x, sc.x, sh.x, act, drop, (unsigned long long)(i * 4 + 0));
     dz.y = dz_of(d.y, v.y, sc.y, sh.y, act, drop, (unsigned long long)(i * 4 + 1));
@@ -333,10 +334,18 @@ bool wide_ok(int C, WideMap& wm) {
 extern "C" int fs2hip_colstats_parts(int M) { return M > 0 ? (M + cs_rows(M) - 1) / cs_rows(M) : 0; }
 extern "C" int fs2hip_colstats_part_rows(int M) { return M > 0 ? cs_rows(M) : 0; }
 
+extern "C" int fs2hip_colstats_b(const void* y, int M, int C, float* partial, int in_bf16, void* stream);
 extern "C" int fs2hip_colstats(const float* y, int M, int C, float* partial, void* stream) {
+  return fs2hip_colstats_b(y, M, C, partial, 0, stream);
+}
+
+// in_bf16: y is a bf16 tensor
+extern "C" int fs2hip_colstats_b(const void* y, int M, int C, float* partial, int in_bf16, void* stream) {
   WideMap wm;
-  if (M <= 0 || C <= 0 || !wide_ok(C, wm) || ((uintptr_t)y % 16) || ((uintptr_t)partial % 16)) return FS2HIP_EINVAL;
-  colstats_wide_kernel<<<dim3(fs2hip_colstats_parts(M)), dim3(256), 0, (hipStream_t)stream>>>(y, M, C, partial, wm);
+  if (M <= 0 || C <= 0 || !wide_ok(C, wm) || ((uintptr_t)y % (in_bf16 ? 8 : 16)) || ((uintptr_t)partial % 16)) return FS2HIP_EINVAL;
+  const dim3 grid(fs2hip_colstats_parts(M));
+  if (in_bf16) colstats_wide_kernel<true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(y, M, C, partial, wm);
+  else colstats_wide_kernel<false><<<grid, dim3(256), 0, (hipStream_t)stream>>>(y, M, C, partial, wm);
   FS2_LAUNCH_CHECK();
   return 0;
 }
@@ -398,7 +407,7 @@ extern "C" int fs2hip_bn_act_bwd(const float* dout, const float* y, const float*
                              drop_step, training, 0, stream);
 }
 
-// in_bf16: dout and y are bf16 tensors
+// in_bf16 bit 0: y is a bf16 tensor; bit 1: dout is
 extern "C" int fs2hip_bn_act_bwd_b(const void* dout, const void* y, const float* stats, float* partial, float* coef,
                                    float* dgamma, float* dbeta, float* dy, void* dy_bf16, int M, int C, int act,
                                    float drop_p, unsigned long long drop_seed, const unsigned long long* drop_step,
@@ -406,25 +415,34 @@ extern "C" int fs2hip_bn_act_bwd_b(const void* dout, const void* y, const float*
   if (((uintptr_t)dy_bf16 % 8) || (!dy && !dy_bf16)) return FS2HIP_EINVAL;
   WideMap wm;
   if (M <= 0 || C <= 0 || !wide_ok(C, wm)) return FS2HIP_EINVAL;
-  const int ia = in_bf16 ? 8 : 16;
-  if (((uintptr_t)dout % ia) || ((uintptr_t)y % ia) || ((uintptr_t)stats % 16) || ((uintptr_t)partial % 16) ||
+  if (((uintptr_t)dout % ((in_bf16 & 2) ? 8 : 16)) || ((uintptr_t)y % ((in_bf16 & 1) ? 8 : 16)) || ((uintptr_t)stats % 16) || ((uintptr_t)partial % 16) ||
       ((uintptr_t)coef % 16) || ((uintptr_t)dy % 16))
     return FS2HIP_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const Fs2Drop drop = fs2_make_drop(drop_p, drop_seed, drop_step);
   const int nparts = fs2hip_colstats_parts(M);
-  if (in_bf16) bn_bwd_reduce_kernel<true><<<dim3(nparts), dim3(256), 0, s>>>(dout, y, stats, M, C, act, drop, partial, wm);
-  else bn_bwd_reduce_kernel<false><<<dim3(nparts), dim3(256), 0, s>>>(dout, y, stats, M, C, act, drop, partial, wm);
+#define FS2_BN_RED(IB_, DB_) bn_bwd_reduce_kernel<IB_, DB_><<<dim3(nparts), dim3(256), 0, s>>>(dout, y, stats, M, C, act, drop, partial, wm)
+  switch (in_bf16 & 3) {
+    case 0: FS2_BN_RED(false, false); break;
+    case 1: FS2_BN_RED(true, false); break;
+    case 2: FS2_BN_RED(false, true); break;
+    default: FS2_BN_RED(true, true); break;
+  }
+#undef FS2_BN_RED
   FS2_LAUNCH_CHECK();
   bn_bwd_finalize_kernel<<<dim3((C + FIN_CH - 1) / FIN_CH), dim3(1024), 0, s>>>(partial, nparts, (long long)M, dgamma, dbeta, coef, C);
   FS2_LAUNCH_CHECK();
   const long long n4 = (long long)M * C / 4;
   long long blocks = (n4 + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  if (in_bf16)
-    bn_bwd_apply_kernel<true><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(dout, y, stats, coef, dy, dy_bf16, n4, C, act, drop, training);
-  else
-    bn_bwd_apply_kernel<false><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(dout, y, stats, coef, dy, dy_bf16, n4, C, act, drop, training);
+#define FS2_BN_APP(IB_, DB_) bn_bwd_apply_kernel<IB_, DB_><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(dout, y, stats, coef, dy, dy_bf16, n4, C, act, drop, training)
+  switch (in_bf16 & 3) {
+    case 0: FS2_BN_APP(false, false); break;
+    case 1: FS2_BN_APP(true, false); break;
+    case 2: FS2_BN_APP(false, true); break;
+    default: FS2_BN_APP(true, true); break;
+  }
+#undef FS2_BN_APP
   FS2_LAUNCH_CHECK();
   return 0;
 }

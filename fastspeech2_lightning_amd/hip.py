@@ -78,6 +78,7 @@ SIGNATURES = {
     "fs2hip_colstats_parts": "i",
     "fs2hip_colstats_part_rows": "i",
     "fs2hip_colstats": "piipp",
+    "fs2hip_colstats_b": "piipip",
     "fs2hip_bn_finalize": "piqiippppffipip",
     "fs2hip_bn_act_fwd": "pppiiifQpp",
     "fs2hip_bn_act_bwd": "ppppppppiiifQpip",
@@ -956,11 +957,12 @@ def dwconv_bwd(dy, x, w, dw, dbias, B, T, *, glu=False, out_dtype=torch.float32)
 
 
 def colstats(y) -> StatParts:
-    _chk(y, name="y")
+    yb = y.dtype == torch.bfloat16
+    _chk(y, y.dtype if yb else torch.float32, "y")
     M, Cc = _rows(y), y.shape[-1]
     nparts = lib().fs2hip_colstats_parts(M)
     partial = torch.empty(nparts, 2, Cc, device=y.device, dtype=torch.float32)
-    _ok(lib().fs2hip_colstats(_p(y), M, Cc, _p(partial), _stream()), "colstats")
+    _ok(lib().fs2hip_colstats_b(_p(y), M, Cc, _p(partial), int(yb), _stream()), "colstats")
     return StatParts(partial, nparts, lib().fs2hip_colstats_part_rows(M), M, M)
 
 
@@ -1005,8 +1007,8 @@ def bn_act_fwd(y, stats, act=None, drop: Drop = NO_DROP, bf16_copy=False, bf16_o
 
 def bn_act_bwd(dout, y, stats, dgamma, dbeta, act=None, drop: Drop = NO_DROP, training=True, bf16_copy=False,
                bf16_only=False):
-    yb = y.dtype == torch.bfloat16  # then dout is bf16 as well (bf16 activation storage)
-    _chk(dout, y.dtype if yb else torch.float32, "dout"); _chk(y, y.dtype if yb else torch.float32, "y")
+    yb, db = y.dtype == torch.bfloat16, dout.dtype == torch.bfloat16  # (bf16 activation storage: either may be bf16)
+    _chk(dout, dout.dtype if db else torch.float32, "dout"); _chk(y, y.dtype if yb else torch.float32, "y")
     for n, t in (("stats", stats), ("dgamma", dgamma), ("dbeta", dbeta)):
         _chk(t, name=n)
     M, Cc = _rows(y), y.shape[-1]
@@ -1018,7 +1020,7 @@ def bn_act_bwd(dout, y, stats, dgamma, dbeta, act=None, drop: Drop = NO_DROP, tr
     dy = None if bf16_only else torch.empty(y.shape, device=y.device, dtype=torch.float32)
     dy_b = torch.empty(y.shape, device=y.device, dtype=torch.bfloat16) if (bf16_copy or bf16_only) else None
     _ok(lib().fs2hip_bn_act_bwd_b(_p(dout), _p(y), _p(stats), _p(ws), coef_ptr, _p(dgamma), _p(dbeta), _p(dy), _p(dy_b),
-                                  M, Cc, _ACT[act], drop.p, drop.seed, drop.step_ptr, int(training), int(yb), _stream()),
+                                  M, Cc, _ACT[act], drop.p, drop.seed, drop.step_ptr, int(training), int(yb) | (2 if db else 0), _stream()),
         "bn_act_bwd")
     if bf16_only:
         return dy_b

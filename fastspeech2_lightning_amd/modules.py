@@ -236,6 +236,11 @@ class FeedForward:
         return self.ln.bwd(dh, c.ln, dx_add=dy, nxt=nxt)
 
 
+#: FS2_BF16_CHAIN=0 (measurement aid): under bf16 operand storage the convolution module's value|gate / depthwise result
+#: and the PostNet's inner convolution results stay fp32 tensors (the state before they became bf16)
+BF16_CHAIN = os.environ.get("FS2_BF16_CHAIN", "1") != "0"
+
+
 class SelfAttention:
     """LayerNorm -> nn.MultiheadAttention(key_padding_mask) -> Dropout; y = x + f(x)."""
 
@@ -350,7 +355,7 @@ class ConvModule:
             # value | gate, the depthwise convolution's result and the gradients that retrace them are bf16 tensors (what
             # autocast hands these convolutions); the BatchNorm statistics are fp32 sums over the rounded values
             h, ln_saved = self.ln.fwd(x, torch.bfloat16)
-            g2 = H.linear_fwd(h, S.pb(self.w1), S.p(self.b1), out_dtype=torch.bfloat16)
+            g2 = H.linear_fwd(h, S.pb(self.w1), S.p(self.b1), out_dtype=torch.bfloat16 if BF16_CHAIN else torch.float32)
         else:
             h, ln_saved = self.ln.fwd(x)
             g2 = H.linear_fwd(h, S.p(self.w1), S.p(self.b1))
@@ -378,8 +383,9 @@ class ConvModule:
                 dz = H.cast_bf16(H.axpby(dy, None, 1.0, 0.0, env.drop(self.p, self.site)))
             with env.side(dz, c.s):
                 H.linear_bwd_weight(dz, c.s, S.g(self.w2), bias_grad=None if fused else S.g(self.b2))
-            ds = H.linear_bwd_data(dz, S.pb(self.w2), out_dtype=bf)
-            dc = H.bn_act_bwd(ds, c.c, c.stats, gg, gb, "silu", training=env.training, bf16_only=True)
+            chain = c.c.dtype == bf
+            ds = H.linear_bwd_data(dz, S.pb(self.w2), out_dtype=bf if chain else torch.float32)
+            dc = H.bn_act_bwd(ds, c.c, c.stats, gg, gb, "silu", training=env.training, bf16_only=chain)
             dg2 = H.dwconv_bwd(dc, c.g2, S.p(self.wd), S.g(self.wd), S.g(self.bd), B, T, glu=True, out_dtype=bf)
             with env.side(dg2, c.h):
                 H.linear_bwd_weight(dg2, c.h, S.g(self.w1), bias_grad=S.g(self.b1))
@@ -750,7 +756,11 @@ class PostNet:
         saved = []
         for i, (w, b, bn, site) in enumerate(self.convs):
             if x.dtype == torch.bfloat16:
-                raw = H.linear_fwd(x.view(B * T, -1), S.pb(w), S.p(b), taps=self.k, T=T).view(B, T, -1)
+                # a convolution between two bf16-only layers writes a bf16 result as well (what autocast's conv1d
+                # returns): BatchNorm's statistics and both of its passes then read half the bytes.  The last
+                # convolution's result meets the loss gradient in fp32 and stays fp32.
+                raw_dt = torch.bfloat16 if i + 1 < self.n and BF16_CHAIN else torch.float32
+                raw = H.linear_fwd(x.view(B * T, -1), S.pb(w), S.p(b), taps=self.k, T=T, out_dtype=raw_dt).view(B, T, -1)
             else:
                 raw = H.linear_fwd(x, S.p(w), S.p(b), taps=self.k, T=T)
             stats = bn.stats(H.colstats(raw) if env.training else None, env.training)
@@ -792,7 +802,10 @@ class PostNet:
             with env.side(draw_b, xb):
                 H.linear_bwd_weight(draw_b.view(B * T, -1), xb.view(B * T, -1), S.g(w), taps=self.k, T=T, bias_grad=S.g(b))
             if need and dgrad_b:
-                dy = H.linear_bwd_data(draw_b.view(B * T, -1), S.pb(w), taps=self.k, T=T).view(B, T, -1)
+                # (the gradient enters the layer below through its BatchNorm backward, which reads it beside that
+                # layer's convolution result: both bf16 or both fp32)
+                dy_dt = torch.bfloat16 if i > 0 and saved[i - 1][1].dtype == torch.bfloat16 else torch.float32
+                dy = H.linear_bwd_data(draw_b.view(B * T, -1), S.pb(w), taps=self.k, T=T, out_dtype=dy_dt).view(B, T, -1)
             elif need:
                 dy = H.linear_bwd_data(draw, S.p(w), taps=self.k, T=T)
         return dy

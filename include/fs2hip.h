@@ -272,6 +272,8 @@ int fs2hip_dwconv_bwd_b(const void* dy, const void* x, int ldx, const float* w, 
 int fs2hip_colstats_parts(int M);
 int fs2hip_colstats_part_rows(int M);
 int fs2hip_colstats(const float* y, int M, int C, float* partial, void* stream);
+/* the same over a bf16 tensor when in_bf16 != 0 (a convolution's bf16 result under bf16 activation storage) */
+int fs2hip_colstats_b(const void* y, int M, int C, float* partial, int in_bf16, void* stream);
 int fs2hip_bn_finalize(const float* partial, int nparts, long long count, int part_rows, int group_rows,
                        const float* gamma, const float* beta, float* running_mean, float* running_var,
                        float momentum, float eps, int training, float* stats, int C, void* stream);
@@ -284,7 +286,7 @@ int fs2hip_bn_act_bwd(const float* dout, const float* y, const float* stats, flo
 /* The same two with a bf16 form of the output (out_bf16 / dy_bf16, [M][C] bf16) for a consuming GEMM that reads bf16
  * operands from memory (Fs2GemmArgs.operand_bf16 == 4).  Either output pointer may be NULL (not both): with out / dy
  * NULL the tensor exists only in bf16. */
-/* in_bf16 != 0: the inputs (y; dout and y) are bf16 tensors as well. */
+/* in_bf16: the inputs are bf16 tensors as well -- fwd: y (any non-zero value); bwd: bit 0 y, bit 1 dout. */
 int fs2hip_bn_act_fwd_b(const void* y, const float* stats, float* out, void* out_bf16, int M, int C, int act,
                         float drop_p, unsigned long long drop_seed, const unsigned long long* drop_step, int in_bf16,
                         void* stream);

@@ -48,7 +48,9 @@ def test_batchnorm_activation_on_bf16_tensors(H, M, C, act, p):
     y = (1.5 * torch.randn(M, C, generator=g) + 0.3).bfloat16().cuda()
     dout = torch.randn(M, C, generator=g).bfloat16().cuda()
     gamma, beta = (1 + 0.1 * torch.randn(C, generator=g)).cuda(), (0.1 * torch.randn(C, generator=g)).cuda()
-    stats = H.bn_finalize(H.colstats(y.float()), gamma, beta, None, None)
+    parts32, partsb = H.colstats(y.float()), H.colstats(y)
+    assert torch.equal(parts32.partial, partsb.partial)
+    stats = H.bn_finalize(partsb, gamma, beta, None, None)
     drop = H.Drop(p, 11) if p > 0 else H.NO_DROP
     o32 = H.bn_act_fwd(y.float(), stats, act, drop, bf16_only=True)
     ob = H.bn_act_fwd(y, stats, act, drop, bf16_only=True)
@@ -60,3 +62,7 @@ def test_batchnorm_activation_on_bf16_tensors(H, M, C, act, p):
     d32f = H.bn_act_bwd(dout.float(), y.float(), stats, dg32, db32, act, drop)
     dbf = H.bn_act_bwd(dout, y, stats, dgb, dbb, act, drop)
     assert dbf.dtype == torch.float32 and torch.equal(d32f, dbf)
+    # one of the two in bf16 (PostNet: the fp32 loss gradient beside a bf16 convolution result, and the reverse)
+    for a, b in ((dout.float(), y), (dout, y.float())):
+        dmix = H.bn_act_bwd(a, b, stats, dgb, dbb, act, drop)
+        assert torch.equal(d32f, dmix) and torch.equal(dg32, dgb) and torch.equal(db32, dbb)
