@@ -66,3 +66,40 @@ def test_batchnorm_activation_on_bf16_tensors(H, M, C, act, p):
     for a, b in ((dout.float(), y), (dout, y.float())):
         dmix = H.bn_act_bwd(a, b, stats, dgb, dbb, act, drop)
         assert torch.equal(d32f, dmix) and torch.equal(dg32, dgb) and torch.equal(db32, dbb)
+
+
+@pytest.mark.parametrize("B,T,C,K,bf", [(2, 648, 256, 9, False), (2, 648, 256, 9, True), (3, 77, 64, 31, False),
+                                       (1, 130, 192, 7, True), (2, 64, 128, 3, False)])
+def test_tiled_glu_depthwise_kernels_give_the_same_bits(H, B, T, C, K, bf):
+    """The LDS-tiled GLU kernels (wide loads, the GLU applied once per element) run the per-thread-window kernels'
+    arithmetic in the same order: identical results, statistics and parameter-gradient partial sums."""
+    import os
+    g = torch.Generator().manual_seed(T + K + C)
+    x = torch.randn(B * T, 2 * C, generator=g).cuda()
+    dy = torch.randn(B, T, C, generator=g).cuda()
+    if bf:
+        x, dy = x.bfloat16(), dy.bfloat16()
+    w = (0.3 * torch.randn(K, C, generator=g)).cuda()
+    bias = (0.1 * torch.randn(C, generator=g)).cuda()
+    out_dt = torch.bfloat16 if bf else torch.float32
+
+    def run():
+        y, parts = H.dwconv_fwd(x, w, bias, B, T, glu=True, stats=True)
+        dw, db = torch.empty(K, C, device="cuda"), torch.empty(C, device="cuda")
+        dx = H.dwconv_bwd(dy, x, w, dw, db, B, T, glu=True, out_dtype=out_dt)
+        torch.cuda.synchronize()
+        return y, parts.partial, dx, dw, db
+
+    prev = os.environ.get("FS2_DWCONV_TILE")
+    try:
+        os.environ["FS2_DWCONV_TILE"] = "0"
+        ref = run()
+        os.environ["FS2_DWCONV_TILE"] = "1"
+        got = run()
+    finally:
+        if prev is None:
+            os.environ.pop("FS2_DWCONV_TILE", None)
+        else:
+            os.environ["FS2_DWCONV_TILE"] = prev
+    for name, a, b in zip(("y", "stats", "dx", "dw", "db"), ref, got):
+        assert torch.equal(a, b), name
