@@ -163,8 +163,16 @@ __device__ __forceinline__ void ab_load_own(u32x4 (&f)[8], const u16* row, bool 
   }
 }
 
-// the transposed accumulators acc[db][head-dim 32 db + 8 g + 4 h + i] of the lane's row, times `mul`, as bf16
-__device__ __forceinline__ void ab_store_row(u16* row, const f32x16 (&acc)[4], float mul, int hi) {
+// The transposed accumulators acc[db][head-dim 32 db + 8 g + 4 h + i] of the lane's row, times `mul`, as bf16 -- through
+// LDS: a lane holds 4 consecutive head-dim values of ITS row per (db, g), i.e. 8-byte pieces at a
+// row stride -- 32 cache lines touched per store instruction, a quarter of each filled (6 us of the forward kernel's
+// 61 in the phase probe).  The wavefront's 32 rows pass through a private LDS region ([32][128] bf16, rows padded to
+// 272 bytes: 16-byte aligned rows, a two-way conflict on the 8-byte writes) and leave as 16 bytes per lane, 256
+// contiguous bytes per row.  `stage` must no longer be read by anybody (the caller's barrier after the last tile).
+constexpr int AB_STG_ROW = 272, AB_STG_BYTES = 32 * AB_STG_ROW;
+__device__ __forceinline__ void ab_store_rows_staged(char* stage, u16* rows0, long long ld, int nvalid,
+                                                     const f32x16 (&acc)[4], float mul, int lane) {
+  const int l32 = lane & 31, hi = lane >> 5;
 #pragma unroll
   for (int db = 0; db < 4; ++db)
 #pragma unroll
@@ -172,8 +180,15 @@ __device__ __forceinline__ void ab_store_row(u16* row, const f32x16 (&acc)[4], f
       u32x2 v;
       v[0] = pack_bf16x2(acc[db][4 * g] * mul, acc[db][4 * g + 1] * mul);
       v[1] = pack_bf16x2(acc[db][4 * g + 2] * mul, acc[db][4 * g + 3] * mul);
-      *reinterpret_cast<u32x2*>(row + 32 * db + 8 * g + 4 * hi) = v;
+      *reinterpret_cast<u32x2*>(stage + l32 * AB_STG_ROW + (32 * db + 8 * g + 4 * hi) * 2) = v;
     }
+  const int rsub = lane >> 4, chunk = lane & 15;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int r = 4 * it + rsub;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(stage + r * AB_STG_ROW + 16 * chunk);
+    if (r < nvalid) *reinterpret_cast<u32x4*>(rows0 + (long long)r * ld + 8 * chunk) = v;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -292,12 +307,14 @@ __global__ __launch_bounds__(256, 2) void attnb_fwd_kernel(AttnBArgs p, u16* __r
     tile(std::integral_constant<int, 0>{}, j);
     if (j + 1 < nt) tile(std::integral_constant<int, 1>{}, j + 1);
   }
-  if (active && q < T) {
+  __syncthreads();  // nobody reads a tile any more: the stages become the wavefronts' store regions
+  if (active) {
     const float dscale = DROP ? drop.scale : 1.f;
     const float lt = l / dscale;  // the row sums carry the dropout scale, the accumulators do too
     const float inv = lt > 0.f ? 1.f / lt : 0.f;
-    ab_store_row(o + ((long long)b * T + q) * D + h * HD, oacc, inv, hi);
-    if (hi == 0) lse[((long long)b * p.H + h) * T + q] = (m + log2f(lt)) * 0.693147180559945f;
+    const int row0 = qb * 128 + wave * 32;
+    ab_store_rows_staged(smem + wave * AB_STG_BYTES, o + ((long long)b * T + row0) * D + h * HD, D, T - row0, oacc, inv, lane);
+    if (hi == 0 && q < T) lse[((long long)b * p.H + h) * T + q] = (m + log2f(lt)) * 0.693147180559945f;
   }
 }
 
@@ -419,7 +436,12 @@ __global__ __launch_bounds__(256, 2) void attnb_bwd_dq_kernel(AttnBArgs p, const
     tile(std::integral_constant<int, 0>{}, j);
     if (j + 1 < nt) tile(std::integral_constant<int, 1>{}, j + 1);
   }
-  if (active && q < T) ab_store_row(dqkv + ((long long)b * T + q) * ld + h * HD, dq, p.scale, hi);
+  __syncthreads();
+  if (active) {
+    const int row0 = qb * 128 + wave * 32;
+    ab_store_rows_staged(smem + wave * AB_STG_BYTES, dqkv + ((long long)b * T + row0) * ld + h * HD, ld, T - row0, dq, p.scale,
+                         lane);
+  }
 }
 
 // dK / dV.  Workgroup = 4 wavefronts = 4 x 32 keys sharing the Q / dO tiles (64 queries) and their {lse', delta'} pairs.
@@ -553,11 +575,14 @@ __global__ __launch_bounds__(256, 1) void attnb_bwd_dkv_kernel(AttnBArgs p, cons
     tile(std::integral_constant<int, 0>{}, j);
     if (j + 1 < nt) tile(std::integral_constant<int, 1>{}, j + 1);
   }
-  if (key < T) {
-    u16* krow = dqkv + ((long long)b * T + key) * ld + D + h * HD;
+  __syncthreads();
+  const int row0 = kb * 128 + wave * 32;
+  if (row0 < T) {
+    u16* krows = dqkv + ((long long)b * T + row0) * ld + D + h * HD;
     const bool valid = key < len;  // a padded key has no weight in any row: its gradients are zero
-    ab_store_row(krow, dk, valid ? p.scale : 0.f, hi);
-    ab_store_row(krow + D, dv, valid ? 1.f : 0.f, hi);
+    char* stage = smem + TILES + wave * AB_STG_BYTES;
+    ab_store_rows_staged(stage, krows, ld, T - row0, dk, valid ? p.scale : 0.f, lane);
+    ab_store_rows_staged(stage, krows + D, ld, T - row0, dv, valid ? 1.f : 0.f, lane);
   }
 }
 
