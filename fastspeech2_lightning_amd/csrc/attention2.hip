@@ -455,11 +455,10 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(Attn2Args p, float* _
   // offsets -- is then provably wave-uniform; as a plain tid >> 6 the DMA's scalar offset compiled to a waterfall loop)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5, l32 = lane & 31;
   const int rb = wave & 1, kg = wave >> 1, gtid = tid & 127;
-  int qb, b, h;
-  work_unit(p, (p.T + 63) / 64, qb, b, h);
+  int qb, b, h, len;
+  work_unit(p, (p.T + 63) / 64, qb, b, h, len);
   const int T = p.T, D = p.H * HD, ld = 3 * D;
   const int q = qb * 64 + rb * 32 + l32;
-  const int len = p.lens[b];
   const int kend = min(T, len);
   const int nt = (kend + KT - 1) / KT, n0 = (nt + 1) / 2;  // key tiles: group 0 takes [0, n0), group 1 [n0, nt)
   const int tile0 = kg ? n0 : 0, mine = kg ? nt - n0 : n0;
@@ -658,11 +657,10 @@ __global__ __launch_bounds__(256, 1) void attn2_bwd_dq_kernel(Attn2Args p, const
   __shared__ __attribute__((aligned(1024))) float smem[8 * TILE];  // [key group][stage][K | V]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5, l32 = lane & 31;
   const int rb = wave & 1, kg = wave >> 1, gtid = tid & 127;
-  int qb, b, h;
-  work_unit(p, (p.T + 63) / 64, qb, b, h);
+  int qb, b, h, len;
+  work_unit(p, (p.T + 63) / 64, qb, b, h, len);
   const int T = p.T, D = p.H * HD, ld = 3 * D;
   const int q = qb * 64 + rb * 32 + l32;
-  const int len = p.lens[b];
   const int kend = min(T, len);
   const int nt = (kend + KT - 1) / KT, n0 = (nt + 1) / 2;
   const int tile0 = kg ? n0 : 0, mine = kg ? nt - n0 : n0;
@@ -821,11 +819,10 @@ __global__ __launch_bounds__(256, 1) void attn2_bwd_dkv_kernel(Attn2Args p, cons
   __shared__ __attribute__((aligned(1024))) float smem[4 * STAGE];  // [query group][stage][Q | dO | aux (1 KB)]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5, l32 = lane & 31;
   const int rb = wave & 1, qg = wave >> 1, gtid = tid & 127;
-  int kblk, b, h;
-  work_unit(p, (p.T + 63) / 64, kblk, b, h);
+  int kblk, b, h, len;
+  work_unit(p, (p.T + 63) / 64, kblk, b, h, len);
   const int T = p.T, D = p.H * HD, ld = 3 * D;
   const int key = kblk * 64 + rb * 32 + l32;
-  const int len = p.lens[b];
   const float* base = p.qkv + (long long)b * T * ld;
   float* krow = dqkv + ((long long)b * T + key) * ld + D + h * HD;
   float* vrow = krow + D;

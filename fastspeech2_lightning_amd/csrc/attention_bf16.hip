@@ -199,12 +199,11 @@ __global__ __launch_bounds__(256, 2) void attnb_fwd_kernel(AttnBArgs p, u16* __r
   constexpr int HD = AB_HD;
   __shared__ __attribute__((aligned(1024))) char smem[4 * AB_TILE];  // stage s: K at 2 s, V at 2 s + 1 (tiles)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5, l32 = lane & 31;
-  int qb, b, h;
-  work_unit(p, (p.T + 127) / 128, qb, b, h);
+  int qb, b, h, len;
+  work_unit(p, (p.T + 127) / 128, qb, b, h, len);
   const int T = p.T, D = p.H * HD, ld = 3 * D;
   const int q = qb * 128 + wave * 32 + l32;
   const bool active = qb * 128 + wave * 32 < T;  // (wave-uniform) a wavefront without rows still stages tiles and syncs
-  const int len = p.lens[b];
   const int kend = min(T, len);
   const int nt = (kend + AB_KT - 1) / AB_KT;
   const Fs2Drop drop = fs2_resolve_drop(p.drop);
@@ -354,12 +353,11 @@ __global__ __launch_bounds__(256, 2) void attnb_bwd_dq_kernel(AttnBArgs p, const
   constexpr int HD = AB_HD;
   __shared__ __attribute__((aligned(1024))) char smem[4 * AB_TILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5, l32 = lane & 31;
-  int qb, b, h;
-  work_unit(p, (p.T + 127) / 128, qb, b, h);
+  int qb, b, h, len;
+  work_unit(p, (p.T + 127) / 128, qb, b, h, len);
   const int T = p.T, D = p.H * HD, ld = 3 * D;
   const int q = qb * 128 + wave * 32 + l32;
   const bool active = qb * 128 + wave * 32 < T;
-  const int len = p.lens[b];
   const int kend = min(T, len);
   const int nt = (kend + AB_KT - 1) / AB_KT;
   const Fs2Drop drop = fs2_resolve_drop(p.drop);
@@ -457,11 +455,10 @@ __global__ __launch_bounds__(256, 1) void attnb_bwd_dkv_kernel(AttnBArgs p, cons
   constexpr int TILES = 2 * 1024;
   __shared__ __attribute__((aligned(1024))) char smem[TILES + 4 * AB_TILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5, l32 = lane & 31;
-  int kb, b, h;
-  work_unit(p, (p.T + 127) / 128, kb, b, h);
+  int kb, b, h, len;
+  work_unit(p, (p.T + 127) / 128, kb, b, h, len);
   const int T = p.T, D = p.H * HD, ld = 3 * D;
   const int key = kb * 128 + wave * 32 + l32;
-  const int len = p.lens[b];
   const int kend = min(T, len);
   const bool active = kb * 128 + wave * 32 < kend;  // (wave-uniform) some of the wavefront's keys are valid
   const bool any = kb * 128 < kend;                 // (workgroup-uniform)

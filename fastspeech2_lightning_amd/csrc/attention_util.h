@@ -61,8 +61,9 @@ struct PairHash {
 // (w >> 3)-th workgroup of XCD (w & 7); unit number (w >> 3) / nblk * 8 + (w & 7) in order of DEcreasing length goes
 // there -- every XCD gets a long-to-short sequence of units, and the row blocks of a unit still share one XCD's L2.
 // Needs B <= 64 (one lane per utterance ranks them) and B * H a multiple of 8; otherwise plain XCD-contiguous order.
+// Also returns the unit's length lens[b].
 template <class Args>
-__device__ __forceinline__ void work_unit(const Args& p, int nblk, int& blk, int& b, int& h) {
+__device__ __forceinline__ void work_unit(const Args& p, int nblk, int& blk, int& b, int& h, int& len) {
   const int units = p.B * p.H;
   if (p.B <= 64 && (units & 7) == 0) {
     const int w = blockIdx.x, k = w >> 3;
@@ -78,18 +79,21 @@ __device__ __forceinline__ void work_unit(const Args& p, int nblk, int& blk, int
     const unsigned long long hit = __builtin_amdgcn_ballot_w64(lane < p.B && rank == u / p.H);
     b = __builtin_ctzll(hit);
     h = u % p.H;
+    len = __builtin_amdgcn_readlane(mylen, b);  // (already here: no second, dependent load of lens[b])
   } else {
     const int wid = fs2_xcd_remap(blockIdx.x, gridDim.x);
     blk = wid % nblk;
     const int bh = wid / nblk;
     h = bh % p.H;
     b = bh / p.H;
+    len = p.lens[b];
   }
   // (integer division runs on the vector pipe: without this the compiler keeps the quotients -- and every pointer,
   // buffer resource and DMA offset derived from them -- in vector registers and wraps each DMA in a waterfall loop)
   blk = __builtin_amdgcn_readfirstlane(blk);
   b = __builtin_amdgcn_readfirstlane(b);
   h = __builtin_amdgcn_readfirstlane(h);
+  len = __builtin_amdgcn_readfirstlane(len);
 }
 
 }  // namespace
