@@ -39,7 +39,7 @@ def rel_l2(a, b):
 
 CASES = [
     (1, 64, [64]), (2, 33, [33, 7]), (3, 130, [130, 64, 1]), (2, 200, [200, 129]), (2, 648, [648, 500]),
-    (1, 128, [128]), (2, 129, [129, 128]), (2, 95, [31, 95]),
+    (1, 128, [128]), (2, 129, [129, 128]), (2, 95, [31, 95]), (2, 5, [5, 2]), (1, 1, [1]), (4, 31, [31, 1, 16, 17]),
     # benchmark size (more row-block workgroups than slots), ragged lengths, one very short sequence
     (32, 648, [648, 430, 40] + [430 + 7 * i for i in range(29)]),
 ]
@@ -65,10 +65,16 @@ def test_attention_bf16_storage_fwd_bwd(H, B, T, lens):
     dqkv = H.attention_bwd_b(qkv, lens_t, o, dout, lse, B, T, Hh)
     assert torch.isfinite(dqkv.float()).all()
     gref = qr.grad
+    # per part, against the scale of the whole gradient (a single-key softmax has exactly zero dQ and dK; what the
+    # kernels leave there is the bf16 rounding of O in delta)
     parts = (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D)))
-    errs = {n: (rel_l2(dqkv.float()[..., sl], gref[..., sl]),
-                (dqkv.float()[..., sl] - gref[..., sl]).abs().max().item() / gref[..., sl].abs().max().item())
-            for n, sl in parts}
+    gmax, gnorm = gref.abs().max().item(), gref.norm().item()
+    errs = {}
+    for n, sl in parts:
+        d = dqkv.float()[..., sl] - gref[..., sl]
+        ref_norm = max(gref[..., sl].norm().item(), 1e-2 * gnorm)
+        ref_max = max(gref[..., sl].abs().max().item(), 1e-1 * gmax)
+        errs[n] = (d.norm().item() / ref_norm, d.abs().max().item() / ref_max)
     assert all(e[0] < 1.5e-2 and e[1] < 3e-2 for e in errs.values()), errs
     pad = torch.arange(T, device="cuda")[None, :] >= lens_t[:, None]
     assert (dqkv.float()[..., D:][pad] == 0).all(), "padded keys must get zero gradients"

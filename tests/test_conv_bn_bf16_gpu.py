@@ -69,7 +69,8 @@ def test_batchnorm_activation_on_bf16_tensors(H, M, C, act, p):
 
 
 @pytest.mark.parametrize("B,T,C,K,bf", [(2, 648, 256, 9, False), (2, 648, 256, 9, True), (3, 77, 64, 31, False),
-                                       (1, 130, 192, 7, True), (2, 64, 128, 3, False)])
+                                       (1, 130, 192, 7, True), (2, 64, 128, 3, False), (2, 5, 64, 9, True),
+                                       (1, 1, 64, 15, False)])
 def test_tiled_glu_depthwise_kernels_give_the_same_bits(H, B, T, C, K, bf):
     """The LDS-tiled GLU kernels (wide loads, the GLU applied once per element) run the per-thread-window kernels'
     arithmetic in the same order: identical results, statistics and parameter-gradient partial sums."""
