@@ -58,6 +58,8 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         if stale:
             cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", str(INCLUDE),
                    "-I", str(CSRC), "-MD", "-MF", str(dep), "-c", str(src), "-o", str(obj)]
+            if os.environ.get("FS2_BUILD_PROBES"):  # phase-ablation instrumentation (FS2_GEMM_PROBE): timing builds only
+                cmd.insert(1, "-DFS2_PROBES")
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

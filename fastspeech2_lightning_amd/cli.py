@@ -378,6 +378,35 @@ def wait_ranks(procs: list, poll_s: float = 0.2) -> int:
     return max((abs(p.returncode) for p in procs), default=0)
 
 
+def gather_from_ranks(procs: list, queue, n: int, timeout: float = 300.0, poll_s: float = 0.5) -> list:
+    """``n`` results from a queue that ``multiprocessing`` ranks feed, watching the ranks while waiting: a rank that
+    dies (non-zero exit code) fails the wait in seconds -- its siblings, which would sit in a rendezvous or a
+    collective, are terminated -- instead of after the queue's whole timeout (``wait_ranks`` for ``Process`` objects)."""
+    import queue as _queue
+    out, deadline = [], time.time() + timeout
+    while len(out) < n:
+        try:
+            out.append(queue.get(timeout=poll_s))
+            continue
+        except _queue.Empty:
+            pass
+        dead = [(r, p.exitcode) for r, p in enumerate(procs) if p.exitcode not in (None, 0)]
+        # (a rank that exited cleanly has already queued its result; Empty + every rank gone = results lost)
+        gone = not dead and all(p.exitcode is not None for p in procs) and queue.empty()
+        if dead or gone or time.time() > deadline:
+            for p in procs:
+                if p.is_alive():
+                    p.terminate()
+            for p in procs:
+                p.join(10)
+                if p.is_alive():
+                    p.kill()
+            why = (f"rank(s) {dead} exited with an error" if dead else
+                   "every rank exited without a result" if gone else f"no result within {timeout:.0f} s")
+            raise RuntimeError(f"gather_from_ranks: {why} ({len(out)} of {n} results)")
+    return out
+
+
 def train(args, argv) -> int:
     p = plan(args)
     if args.dry_run:

@@ -189,8 +189,13 @@ extern "C" int fs2hip_version(void) { return 1; }
 extern "C" int fs2hip_gemm(const Fs2GemmArgs* args, void* stream) {
   GemmP p;
   p.staged = 0;
+#ifdef FS2_PROBES  // phase-ablation builds only (FS2_BUILD_PROBES=1 python -m fastspeech2_lightning_amd.build --force;
+  // tools/probe_phases_bf16.sh): wrong results, timing only -- never in the shipped library
   static const int env_probe = getenv("FS2_GEMM_PROBE") ? atoi(getenv("FS2_GEMM_PROBE")) : 0;
   p.probe = env_probe;
+#else
+  p.probe = 0;
+#endif
   p.a = *args;
   Fs2GemmArgs& a = p.a;
   if (a.Mc <= 0 || a.Nc <= 0 || a.R <= 0) return FS2HIP_EINVAL;

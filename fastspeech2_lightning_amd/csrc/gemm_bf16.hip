@@ -56,7 +56,9 @@ __global__ __launch_bounds__(256) void gemmb_kernel(GemmP p) {
   setup_pieces_b<BN, BKC, false, TAPS>(pb, p, n0, r_begin, tid);
   st.begin(p, r_begin, r_end, shift_z);
   auto issue = [&](int stage) {
+#ifdef FS2_PROBES
     if (p.probe & 2) return;
+#endif
     char* At = lds + stage * STAGE;
     st.template issue<BM, BN>(p, At, At + A_BYTES, pa, pb, wave, tid);
   };
@@ -76,13 +78,18 @@ __global__ __launch_bounds__(256) void gemmb_kernel(GemmP p) {
     else b_wait_vmcnt_barrier<0>();
     if (kt + NST - 1 < nkt) issue(stage == 0 ? NST - 1 : stage - 1);  // the stage read in iteration kt - 1
     const unsigned sa = lds0 + stage * STAGE, sb = sa + A_BYTES;
-    if (!(p.probe & 1)) compute_ktile_b<BM, BN, AKC, BKC, COLSUM>(acc, cs, rda, rdb, sa, sb, do_cs);
+#ifdef FS2_PROBES
+    if (!(p.probe & 1))
+#endif
+    compute_ktile_b<BM, BN, AKC, BKC, COLSUM>(acc, cs, rda, rdb, sa, sb, do_cs);
     stage = stage + 1 == NST ? 0 : stage + 1;
   }
   // the stages are free once every wavefront has left the last K-tile: each takes a region of them for its stores
   static_assert(4 * Stager<(BN / 2) * 4>::BYTES <= NST * STAGE, "staging regions fit in the ring");
   __builtin_amdgcn_s_barrier();
+#ifdef FS2_PROBES
   if (p.probe & 4) return;
+#endif
   epilogue_dispatch_b<BM, BN, true>(p, acc, m0, n0, wm, wn, lane, split, tapz, lds + wave * Stager<(BN / 2) * 4>::BYTES);
   if (COLSUM && do_cs && wn == 0 && lane < 32) {  // every row of cs[i] is the same sum: take the lane's first register
 #pragma unroll

@@ -357,9 +357,13 @@ def _tile_key(a):
     flags = ((1 if a.bias else 0) | (2 if a.resid else 0) | (4 if a.aux else 0) | (8 if a.out_pre else 0)
              | (16 if (a.ldc % 4 == 0 and (a.C or 0) % 16 == 0) else 0) | (32 if a.drop_p > 0 else 0)
              | (64 if a.counters else 0) | (128 * a.io_bf16) | (512 if a.colsum else 0))
-    # (a cached tile that an exact shape does not admit is dropped again by _launch_gemm)
+    # (a cached tile that an exact shape of the bucket does not admit: that launch alone takes the library's choice,
+    # see _launch_gemm).  The padded length T of a convolution differs from batch to batch like the row counts do: it
+    # is quantised the same way, with the two legality classes of the shifted-operand cores (fp32: T >= 32, bf16
+    # storage: T >= 64) kept apart.
+    tq = (_q(a.T), a.T >= 32, a.T >= 64) if a.taps > 1 else 0
     return (_q(a.Mc), _q(a.Nc), _q(a.R), a.taps, a.a_kcontig, a.b_kcontig, a.shift_operand, a.splitk, a.epi, a.operand_bf16,
-            a.T if a.taps > 1 else 0, flags, _current_device())
+            tq, flags, _current_device())
 
 
 def tile_table() -> dict:
@@ -448,8 +452,9 @@ def _tune_tile(a) -> int:
 def _launch_gemm(a):
     rc = lib().fs2hip_gemm(C.byref(a), _stream())
     if rc == -22 and a.tile != 0:
-        # a cached / replayed tile that this launch's geometry does not admit: forget it and let the library choose
-        _TILE_CACHE.pop(_tile_key(a), None)
+        # a cached / replayed tile that this exact geometry does not admit (the key quantises long extents): the
+        # library chooses for THIS launch; the entry stays -- it is right for the other shapes of its bucket, and
+        # dropping it made two alternating shapes re-run the tuner every step (a refusal costs no launch)
         a.tile = 0
         rc = lib().fs2hip_gemm(C.byref(a), _stream())
     _ok(rc, "gemm")

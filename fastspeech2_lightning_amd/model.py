@@ -282,6 +282,9 @@ class _DeliverGrad(torch.autograd.Function):
             # gradient accumulation without zero_grad(): the previous delivery aliases the buffer the backward pass has
             # just overwritten -- impossible to add to.  training_step() moves it aside before it runs (see there).
             raise RuntimeError("FastSpeech2: the previous step's gradient still aliases the flat gradient buffer")
+        opt = getattr(m, "optimizer", None)
+        if opt is not None:
+            opt.steps_since_delivery = 0
         return g.view(g.shape), None, None
 
 
@@ -365,6 +368,9 @@ class FastSpeech2(_Base):
         self.flat_param = torch.nn.Parameter(S.flat)
         self.bad_count = torch.zeros(1, device=self.device_, dtype=torch.int32)
         self._bad_seen, self._pending_bad, self._in_step = 0, [], False
+        self._trainer_precision_seen = None
+        self.callback_metrics = {}   # (without Lightning: what ``trainer.callback_metrics`` would hold; see ``log_dict``)
+        self._val_acc = {}
         if self.variance_adaptor is not None:
             self.variance_adaptor.bad_count = self.bad_count
         self._reorder_state_dict_keys()
@@ -644,9 +650,19 @@ class FastSpeech2(_Base):
         the flat gradient buffer directly."""
         if not self.training:
             raise RuntimeError("training_step() needs model.train()")
+        self._adopt_trainer_precision()
         p = self.flat_param
         if p.grad is not None and p.grad.untyped_storage().data_ptr() == self.store.grad.untyped_storage().data_ptr():
-            p.grad = p.grad.clone()  # accumulation across steps (no zero_grad in between): keep what was delivered
+            # Lightning calls ``zero_grad`` AFTER ``training_step`` (closure order: training_step -> zero_grad ->
+            # backward), so at this point ``p.grad`` normally still aliases the gradient buffer of the previous step.
+            # If the optimizer has stepped since that gradient was delivered it has been consumed: the stale alias is
+            # dropped (the coming zero_grad would drop it anyway).  Only a gradient that is still waiting for its
+            # optimizer step (accumulation across batches without zero_grad) must survive the backward pass below.
+            opt = getattr(self, "optimizer", None)
+            if opt is not None and getattr(opt, "steps_since_delivery", 0) > 0:
+                p.grad = None
+            else:
+                p.grad = p.grad.clone()
         self._in_step = True
         try:
             output = self(batch)
@@ -655,9 +671,22 @@ class FastSpeech2(_Base):
         finally:
             self._in_step = False
         self.last_losses, self.last_output = losses, output
+        # fs2/model.py:387-389 -- the reference reads every term back with ``.item()`` (6-8 host syncs per step); here
+        # the values stay 0-dim device tensors (views of ONE slot vector): Lightning keeps logged tensors on the device
+        # and reads them at its logging / progress-bar interval, the native loops read the whole vector in one copy
+        # (``losses_to_host``).  No synchronisation is added to the step.
+        self.log_dict({f"training/{k}_loss": v for k, v in losses.items()}, prog_bar=True)
         if torch.is_grad_enabled():
             return _DeliverGrad.apply(p, losses["total"], self)
         return losses["total"]
+
+    def losses_to_host(self, losses=None) -> dict:
+        """Every term of the last ``loss()`` as Python floats with ONE device-to-host copy (the slot vector)."""
+        losses = self.last_losses if losses is None else losses
+        host = self._loss_slots.detach().cpu().tolist()
+        out = {k: host[LOSS_KEYS.index(k)] for k in losses if k != "total"}
+        out["total"] = host[len(LOSS_KEYS)]
+        return out
 
     def check_bad_data(self):
         """fs2/variance_adaptor.py:289-305: raises ``BadDataError`` naming the utterances whose aligner durations did not
@@ -675,15 +704,145 @@ class FastSpeech2(_Base):
         raise BadDataError(f"Something failed with the following items, please check them for errors: {mismatches}")
 
     def validation_step(self, batch, batch_idx=0):
-        """fs2/model.py:515-528 (plots/audio logging are out of scope)."""
+        """fs2/model.py:515-528 (plots/audio logging are out of scope): forward, losses, and the epoch-mean metrics
+        ``validation/{k}_loss`` with ``sync_dist=True`` -- ``validation/total_loss`` is what the reference's
+        ``ModelCheckpoint`` monitors (fs2/cli/train.py:37)."""
+        self._adopt_trainer_precision()
         was = self.training
         self.eval()
         try:
             output = self(batch)
             losses = self.loss(output, self.prepare_batch(batch), self.current_epoch)
+            self.log_dict({f"validation/{k}_loss": v for k, v in losses.items()}, batch_size=self.batch_size,
+                          sync_dist=True)
         finally:
             self.train(was)
         return losses
+
+    # ---- metric logging without Lightning ---------------------------------------------------------------------
+    # ``LightningModule.log_dict`` feeds ``trainer.callback_metrics``, which ``ModelCheckpoint(monitor=...)`` reads.
+    # Lightning is not in the build image, so when ``_Base`` is ``nn.Module`` the same call sites write into
+    # ``self.callback_metrics`` with Lightning's default reductions for these two hooks: the latest value of a training
+    # step (``on_step``), the batch-size-weighted epoch mean of validation steps (``on_epoch``, summed over ranks when
+    # ``sync_dist``).  Values stay device tensors; nothing here synchronises with the host.
+    if _Base is torch.nn.Module:
+        def log_dict(self, dictionary, prog_bar=False, batch_size=None, sync_dist=False, **kwargs):
+            if self.training:
+                for k, v in dictionary.items():
+                    self.callback_metrics[k] = v.detach() if torch.is_tensor(v) else v
+                return
+            w = float(batch_size or 1)
+            for k, v in dictionary.items():
+                v = v.detach().float() if torch.is_tensor(v) else torch.tensor(float(v), device=self.device_)
+                acc = self._val_acc.get(k)
+                if acc is None:
+                    self._val_acc[k] = [v * w, w, bool(sync_dist)]
+                else:
+                    acc[0] = acc[0] + v * w
+                    acc[1] += w
+
+        def on_validation_epoch_end(self):
+            """Closes the validation epoch of ``log_dict``: means into ``callback_metrics`` (one all-reduce of the
+            stacked sums and the weight under ``sync_dist`` when a process group is up)."""
+            import torch.distributed as dist
+            acc, self._val_acc = self._val_acc, {}
+            if not acc:
+                return
+            keys = list(acc)
+            stat = torch.stack([acc[k][0] for k in keys] + [torch.tensor(acc[keys[0]][1], device=self.device_)])
+            if any(a[2] for a in acc.values()) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                dist.all_reduce(stat)
+            mean = stat[:-1] / stat[-1]
+            for i, k in enumerate(keys):
+                self.callback_metrics[k] = mean[i]
+
+    def on_train_batch_end(self, outputs=None, batch=None, batch_idx=0):
+        """Lightning's per-step hook: the reference raises ``BadDataError`` inside the step's forward
+        (fs2/variance_adaptor.py:289-305); here the check is one 4-byte read after the step has been enqueued (only
+        models that learn the alignment ever queue anything to check)."""
+        if self._pending_bad:
+            self.check_bad_data()
+
+    def _adopt_trainer_precision(self):
+        """``Trainer(precision=...)`` reaches a LightningModule as ``self.trainer.precision`` ("32-true", "bf16-mixed",
+        ...), not as a constructor argument: take it from there when a trainer is attached (fs2/cli/train.py:33-41
+        passes the precision to the Trainer).  A precision this path has no arithmetic for is refused."""
+        try:
+            trainer = self.trainer
+        except Exception:  # LightningModule.trainer raises while detached
+            trainer = None
+        prec = getattr(trainer, "precision", None)
+        if prec is None or str(prec) == self._trainer_precision_seen:
+            return
+        key = str(prec)
+        if key not in H.PRECISIONS:
+            raise ValueError(f"Trainer(precision={prec!r}): this path runs \"32-true\" and \"bf16-mixed\" "
+                             f"(and \"32-split\"); other precisions have no kernels here")
+        self._trainer_precision_seen = key
+        H.set_precision(key)
+        self.precision = H.get_precision()
+
+    def setup(self, stage=None):
+        self._adopt_trainer_precision()
+
+    def on_fit_start(self):
+        self._adopt_trainer_precision()
+
+    def _apply(self, fn, recurse=True):
+        """``nn.Module._apply`` is what ``model.to(...)``, ``.half()``, ``.bfloat16()``, ``.cuda(i)`` and Lightning's
+        strategy / precision plugins go through.  It would replace ``flat_param.data`` with a converted COPY and so
+        cut the alias with ``store.flat`` that the kernels read and the optimizer writes -- silently.  A dtype change
+        is refused (reduced-precision arithmetic is ``precision="bf16-mixed"``, the master weights stay fp32); a move
+        to another GPU re-homes every buffer of the model; a no-op cast is a no-op."""
+        cur = self.store.flat
+        probe = fn(torch.empty(0, dtype=cur.dtype, device=cur.device))
+        if probe.dtype != cur.dtype:
+            raise RuntimeError(f"FastSpeech2 (MI355X build): cannot cast the module to {probe.dtype} -- the flat fp32 "
+                               "parameter buffer is what the kernels and the fused optimizer address; use "
+                               "precision=\"bf16-mixed\" (Trainer(precision=...)) for bf16 arithmetic")
+        if probe.device != cur.device:
+            if probe.device.type != "cuda":
+                raise RuntimeError(f"FastSpeech2 (MI355X build): cannot move the module to {probe.device}: there is "
+                                   "no CPU path")
+            self.move_to(probe.device)
+        return self
+
+    def move_to(self, device, force=False):
+        """Re-homes the model on another GPU (parameters, gradient, moments, buffers, device records), keeping the
+        ``flat_param`` / ``store.flat`` alias.  Optimizers built before the move must be rebuilt
+        (``configure_optimizers``): Lightning moves the module before it sets the optimizers up."""
+        device = torch.device(device)
+        if device == self.device_ and not force:
+            return self
+        S = self.store
+        with torch.no_grad():
+            for name in ("flat", "grad", "adam_m", "adam_v"):
+                setattr(S, name, getattr(S, name).to(device, copy=True))
+            counters = S.bn_counters.to(device, copy=True)
+            names = [n for n in S.buffers if n.endswith("num_batches_tracked")]
+            for n in list(S.buffers):
+                if n not in names:
+                    S.buffers[n] = S.buffers[n].to(device, copy=True)
+            for i, n in enumerate(names):
+                S.buffers[n] = counters[i]
+            S.bn_counters = counters
+            S.device = device
+            S._pviews, S._gviews, S._bviews, S.flat_bf16 = {}, {}, {}, None
+            self.step_state = self.step_state.to(device, copy=True)
+            self.env.step_state = self.step_state
+            if getattr(self.env, "_side_stream", None) is not None:
+                self.env.join()
+                self.env._side_stream = None
+            self.bad_count = self.bad_count.to(device, copy=True)
+            if self.variance_adaptor is not None:
+                self.variance_adaptor.bad_count = self.bad_count
+            self.flat_param.data = S.flat
+            self.flat_param.grad = None
+        self.device_ = device
+        self._tables, self._ctx, self._loss_grads, self._loss_slots = {}, None, None, None
+        if getattr(self, "optimizer", None) is not None:
+            self.optimizer = None  # held the old device record
+        return self
 
     def predict_step(self, batch, batch_idx=0):
         was = self.training

@@ -734,7 +734,7 @@ class PostNet:
     DROPOUT = 0.5  # hard-coded in the reference (fs2/layers.py:207-209)
 
     def __init__(self, S, env: Env, prefix, n_mel, dim=512, k=5, n=5):
-        self.S, self.env, self.k, self.n = S, env, k, n
+        self.S, self.env, self.k, self.n, self.n_mel = S, env, k, n, n_mel
         self.dropout_p = self.DROPOUT
         chans = [n_mel] + [dim] * (n - 1) + [n_mel]
         self.convs = []
@@ -752,7 +752,10 @@ class PostNet:
         (80 mel bins: not whole 64-deep K-tiles per tap) stays on the fp32-operand core."""
         S, env = self.S, self.env
         B, T, _ = x.shape
-        stored = env.stored and T >= 64
+        # (the first layer's weight gradient reads the mel input cast to bf16 (K = n_mel), the last layer's reads a bf16
+        # output gradient with N = n_mel rows: both need n_mel % 8 == 0 -- 100 mel bands run with fp32-stored operands
+        # rounded in registers, like every GEMM outside the operand-storage mode)
+        stored = env.stored and T >= 64 and self.n_mel % 8 == 0
         saved = []
         for i, (w, b, bn, site) in enumerate(self.convs):
             if x.dtype == torch.bfloat16:

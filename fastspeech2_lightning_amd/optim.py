@@ -46,6 +46,9 @@ class FusedAdamWNoam(torch.optim.Optimizer):
         self.warmup_steps = int(warmup_steps)
         self.max_grad_norm = max_grad_norm
         self.grad_scale = 1.0  # 1/world_size under data parallelism (gradients are summed by the all-reduce)
+        #: optimizer steps since autograd last delivered a gradient (model._DeliverGrad resets it): a ``param.grad`` that
+        #: still aliases the flat gradient buffer has been consumed when this is > 0 (FastSpeech2.training_step)
+        self.steps_since_delivery = 0
         defaults = dict(lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.weight_decay, amsgrad=False,
                         maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
                         decoupled_weight_decay=True)
@@ -68,6 +71,7 @@ class FusedAdamWNoam(torch.optim.Optimizer):
             H.grad_clip_coef(g, float(self.max_grad_norm or 0.0), self.grad_scale, self.step_state)
             H.adamw_step(S.flat, g, S.adam_m, S.adam_v, self.step_state, self.betas[0], self.betas[1], self.eps,
                          self.weight_decay)
+        self.steps_since_delivery += 1
         return loss
 
     def zero_grad(self, set_to_none: bool = True):

@@ -69,7 +69,8 @@ def test_bucketed_exchange_world2_on_one_gpu(variant):
     procs = [ctx.Process(target=_rank, args=(r, 2, port, q, variant)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=300) for _ in procs]
+    from fastspeech2_lightning_amd.cli import gather_from_ranks
+    res = gather_from_ranks(procs, q, len(procs), timeout=300)  # a rank that raises fails the test in seconds
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
@@ -120,7 +121,8 @@ def test_rccl_call_path_with_one_rank():
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_single, args=(port, q))
     p.start()
-    err = q.get(timeout=300)
+    from fastspeech2_lightning_amd.cli import gather_from_ranks
+    err = gather_from_ranks([p], q, 1, timeout=300)[0]
     p.join(120)
     assert p.exitcode == 0
     assert err < 1e-6, err

@@ -53,13 +53,22 @@ def automatic_optimization(model, batch, n, clip="hook", accumulate=1):
     losses, lrs = [], []
     for i in range(n):
         def closure():
-            opt.zero_grad()
+            # Lightning's closure order: training_step -> zero_grad (first micro-batch of an accumulation window
+            # only) -> backward.  ``param.grad`` therefore still aliases the previous step's gradient buffer when
+            # training_step is entered.
             total = 0.0
-            for _ in range(accumulate):
+            for j in range(accumulate):
                 loss = model.training_step(batch, i)
                 assert loss.requires_grad and loss.grad_fn is not None and loss.dim() == 0
+                if j == 0:
+                    opt.zero_grad()
                 (loss / accumulate if accumulate > 1 else loss).backward()
+                model.on_train_batch_end(loss, batch, i)
                 total += float(loss.detach())
+                logged = model.callback_metrics  # fs2/model.py:387-389: training/{k}_loss every step
+                assert float(logged["training/total_loss"]) == pytest.approx(float(loss.detach()), rel=1e-6)
+                assert {"training/spec_loss", "training/postnet_loss", "training/duration_loss", "training/pitch_loss",
+                        "training/energy_loss"} <= set(logged)
             if clip == "hook":      # LightningModule.configure_gradient_clipping(optimizer, gradient_clip_val, algorithm)
                 model.configure_gradient_clipping(opt, 1.0, "norm")
             else:                   # what the default hook does: clip_grad_norm_ over the optimizer's parameters
@@ -159,9 +168,9 @@ def test_cost_of_the_autograd_hand_over():
         opt.step()
 
     def automatic():
-        def closure():
-            opt.zero_grad()
+        def closure():  # Lightning's order: the stale alias of the last step's gradient is dropped, not cloned
             loss = model.training_step(batch)
+            opt.zero_grad()
             loss.backward()
             model.configure_gradient_clipping(opt, 1.0, "norm")
             return loss
@@ -184,3 +193,65 @@ def test_cost_of_the_autograd_hand_over():
     a, b = sorted(a)[2], sorted(b)[2]
     print(f"\nnative {a * 1e3:.3f} ms/step, automatic optimization {b * 1e3:.3f} ms/step (+{(b / a - 1) * 100:.2f} %)")
     assert b <= 1.02 * a + 1e-4, (a, b)
+
+
+def test_monitored_validation_metric_and_trainer_precision():
+    """The reference's call site (fs2/cli/train.py:33-41): ``ModelCheckpoint(monitor="validation/total_loss")`` reads
+    ``trainer.callback_metrics`` after a validation pass; ``validation_step`` must have logged it (fs2/model.py:524-528,
+    ``sync_dist=True``) as the epoch mean -- the value ``data.validate`` computes.  ``Trainer(precision=...)`` reaches
+    the module through ``self.trainer.precision``."""
+    from types import SimpleNamespace
+    from fastspeech2_lightning_amd import data as D
+    model, batch = _model()
+    batch2 = O.synthetic_batch(B=3, ts_lo=5, ts_hi=9, n_symbols=C.N_SYMBOLS,
+                               n_mels=model.config.preprocessing.audio.n_mels, seed=5, dur_hi=3)
+    want = D.validate(model, [batch, batch2])
+    model._val_acc = {}
+    model.callback_metrics.clear()
+    for i, b in enumerate((batch, batch2)):   # Lightning's validation loop
+        model.validation_step(b, i)
+    model.on_validation_epoch_end()
+    monitor = "validation/total_loss"         # ModelCheckpoint(monitor=...) looks it up in callback_metrics
+    assert monitor in model.callback_metrics
+    for k, v in want.items():
+        assert float(model.callback_metrics[k]) == pytest.approx(v, rel=1e-6), k
+    # Trainer(precision="bf16-mixed") -> module.trainer.precision -> the kernels' precision, without a constructor kwarg
+    assert model.precision == "32-true"
+    model.trainer = SimpleNamespace(precision="bf16-mixed")
+    model.setup("fit")
+    assert model.precision == "bf16-mixed"
+    loss_b = float(model.training_step(batch).detach())
+    model.trainer = SimpleNamespace(precision="32-true")
+    model.on_fit_start()
+    assert model.precision == "32-true"
+    loss_f = float(model.training_step(batch).detach())
+    assert loss_b != loss_f and abs(loss_b - loss_f) < 2e-2 * abs(loss_f)
+    model.trainer = SimpleNamespace(precision="16-mixed")
+    with pytest.raises(ValueError):
+        model.setup("fit")
+
+
+def test_module_casts_keep_or_refuse_the_flat_parameter_alias():
+    """``nn.Module._apply`` (``.half()``, ``.to(dtype)``, Lightning's precision plugins) would replace ``flat_param``
+    with a converted copy and cut its alias with ``store.flat``: dtype casts raise, same-device moves are no-ops, and
+    a re-homing (forced here onto the same GPU: the box has one) keeps alias, weights and training intact."""
+    ref_model, ref_losses = native_steps(3)
+    model, batch = _model()
+    for cast in (lambda m: m.half(), lambda m: m.bfloat16(), lambda m: m.to(torch.float64), lambda m: m.cpu()):
+        with pytest.raises(RuntimeError):
+            cast(model)
+    assert model.to("cuda") is model and model.cuda() is model and model.float() is model
+    assert model.flat_param.data_ptr() == model.store.flat.data_ptr()
+    old_ptr = model.store.flat.data_ptr()
+    model.move_to(model.device_, force=True)
+    assert model.store.flat.data_ptr() != old_ptr
+    assert model.flat_param.data_ptr() == model.store.flat.data_ptr()
+    opt = model.configure_optimizers()[0][0]
+    model.configure_gradient_clipping(opt, 1.0, "norm")
+    losses = []
+    for _ in range(3):
+        with torch.no_grad():
+            losses.append(float(model.training_step(batch)))
+        opt.step()
+    assert losses == pytest.approx(ref_losses, rel=1e-6)
+    assert float((model.store.flat - ref_model.store.flat).abs().max()) <= 1e-6 * float(ref_model.store.flat.abs().max())

@@ -259,6 +259,35 @@ def test_bf16_mixed_train_step_within_the_reference_autocast_error():
     assert rel(o32["postnet_output"].detach().cpu().numpy(), ref["postnet_output"].detach().numpy()) < 1e-4
 
 
+def test_bf16_mixed_with_mel_bands_that_are_not_a_multiple_of_8():
+    """n_mels = 100 (a multiple of 4, not of 8) in ``bf16-mixed`` with T >= 64 -- the PostNet's first and
+    last layers cannot take the bf16 operand-storage weight gradient (K = n_mels / N = n_mels must be multiples of
+    8); the PostNet then keeps fp32-stored operands.  Forward AND backward must run and agree with the fp32 oracle
+    at the bf16 tolerances."""
+    from fastspeech2_lightning_amd.model import FastSpeech2
+    config = C.small_config(learn_alignment=False, n_mels=100)
+    batch = O.synthetic_batch(B=2, ts_lo=20, ts_hi=30, n_symbols=C.N_SYMBOLS, n_mels=100, seed=9, dur_hi=5)
+    assert int(batch["max_mel_len"]) >= 64
+    oracle = O.FastSpeech2Oracle(config, Stats(**C.STATS), n_symbols=C.N_SYMBOLS)
+    sd = O.seeded_state_dict(oracle.state_dict())
+    oracle.load_state_dict(sd)
+    oracle.train()
+    oracle.postnet.dropout_p = 0.0
+    ref = oracle(batch)
+    ref_losses = oracle.loss(ref, batch, 0)
+    ref_losses["total"].backward()
+    model = FastSpeech2(config, Stats(**C.STATS), precision="bf16-mixed")
+    model.load_state_dict(sd)
+    model.train()
+    model.postnet.dropout_p = 0.0
+    total = model.training_step(batch)   # raised ValueError in the first backward before the gate
+    assert abs(float(total) - float(ref_losses["total"])) < 1e-2 * abs(float(ref_losses["total"]))
+    got = model.store.grad_state_dict()
+    num = sum(float((got[k].cpu() - p.grad).pow(2).sum()) for k, p in oracle.named_parameters() if p.grad is not None)
+    den = sum(float(p.grad.pow(2).sum()) for k, p in oracle.named_parameters() if p.grad is not None)
+    assert (num / den) ** 0.5 < 0.1, (num / den) ** 0.5
+
+
 @pytest.mark.parametrize("learn_alignment", [False, True])
 def test_five_optimizer_steps_track_the_oracle(learn_alignment):
     """The whole train step repeated: forward + losses + backward + gradient-norm clip (1.0) + AdamW under the Noam

@@ -198,3 +198,40 @@ def test_a_failing_rank_stops_the_others():
     assert all(p.poll() is not None for p in procs)
     ok = [subprocess.Popen([sys.executable, "-c", "pass"]) for _ in range(2)]
     assert wait_ranks(ok) == 0
+
+
+def _dies(rank, q):
+    import time
+    if rank == 1:
+        raise ValueError("rank 1 fails at start")
+    time.sleep(60)
+    q.put(rank)
+
+
+def _answers(rank, q):
+    q.put(rank)
+
+
+def test_gather_from_ranks_fails_in_seconds_when_a_rank_dies():
+    """a multiprocessing rank that raises must fail its parent's wait at once (the GPU test
+    harness sat in ``q.get(timeout=300)``), and its sibling must not be left behind."""
+    import time
+    import torch.multiprocessing as mp
+    from fastspeech2_lightning_amd.cli import gather_from_ranks
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dies, args=(r, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    t0 = time.time()
+    with pytest.raises(RuntimeError, match="exited with an error"):
+        gather_from_ranks(procs, q, 2, timeout=120)
+    assert time.time() - t0 < 45
+    assert all(not p.is_alive() for p in procs)
+    q2 = ctx.Queue()
+    ok = [ctx.Process(target=_answers, args=(r, q2)) for r in range(2)]
+    for p in ok:
+        p.start()
+    assert sorted(gather_from_ranks(ok, q2, 2, timeout=120)) == [0, 1]
+    for p in ok:
+        p.join(30)
