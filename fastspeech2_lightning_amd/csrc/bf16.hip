@@ -38,7 +38,48 @@ __global__ __launch_bounds__(256) void transpose_cast_bf16_kernel(const float* _
   }
 }
 
+// several matrices in one launch (the transposed bf16 mirrors of the K = 256 data-gradient weights, once per step)
+struct TransposeJobs {
+  Fs2TransposeJob j[FS2_TRANSPOSE_MAX_JOBS];
+};
+__global__ __launch_bounds__(256) void transpose_cast_bf16_multi_kernel(TransposeJobs jobs) {
+  __shared__ float tile[64][65];
+  const Fs2TransposeJob& jb = jobs.j[blockIdx.y];
+  const int tc = (jb.cols + 63) / 64, tr = (jb.rows + 63) / 64;
+  if ((int)blockIdx.x >= tc * tr) return;  // uniform per workgroup
+  const int r0 = ((int)blockIdx.x / tc) * 64, c0 = ((int)blockIdx.x % tc) * 64;
+  const float* __restrict__ src = jb.src;
+  __bf16* __restrict__ dst = (__bf16*)jb.dst;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < jb.rows && c < jb.cols) ? src[(long long)r * jb.cols + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < jb.cols && r < jb.rows) dst[(long long)c * jb.rows + r] = (__bf16)tile[tx][i];
+  }
+}
+
 }  // namespace
+
+extern "C" int fs2hip_transpose_cast_bf16_multi(const Fs2TransposeJob* jobs, int njobs, void* stream) {
+  if (njobs <= 0) return 0;
+  if (!jobs || njobs > FS2_TRANSPOSE_MAX_JOBS) return FS2HIP_EINVAL;
+  TransposeJobs arg;
+  int tmax = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const Fs2TransposeJob& j = jobs[i];
+    if (!j.src || !j.dst || j.rows <= 0 || j.cols <= 0) return FS2HIP_EINVAL;
+    arg.j[i] = j;
+    const int t = ((j.rows + 63) / 64) * ((j.cols + 63) / 64);
+    tmax = t > tmax ? t : tmax;
+  }
+  transpose_cast_bf16_multi_kernel<<<dim3(tmax, njobs), dim3(256), 0, (hipStream_t)stream>>>(arg);
+  FS2_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int fs2hip_cast_bf16(const float* src, void* dst, long long n, void* stream) {
   if (n <= 0 || (n % 8) || ((uintptr_t)src % 16) || ((uintptr_t)dst % 16)) return FS2HIP_EINVAL;

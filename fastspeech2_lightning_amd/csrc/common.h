@@ -70,6 +70,28 @@ __device__ __forceinline__ float fs2_drop_factor(const Fs2Drop& d, unsigned long
   return ((idx & 1) ? (h >> 16) : (h & 0xffffu)) < d.thresh ? 0.f : d.scale;
 }
 
+// The same factors for FOUR consecutive elements idx .. idx + 3 with idx EVEN: the quad is two whole pairs, so two hashes
+// serve it (written element by element the compiler cannot know that idx is even and hashes four times; the two
+// integer multiplies of a hash are quarter-rate instructions, and the SiLU / dropout epilogues of the feed-forward
+// GEMMs are bound by exactly this arithmetic).  idx < 2^32 (every tensor here is below 2 GiB).
+__device__ __forceinline__ uint32_t fs2_hash32_lo(unsigned long long seed, uint32_t idx) {  // = fs2_hash32(seed, idx)
+  uint32_t x = idx ^ (uint32_t)seed;
+  x ^= x >> 16;
+  x *= 0x7feb352du;
+  x ^= (uint32_t)(seed >> 32);
+  x ^= x >> 15;
+  x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ void fs2_drop_quad(const Fs2Drop& d, uint32_t idx, float (&f)[4]) {
+  const uint32_t h0 = fs2_hash32_lo(d.seed, idx >> 1), h1 = fs2_hash32_lo(d.seed, (idx >> 1) + 1u);
+  f[0] = (h0 & 0xffffu) < d.thresh ? 0.f : d.scale;
+  f[1] = (h0 >> 16) < d.thresh ? 0.f : d.scale;
+  f[2] = (h1 & 0xffffu) < d.thresh ? 0.f : d.scale;
+  f[3] = (h1 >> 16) < d.thresh ? 0.f : d.scale;
+}
+
 // ---- activations ------------------------------------------------------------------------
 // v_exp_f32 + v_rcp_f32 (about 1 ulp each): the epilogues that call this run once per output element
 __device__ __forceinline__ float fs2_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }

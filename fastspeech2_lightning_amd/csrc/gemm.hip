@@ -245,6 +245,7 @@ extern "C" int fs2hip_gemm(const Fs2GemmArgs* args, void* stream) {
     const int nzb = (a.shift_operand == 1 ? a.taps : 1) * a.splitk;
     int tb = a.tile;
     if (tb == 0) tb = (long long)((a.Mc + 127) / 128) * ((a.Nc + 127) / 128) * nzb >= 256 ? 20 : 23;
+    if (tb >= 30) return nzb == 1 ? fs2_gemmws_launch(p, tb, (hipStream_t)stream) : FS2HIP_EINVAL;
     return fs2_gemmb_launch(p, tb, nzb, (hipStream_t)stream);
   }
   // vector-load preconditions: the contiguous dimension of every operand is a multiple of 4

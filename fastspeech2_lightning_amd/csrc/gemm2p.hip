@@ -186,8 +186,15 @@ __global__ __launch_bounds__(256) void tail_fixup_epi_kernel(GemmP p, Hybrid hy)
       v[0] *= fs2_dact(a.act, x.x); v[1] *= fs2_dact(a.act, x.y); v[2] *= fs2_dact(a.act, x.z); v[3] *= fs2_dact(a.act, x.w);
     }
     if (a.epi > 0 && drop.on) {
+      if ((a.ldc & 1) == 0) {  // n is a multiple of 4: two whole hash pairs
+        float f[4];
+        fs2_drop_quad(drop, (unsigned)(m * a.ldc + n), f);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] *= fs2_drop_factor(drop, (unsigned long long)(unsigned)(m * a.ldc + n + e));
+        for (int e = 0; e < 4; ++e) v[e] *= f[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= fs2_drop_factor(drop, (unsigned long long)(unsigned)(m * a.ldc + n + e));
+      }
     }
     if (a.epi == FS2_EPI_RESID) {
       const float4 x = *reinterpret_cast<const float4*>(a.resid + (long long)m * a.ldr + n);

@@ -371,9 +371,16 @@ __device__ __forceinline__ void epilogue_b(const GemmP& p, const f32x16 (&acc)[B
           for (int e = 0; e < 4; ++e) v[e] *= dact_b<ACT>(a.act, x[e]);
         }
         if (EPI > 0 && drop.on) {  // element index m * ldc + n, as everywhere else this mask is used
-          const unsigned long long idx = (unsigned long long)(unsigned)(m * ldc + n);
+          const unsigned idx = (unsigned)(m * ldc + n);
+          if ((ldc & 1) == 0) {  // n is a multiple of 4: the quad is two whole hash pairs
+            float f[4];
+            fs2_drop_quad(drop, idx, f);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] *= fs2_drop_factor(drop, idx + e);
+            for (int e = 0; e < 4; ++e) v[e] *= f[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= fs2_drop_factor(drop, (unsigned long long)idx + e);
+          }
         }
         if (EPI == FS2_EPI_RESID) {
           const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.resid, 0, a.Mc * a.ldr * 4, 0x00020000);
@@ -502,9 +509,16 @@ __device__ __forceinline__ void epilogue_staged_b(const GemmP& p, const f32x16 (
           for (int e = 0; e < 4; ++e) q[e] *= dact_b<ACT>(a.act, x[e]);
         }
         if (EPI > 0 && drop.on) {
-          const unsigned long long idx = (unsigned long long)(unsigned)(m * ldc + n);
+          const unsigned idx = (unsigned)(m * ldc + n);
+          if ((ldc & 1) == 0) {  // n is a multiple of 4: the quad is two whole hash pairs
+            float f[4];
+            fs2_drop_quad(drop, idx, f);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) q[e] *= fs2_drop_factor(drop, idx + e);
+            for (int e = 0; e < 4; ++e) q[e] *= f[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q[e] *= fs2_drop_factor(drop, (unsigned long long)idx + e);
+          }
         }
         if (EPI == FS2_EPI_RESID) {
           const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.resid, 0, a.Mc * a.ldr * 4, 0x00020000);

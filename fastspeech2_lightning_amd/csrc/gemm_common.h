@@ -107,9 +107,29 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmP& p, const f32x16 
         }
       }
       if (EPI > 0 && drop.on) {  // element index m * ldc + n, as everywhere else this mask is used
+        if ((ldc & 1) == 0) {
+          // One hash serves a pair of neighbouring elements and in this layout the pair sits in neighbouring LANES
+          // (same register), so written per element both lanes compute the same hash.  With ldc even the lane's
+          // parity is the element's: for registers r, r + 1 (rows one apart) the even lane hashes the pair of row r,
+          // the odd lane the pair of row r + 1, and they swap (DPP quad_perm [1, 0, 3, 2]): one hash per lane for
+          // two elements -- the hash is most of the vector work of these epilogues, and fp32 vector work comes
+          // straight out of the fp32 MFMAs' budget.
+          const int par = lane & 1;
+          const unsigned he = (unsigned)((mrow * ldc + n) + par * ldc);  // the lane's hashed element of register 0, block 0
+          const unsigned sh = par << 4;
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          v[r] *= fs2_drop_factor(drop, (unsigned long long)((unsigned)(vc + FS2_ROWOFF(i, r) * ldc * 4) >> 2));
+          for (int r = 0; r < 16; r += 2) {
+            const uint32_t H = fs2_hash32_lo(drop.seed, (he + (unsigned)(FS2_ROWOFF(i, r) * ldc)) >> 1);
+            const uint32_t Hn = (uint32_t)__builtin_amdgcn_mov_dpp((int)H, 0xB1, 0xF, 0xF, true);
+            const uint32_t ha = par ? Hn : H, hb = par ? H : Hn;  // the pair of row r / of row r + 1
+            v[r] *= ((ha >> sh) & 0xffffu) < drop.thresh ? 0.f : drop.scale;
+            v[r + 1] *= ((hb >> sh) & 0xffffu) < drop.thresh ? 0.f : drop.scale;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            v[r] *= fs2_drop_factor(drop, (unsigned long long)((unsigned)(vc + FS2_ROWOFF(i, r) * ldc * 4) >> 2));
+        }
       }
       if (EPI == FS2_EPI_RESID) {
         const __amdgpu_buffer_rsrc_t rx = fs2_epi_rsrc(a.resid, a.Mc, a.ldr);
@@ -240,6 +260,9 @@ int fs2_gemm2p_launch(GemmP& p, int tile, int nz, hipStream_t s);
 // bf16-storage core (gemm_bf16.hip / gemm_bf16p.hip); tile: 20 = 128x128, 22 = 128x64, 23 = 64x64, 24 / 25 = persistent
 // 128x128 / 128x64
 int fs2_gemmb_launch(GemmP& p, int tile, int nz, hipStream_t s);
+// weights-stationary streaming form of the bf16-storage core (gemm_ws.hip): forward orientation, K = 256; tile 30 / 31 =
+// 512 / 256 output columns per workgroup
+int fs2_gemmws_launch(GemmP& p, int tile, hipStream_t s);
 // finishes the reduction-split tail tiles of a persistent launch (reduce.hip)
 int fs2_tail_fixup(const float* ws, int S, long long slab, float* C, int ldc, const float* bias, float alpha, int m0,
                    int Mc, int Nc, hipStream_t s);

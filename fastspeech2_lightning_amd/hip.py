@@ -102,6 +102,7 @@ SIGNATURES = {
     "fs2hip_axpby": "pppqfffQpp",
     "fs2hip_cast_bf16": "ppqp",
     "fs2hip_transpose_cast_bf16": "piiipiip",
+    "fs2hip_transpose_cast_bf16_multi": None,  # (const Fs2TransposeJob*, int, void*): set below
     "fs2hip_add_rowvec": "pppiiip",
     "fs2hip_scale_dev": "pqpp",
     "fs2hip_dact_mul": "pppqip",
@@ -148,6 +149,7 @@ def lib():
         L.fs2hip_gemm.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
         L.fs2hip_reduce_rows_multi.argtypes = [C.POINTER(ReduceJob), C.c_int, C.c_void_p]
         L.fs2hip_reduce_slabs_multi.argtypes = [C.POINTER(SlabJob), C.c_int, C.c_void_p]
+        L.fs2hip_transpose_cast_bf16_multi.argtypes = [C.POINTER(TransposeJob), C.c_int, C.c_void_p]
         _lib = L
     return _lib
 
@@ -293,8 +295,9 @@ def get_precision() -> str:
     return {0: "32-true", 1: "bf16-mixed", 2: "32-split"}[int(GEMM_BF16)]
 
 
-GEMM_TILES_B = (20, 21, 22, 23, 24, 25, 26)  # bf16-storage core (operand_bf16 == 4): 128x128, 128x64, 64x64;
-#                                      24 / 25: persistent 128x128 / 128x64
+GEMM_TILES_B = (20, 21, 22, 23, 24, 25, 26, 30, 31)  # bf16-storage core (operand_bf16 == 4): 128x128, 128x64, 64x64;
+#                                      24 / 25: persistent 128x128 / 128x64; 30 / 31: weights-stationary streaming form
+#                                      (K = 256, forward orientation: csrc/gemm_ws.hip), 512 / 256 columns per workgroup
 GEMM_TILES = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)  # 1-3: register-staged BK=16 core; 4-9: direct-to-LDS BK=32 core;
 #                                                      10-12: persistent direct-to-LDS core; 13-15: + split tail
 _TILE_CACHE = {}
@@ -533,10 +536,14 @@ def linear_fwd(x, w, bias=None, *, epi=EPI_STORE, act=None, resid=None, res_scal
 
 
 def linear_bwd_data(dy, w, *, epi=EPI_STORE, act=None, aux=None, alpha=1.0, drop: Drop = NO_DROP,
-                    taps=1, T=0, out=None, out_dtype=torch.float32):
+                    taps=1, T=0, out=None, out_dtype=torch.float32, wt=None):
     """dx[M, K] = epi(alpha * dy[M, N] @ w) with w [N, K] (or [taps, N, Kper], transposed conv).
     bf16 ``dy`` and ``w`` (operand storage): the weight is read as it is stored (reduction-major operand of the
-    bf16 core); ``aux`` may be fp32 or bf16, the result is ``out_dtype``."""
+    bf16 core); ``aux`` may be fp32 or bf16, the result is ``out_dtype``.
+    ``wt`` (bf16 [K, N] = w transposed, from ``ParamStore.pbt``): the product runs in the forward orientation -- both
+    operands k-contiguous -- which the weights-stationary streaming kernel takes for N = 256 (csrc/gemm_ws.hip)."""
+    if wt is not None and dy.dtype == torch.bfloat16 and taps == 1:
+        return _bwd_data_transposed(dy, wt, epi, act, aux, alpha, drop, out, out_dtype)
     stored = dy.dtype == torch.bfloat16
     _chk(dy, dy.dtype if stored else torch.float32, "dy"); _chk(w, dy.dtype if stored else torch.float32, "w")
     _req(stored or out_dtype == torch.float32, "linear_bwd_data: bf16 results need bf16 operands")
@@ -572,6 +579,31 @@ def linear_bwd_data(dy, w, *, epi=EPI_STORE, act=None, aux=None, alpha=1.0, drop
     return out
 
 
+def _bwd_data_transposed(dy, wt, epi, act, aux, alpha, drop, out, out_dtype):
+    _chk(dy, torch.bfloat16, "dy"); _chk(wt, torch.bfloat16, "wt")
+    M, N = _rows(dy), dy.shape[-1]
+    _req(wt.dim() == 2 and wt.shape[1] == N and N % 8 == 0, "linear_bwd_data: wt must be [K, N] with N a multiple of 8")
+    K = wt.shape[0]
+    if out is None:
+        out = torch.empty(*dy.shape[:-1], K, device=dy.device, dtype=out_dtype)
+    _chk(out, out.dtype, name="out")
+    _req(_rows(out) == M and out.shape[-1] == K, "linear_bwd_data: bad output shape")
+    io = 1 if out.dtype == torch.bfloat16 else 0
+    kw = dict(A=_p(dy), B=_p(wt), C=_p(out), Mc=M, Nc=K, R=N, lda=N, ldb=N, ldc=K, a_kcontig=1, b_kcontig=1, taps=1, T=0,
+              tap_mul=1, tap_add=0, shift_operand=0, epi=epi, act=_ACT[act], alpha=float(alpha),
+              drop_p=drop.p, drop_seed=drop.seed, drop_step=drop.step_ptr)
+    if epi == EPI_DACT:
+        _req(aux is not None, "linear_bwd_data: the act' epilogue needs aux")
+        _chk(aux, torch.bfloat16 if aux.dtype == torch.bfloat16 else torch.float32, name="aux")
+        _req(aux.shape == out.shape, "linear_bwd_data: aux shape")
+        kw.update(aux=_p(aux), ldaux=K)
+        if aux.dtype == torch.bfloat16:
+            io |= 2
+    kw.update(operand_bf16=4, io_bf16=io)
+    _gemm(**kw)
+    return out
+
+
 def cast_bf16(x, out=None):
     """bf16 copy (round to nearest even) of an fp32 tensor whose size is a multiple of 8."""
     _chk(x, name="x")
@@ -597,6 +629,26 @@ def transpose_cast_bf16(w, out=None):
     _req(out.numel() == w.numel(), "transpose_cast_bf16: output size")
     _ok(lib().fs2hip_transpose_cast_bf16(_p(w), R, Cc, Cc, _p(out), R, batch, _stream()), "transpose_cast_bf16")
     return out
+
+
+TRANSPOSE_MAX_JOBS = 64
+
+
+class TransposeJob(C.Structure):  # mirrors Fs2TransposeJob (include/fs2hip.h)
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int)]
+
+
+def transpose_cast_bf16_multi(pairs):
+    """``pairs``: [(src fp32 [R, C], dst bf16 [C, R]), ...] -- every dst = src^T rounded to bf16, ``TRANSPOSE_MAX_JOBS``
+    matrices per launch."""
+    for i in range(0, len(pairs), TRANSPOSE_MAX_JOBS):
+        batch = pairs[i:i + TRANSPOSE_MAX_JOBS]
+        jobs = (TransposeJob * len(batch))()
+        for j, (src, dst) in zip(jobs, batch):
+            _chk(src, name="src"); _chk(dst, torch.bfloat16, "dst")
+            _req(src.dim() == 2 and tuple(dst.shape) == (src.shape[1], src.shape[0]), "transpose_cast_bf16_multi: dst must be src^T")
+            j.src, j.dst, j.rows, j.cols = _p(src), _p(dst), src.shape[0], src.shape[1]
+        _ok(lib().fs2hip_transpose_cast_bf16_multi(jobs, len(batch), _stream()), "transpose_cast_bf16_multi")
 
 
 def pick_splitk(Mc: int, Nc: int, R: int, taps: int = 1) -> int:

@@ -827,7 +827,7 @@ class FastSpeech2(_Base):
                 S.buffers[n] = counters[i]
             S.bn_counters = counters
             S.device = device
-            S._pviews, S._gviews, S._bviews, S.flat_bf16 = {}, {}, {}, None
+            S._pviews, S._gviews, S._bviews, S._tviews, S.flat_bf16 = {}, {}, {}, {}, None
             self.step_state = self.step_state.to(device, copy=True)
             self.env.step_state = self.step_state
             if getattr(self.env, "_side_stream", None) is not None:

@@ -183,6 +183,8 @@ class FeedForward:
         decl_linear(S, prefix + "sequential.4.", d, f)
         self.s1, self.s2 = env.new_site(), env.new_site()
         self.f, self.d = f, d
+        if dims_ok and d == 256:  # the data gradient through the second Linear reduces over d: forward orientation on W2^T
+            S.want_transposed(self.w2)
 
     def fwd(self, x):
         S, env = self.S, self.env
@@ -220,7 +222,7 @@ class FeedForward:
             with env.side(dz, c.a):
                 H.linear_bwd_weight(dz, c.a, S.g(self.w2), bias_grad=None if fused else S.g(self.b2))
             du = H.linear_bwd_data(dz, S.pb(self.w2), epi=H.EPI_DACT, act="silu", aux=c.u,
-                                   drop=env.drop(self.p, self.s1), out_dtype=bf)
+                                   drop=env.drop(self.p, self.s1), out_dtype=bf, wt=S.pbt(self.w2))
             with env.side(du, c.h):
                 H.linear_bwd_weight(du, c.h, S.g(self.w1), bias_grad=S.g(self.b1))
             dh = H.linear_bwd_data(du, S.pb(self.w1), out_dtype=bf)
@@ -261,6 +263,8 @@ class SelfAttention:
         S.add(self.bo, (d,), "id", P.init_zeros)
         self.sa, self.so = env.new_site(), env.new_site()
         self.d = d
+        if dims_ok and d == 256:
+            S.want_transposed(self.wo)
 
     def fwd(self, x, lens):
         S, env = self.S, self.env
@@ -300,7 +304,7 @@ class SelfAttention:
             with env.side(dz, c.ob):
                 H.linear_bwd_weight(dz, c.ob, S.g(self.wo), bias_grad=None if fused else S.g(self.bo))
             if c.o is None:
-                do = H.linear_bwd_data(dz, S.pb(self.wo), out_dtype=bf)
+                do = H.linear_bwd_data(dz, S.pb(self.wo), out_dtype=bf, wt=S.pbt(self.wo))
                 dqkv = H.attention_bwd_b(c.qkv, c.lens, c.ob, do, c.lse, B, T, self.heads, env.drop(self.p, self.sa))
             else:
                 do = H.linear_bwd_data(dz, S.pb(self.wo))  # fp32: the attention kernels' input
@@ -346,6 +350,8 @@ class ConvModule:
         S.add(self.w2, (d, d, 1), "pw", P.init_linear_weight)
         S.add(self.b2, (d,), "id", P.init_bias_for(d))
         self.site = env.new_site()
+        if dims_ok and d == 256:
+            S.want_transposed(self.w2)
 
     def fwd(self, x):
         S, env = self.S, self.env
@@ -384,7 +390,7 @@ class ConvModule:
             with env.side(dz, c.s):
                 H.linear_bwd_weight(dz, c.s, S.g(self.w2), bias_grad=None if fused else S.g(self.b2))
             chain = c.c.dtype == bf
-            ds = H.linear_bwd_data(dz, S.pb(self.w2), out_dtype=bf if chain else torch.float32)
+            ds = H.linear_bwd_data(dz, S.pb(self.w2), out_dtype=bf if chain else torch.float32, wt=S.pbt(self.w2))
             dc = H.bn_act_bwd(ds, c.c, c.stats, gg, gb, "silu", training=env.training, bf16_only=chain)
             dg2 = H.dwconv_bwd(dc, c.g2, S.p(self.wd), S.g(self.wd), S.g(self.bd), B, T, glu=True, out_dtype=bf)
             with env.side(dg2, c.h):

@@ -112,6 +112,7 @@ class ParamStore:
         self.total = 0
         self._bucket = 0
         self._pviews, self._gviews = {}, {}
+        self._transposed, self._tviews = [], {}
 
     # ---- declaration phase -----------------------------------------------------------------
     def add(self, name, ref_shape, kind="id", init=init_zeros):
@@ -173,6 +174,25 @@ class ParamStore:
         if self.flat_bf16 is None:
             self.flat_bf16 = torch.empty(self.total, device=self.flat.device, dtype=torch.bfloat16)
         H.cast_bf16(self.flat, out=self.flat_bf16)
+        if self._transposed:
+            # transposed bf16 mirrors (one launch for all of them): the weights whose data-gradient GEMM runs in the
+            # forward orientation on the weights-stationary kernel (reduction = the model width)
+            if not self._tviews:
+                for name in self._transposed:
+                    n, k = native_shape(self.entries[name].ref_shape, self.entries[name].kind)
+                    self._tviews[name] = torch.empty(k, n, device=self.flat.device, dtype=torch.bfloat16)
+            H.transpose_cast_bf16_multi([(self.p(name), self._tviews[name]) for name in self._transposed])
+
+    def want_transposed(self, name):
+        """Declares that ``pbt(name)`` -- the weight [N, K] as bf16 [K, N] -- is wanted (kept by ``refresh_bf16``)."""
+        if len(native_shape(self.entries[name].ref_shape, self.entries[name].kind)) != 2:
+            raise ValueError(f"{name}: only matrices have a transposed mirror")
+        if name not in self._transposed:
+            self._transposed.append(name)
+
+    def pbt(self, name):
+        """The transposed bf16 mirror of ``name`` (None when it was not declared or not refreshed yet)."""
+        return self._tviews.get(name)
 
     def pb(self, name):
         v = self._bviews.get(name)

@@ -363,6 +363,18 @@ int fs2hip_adamw_step(float* p, const float* g, float* m, float* v, long long n,
 int fs2hip_cast_bf16(const float* src, void* dst, long long n, void* stream);
 int fs2hip_transpose_cast_bf16(const float* src, int rows, int cols, int ld_src, void* dst, int ld_dst, int batch,
                                void* stream);
+/* The same for up to FS2_TRANSPOSE_MAX_JOBS matrices in one launch: dst[c][r] = bf16(src[r][c]), src fp32 [rows][cols]
+ * (dense), dst bf16 [cols][rows] (dense).  Keeps the transposed bf16 mirrors of the weights whose DATA gradient runs in
+ * the forward orientation (dz . W with W [256][K'] -> W^T [K'][256], the out-projection / second pointwise convolution /
+ * second feed-forward weights of a Conformer layer: torchaudio ConformerLayer, call sites fs2/model.py:193, :241), once
+ * per optimizer step, beside the bf16 mirror of the flat parameter buffer. */
+#define FS2_TRANSPOSE_MAX_JOBS 64
+typedef struct {
+  const float* src;
+  void* dst;
+  int rows, cols;
+} Fs2TransposeJob;
+int fs2hip_transpose_cast_bf16_multi(const Fs2TransposeJob* jobs, int njobs, void* stream);
 
 /* out = a * x * dropmask + b * y (y may be NULL);  out[b,t,:] = x[b,t,:] + e[b,:] */
 int fs2hip_axpby(const float* x, const float* y, float* out, long long n, float a, float b, float drop_p,
