@@ -49,11 +49,13 @@ template <int OFF>
 __device__ __forceinline__ void ws_ld64(u32x2& v, u32x4 r, int voff) {
   asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen offset:%3" : "=v"(v) : "v"(voff), "s"(r), "n"(OFF) : "memory");
 }
-// (a buffer store of more than 8 bytes whose soffset is not a register must not be followed at once by a write of its
-// data registers -- the compiler's hazard recogniser pads its own stores, it does not see these: the row-tile offset
-// travels in soffset, which also makes the per-lane offset a constant of the launch)
+// A buffer store of more than 8 bytes must not be followed at once by a write of its data registers (the store reads them
+// over the following cycles: two wait states on gfx950).  The compiler's hazard recogniser pads its own stores; it does not
+// see these, and does reuse the registers in the very next instruction (seen on the chip: the second dword of some lanes
+// came out overwritten) -- hence the s_nop inside the statement.  The row-tile offset travels in soffset, which makes the
+// per-lane offset a constant of the launch.
 __device__ __forceinline__ void ws_st128(u32x4 v, u32x4 r, int voff, int soff) {
-  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" ::"v"(v), "v"(voff), "s"(r), "s"(soff) : "memory");
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(r), "s"(soff) : "memory");
 }
 template <int OFF>
 __device__ __forceinline__ void ws_ld128s(u32x4& v, u32x4 r, int voff, int soff) {
@@ -90,12 +92,15 @@ struct WsCounts {
 };
 
 // NB: 32-column blocks per wavefront (a workgroup covers 256 * NB output columns).
-// EPI / ACT / OBF (bf16 results) / TWO (pre-activation output) / AUXB (bf16 act' operand): compile-time epilogue.
-template <int NB, int EPI, int ACT, bool OBF, bool TWO, bool AUXB>
-__global__ __launch_bounds__(WS_THREADS) void gemmws_kernel(GemmP p, int n_slices, int n_streams, int n_row_tiles) {
+// EPI / ACT / OBF (bf16 results) / TWO (pre-activation output) / AUXB (bf16 act' operand) / DROP (dropout on):
+// compile-time epilogue.
+template <int NB, int EPI, int ACT, bool OBF, bool TWO, bool AUXB, bool DROP>
+__global__ __launch_bounds__(WS_THREADS, (NB == 1 && OBF) ? 4 : 2) void gemmws_kernel(GemmP p, int n_slices, int n_streams,
+                                                                                        int n_row_tiles) {
   typedef WsCounts<NB, EPI, OBF, TWO> CT;
   constexpr int ES = CT::ES, ROWB = CT::ROWB, RS = ROWB + 16, LPR = CT::LPR, RPP = CT::RPP;
   constexpr int STG = 32 * RS;  // staging bytes per wavefront
+  constexpr bool DELAY_PRE = !(NB == 1 && OBF);
   constexpr int RING = WS_NST * WS_TILE_BYTES, BIAS_OFF = RING + WS_WAVES * STG;
   __shared__ __attribute__((aligned(16))) char lds[BIAS_OFF + 256 * NB * 4];
   const Fs2GemmArgs& a = p.a;
@@ -139,21 +144,18 @@ __global__ __launch_bounds__(WS_THREADS) void gemmws_kernel(GemmP p, int n_slice
   // piece q = it * 512 + tid of a row tile: K-tile q >> 8, row (q >> 3) & 31, 16-byte chunk q & 7 (swizzled on the
   // source side); the LDS image [KT][32][128 B] is piece-linear.  Rows past Mc read zeros (num_records = the operand).
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, a.Mc * a.lda * 2, 0x00020000);
-  int avoff[CT::DMA];
-#pragma unroll
-  for (int it = 0; it < CT::DMA; ++it) {
-    const int q = it * WS_THREADS + tid;
-    const int kt = q >> 8, row = (q >> 3) & 31, c = q & 7;
-    avoff[it] = (row * a.lda + kt * 64 + ((c ^ ((row >> 1) & 7)) << 3)) * 2;
-  }
+  // (piece it * 512 + tid: the K-tile index grows by 2 per `it`, i.e. 256 bytes along the row)
+  static_assert(CT::DMA == 2, "two pieces per thread");
+  const int avoff = (((tid >> 3) & 31) * a.lda + (tid >> 8) * 64 + (((tid & 7) ^ ((tid >> 4) & 7)) << 3)) * 2;
   const int tile_stride = 32 * a.lda * 2;  // bytes between row tiles
   auto dma = [&](int k) {  // k-th row tile of this workgroup -> stage k % NST (k >= cnt: zeros into a stage nobody reads)
     const bool real = k < cnt;
     const int soff = real ? (stream + k * n_streams) * tile_stride : 0;
     char* dst = lds + (k % WS_NST) * WS_TILE_BYTES;
-#pragma unroll
-    for (int it = 0; it < CT::DMA; ++it)
-      b_dma16(ra, real ? avoff[it] : B_OOB, soff, dst + (it * WS_THREADS + wave * 64) * 16);
+    const int vo = real ? avoff : B_OOB;
+    // (the 256 bytes travel in the scalar offset: an instruction offset would move the LDS destination as well)
+    b_dma16(ra, vo, soff, dst + (wave * 64) * 16);
+    b_dma16(ra, vo, soff + 256, dst + (WS_THREADS + wave * 64) * 16);
   };
 
   // A fragment reads: K-step s = 4 kt + g reads chunk 2 g + h of K-tile kt
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(WS_THREADS) void gemmws_kernel(GemmP p, int n_slice
     xvoff[j] = n < a.Nc ? (l31 * ldx + n) * XES : B_OOB;
   }
   const int cvoff = ncol + 16 / ES <= a.Nc ? (rr * a.ldc + ncol) * ES : B_OOB;
-  const int pvoff = (TWO && ncol + 16 / ES <= a.Nc) ? (rr * a.ldpre + ncol) * ES : B_OOB;
+  const int pvoff = cvoff;  // (the launcher requires ldpre == ldc)
   auto load_x = [&](int k) {  // operand quads for the epilogue of the k-th row tile, issued ahead of its MFMAs
     if constexpr (CT::LOADS != 0) {
       const int soff = (stream + k * n_streams) * 32 * ldx * XES;
@@ -204,18 +206,6 @@ __global__ __launch_bounds__(WS_THREADS) void gemmws_kernel(GemmP p, int n_slice
     }
   };
 
-  // everything staged so far goes out as whole rows: rows 0..31 of the tile into tensor r (leading dimension ld)
-  auto flush = [&](u32x4 r, int ld, int voff, int m0) {
-    u32x4 w[32 / RPP];
-#pragma unroll
-    for (int ps = 0; ps < 32 / RPP; ++ps) ws_dsr128<0>(w[ps], stg + (ps * RPP + rr) * RS + cc * 16);
-    b_lds_wait<0>();
-#pragma unroll
-    for (int ps = 0; ps < 32 / RPP; ++ps) {
-      asm volatile("" : "+v"(w[ps]));
-      ws_st128(w[ps], r, voff, (m0 + ps * RPP) * ld * ES);
-    }
-  };
   auto put = [&](int j, int t, const float (&v)[4]) {
     const unsigned ad = stg + l31 * RS + 4 * h * ES + (32 * j + 8 * t) * ES;
     if (OBF) {
@@ -226,49 +216,66 @@ __global__ __launch_bounds__(WS_THREADS) void gemmws_kernel(GemmP p, int n_slice
       ws_dsw128(ad, __builtin_bit_cast(u32x4, w));
     }
   };
-  // alpha * acc + bias of one quad (the bias comes from LDS: four reads in flight, waited for together)
-  auto biased = [&](int j, const f32x4 (&b)[4], int t, float (&v)[4]) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = EPI >= 0 ? a.alpha * acc[j][4 * t + e] + b[t][e] : acc[j][4 * t + e];
+  // acc = alpha * acc + bias, in place; the bias quads come from LDS one quad ahead of their use (two rotating registers)
+  auto add_bias = [&]() {
+    if constexpr (EPI >= 0) {
+      u32x4 bq[2];
+      ws_dsr128<0>(bq[0], bias_rd);
+#define WS_BIAS(Q_)                                                                                        \
+  if constexpr ((Q_) + 1 < 4 * NB) ws_dsr128<32 * (((Q_) + 1) & 3)>(bq[((Q_) + 1) & 1], bias_rd + 128 * (((Q_) + 1) >> 2)); \
+  if constexpr ((Q_) + 1 < 4 * NB) b_lds_wait<1>(); else b_lds_wait<0>();                                  \
+  {                                                                                                        \
+    asm volatile("" : "+v"(bq[(Q_) & 1]));                                                                 \
+    const f32x4 b = __builtin_bit_cast(f32x4, bq[(Q_) & 1]);                                               \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                          \
+      acc[(Q_) >> 2][4 * ((Q_) & 3) + e] = a.alpha * acc[(Q_) >> 2][4 * ((Q_) & 3) + e] + b[e];            \
+  }
+      WS_BIAS(0) WS_BIAS(1) WS_BIAS(2) WS_BIAS(3)
+      if constexpr (NB == 2) { WS_BIAS(4) WS_BIAS(5) WS_BIAS(6) WS_BIAS(7) }
+#undef WS_BIAS
+    }
   };
-  auto bias_of = [&](int j, f32x4 (&b)[4]) {
-    u32x4 q[4];
-    ws_dsr128<0>(q[0], bias_rd + 128 * j); ws_dsr128<32>(q[1], bias_rd + 128 * j);
-    ws_dsr128<64>(q[2], bias_rd + 128 * j); ws_dsr128<96>(q[3], bias_rd + 128 * j);
-    b_lds_wait<0>();
+  // the two halves of a flush: the staged rows are requested from LDS; later -- after other work has covered the LDS
+  // round trip -- they are stored (LDS serves a wavefront's accesses in order: puts issued in between land behind the reads)
+  auto flush_begin = [&](u32x4 (&w)[32 / RPP]) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      asm volatile("" : "+v"(q[t]));
-      b[t] = __builtin_bit_cast(f32x4, q[t]);
+    for (int ps = 0; ps < 32 / RPP; ++ps) ws_dsr128<0>(w[ps], stg + (ps * RPP + rr) * RS + cc * 16);
+  };
+  auto flush_end = [&](u32x4 (&w)[32 / RPP], u32x4 r, int ld, int voff, int m0) {
+#pragma unroll
+    for (int ps = 0; ps < 32 / RPP; ++ps) {
+      asm volatile("" : "+v"(w[ps]));
+      ws_st128(w[ps], r, voff, (m0 + ps * RPP) * ld * ES);
     }
   };
 
   auto epilogue = [&](int k) {  // accumulators of the k-th row tile -> memory
     const int m0 = (stream + k * n_streams) * 32;
     const int m = m0 + l31;
-    if (TWO) {
+    add_bias();
+    u32x4 wpre[32 / RPP];
+    if constexpr (TWO) {
 #pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        f32x4 b[4];
-        bias_of(j, b);
+      for (int j = 0; j < NB; ++j)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          float v[4];
-          biased(j, b, t, v);
+          const float v[4] = {acc[j][4 * t], acc[j][4 * t + 1], acc[j][4 * t + 2], acc[j][4 * t + 3]};
           put(j, t, v);
         }
+      flush_begin(wpre);
+      if constexpr (!DELAY_PRE) {  // (four wavefronts per SIMD: the others cover the round trip; the registers are worth more)
+        b_lds_wait<0>();
+        flush_end(wpre, rp, a.ldpre, pvoff, m0);
       }
-      flush(rp, a.ldpre, pvoff, m0);  // (LDS serves a wavefront's accesses in order: the next puts land behind these reads)
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      f32x4 b[4];
-      bias_of(j, b);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int n = nw0 + 32 * j + 8 * t + 4 * h;
         float q[4];
-        biased(j, b, t, q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q[e] = acc[j][4 * t + e];
         if constexpr (EPI == FS2_EPI_ACT) {
           if (OBF && TWO) {  // the activation sees what the backward pass will read back: the rounded pre-activation
             const unsigned w0 = pack_bf16x2(q[0], q[1]), w1 = pack_bf16x2(q[2], q[3]);
@@ -288,8 +295,8 @@ __global__ __launch_bounds__(WS_THREADS) void gemmws_kernel(GemmP p, int n_slice
 #pragma unroll
           for (int e = 0; e < 4; ++e) q[e] *= dact_b<ACT>(a.act, x[e]);
         }
-        if (EPI > 0 && drop.on) {  // element index m * ldc + n, as everywhere else this mask is used; ldc is a
-          float f[4];              // multiple of 4 here, so a quad is two whole hash pairs
+        if constexpr (EPI > 0 && DROP) {  // element index m * ldc + n, as everywhere else this mask is used; ldc is a
+          float f[4];                     // multiple of 4 here, so a quad is two whole hash pairs
           fs2_drop_quad(drop, (unsigned)(m * a.ldc + n), f);
 #pragma unroll
           for (int e = 0; e < 4; ++e) q[e] *= f[e];
@@ -299,10 +306,19 @@ __global__ __launch_bounds__(WS_THREADS) void gemmws_kernel(GemmP p, int n_slice
 #pragma unroll
           for (int e = 0; e < 4; ++e) q[e] = xf[e] + a.res_scale * q[e];
         }
+        if constexpr (TWO && DELAY_PRE) {
+          if (j == 0 && t == 1) {  // the pre-activation rows: their LDS reads have had two quads of arithmetic to come back
+            b_lds_wait<0>();
+            flush_end(wpre, rp, a.ldpre, pvoff, m0);
+          }
+        }
         put(j, t, q);
       }
     }
-    flush(rc, a.ldc, cvoff, m0);
+    u32x4 wout[32 / RPP];
+    flush_begin(wout);
+    b_lds_wait<0>();
+    flush_end(wout, rc, a.ldc, cvoff, m0);
   };
 
   auto mfmas = [&](int k) {  // acc = A(row tile k) . W^T
@@ -311,20 +327,20 @@ __global__ __launch_bounds__(WS_THREADS) void gemmws_kernel(GemmP p, int n_slice
     for (int j = 0; j < NB; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    // sixteen K-steps; the A fragment of step s + 3 is requested while step s is in the MFMAs (four rotating buffers)
-    u32x4 af[4];
-#define WS_RD(S_) ws_dsr128<((S_) >> 2) * 4096>(af[(S_) & 3], ard[(S_) & 3] + sb);
+    // sixteen K-steps; the A fragment of step s + 2 is requested while step s is in the MFMAs (three rotating buffers)
+    u32x4 af[3];
+#define WS_RD(S_) ws_dsr128<((S_) >> 2) * 4096>(af[(S_) % 3], ard[(S_) & 3] + sb);
 #define WS_MM(S_, PENDING)                                                                                       \
   b_lds_wait<PENDING>();                                                                                         \
-  asm volatile("" : "+v"(af[(S_) & 3]));                                                                         \
+  asm volatile("" : "+v"(af[(S_) % 3]));                                                                         \
   _Pragma("unroll") for (int j = 0; j < NB; ++j)                                                                 \
     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[S_][j]),                       \
-                                                     __builtin_bit_cast(bf16x8, af[(S_) & 3]), acc[j], 0, 0, 0);
-    WS_RD(0) WS_RD(1) WS_RD(2)
-#define WS_STEP(S_) WS_RD((S_) + 3) WS_MM(S_, 3)
+                                                     __builtin_bit_cast(bf16x8, af[(S_) % 3]), acc[j], 0, 0, 0);
+    WS_RD(0) WS_RD(1)
+#define WS_STEP(S_) WS_RD((S_) + 2) WS_MM(S_, 2)
     WS_STEP(0) WS_STEP(1) WS_STEP(2) WS_STEP(3) WS_STEP(4) WS_STEP(5) WS_STEP(6) WS_STEP(7)
-    WS_STEP(8) WS_STEP(9) WS_STEP(10) WS_STEP(11) WS_STEP(12)
-    WS_MM(13, 2) WS_MM(14, 1) WS_MM(15, 0)
+    WS_STEP(8) WS_STEP(9) WS_STEP(10) WS_STEP(11) WS_STEP(12) WS_STEP(13)
+    WS_MM(14, 1) WS_MM(15, 0)
 #undef WS_STEP
 #undef WS_RD
 #undef WS_MM
@@ -389,8 +405,13 @@ __global__ __launch_bounds__(WS_THREADS) void gemmws_kernel(GemmP p, int n_slice
   ws_vmwait<0>();  // nothing of this wavefront may still be writing LDS or memory when the workgroup's LDS is released
 }
 
-#define WS_GO(NB_, EPI_, ACT_, OBF_, TWO_, AUXB_) \
-  gemmws_kernel<NB_, EPI_, ACT_, OBF_, TWO_, AUXB_><<<grid, block, 0, s>>>(p, n_slices, n_streams, n_row_tiles)
+#define WS_GO(NB_, EPI_, ACT_, OBF_, TWO_, AUXB_)                                                                       \
+  do {                                                                                                                  \
+    if ((EPI_) > 0 && p.drop.on)                                                                                        \
+      gemmws_kernel<NB_, EPI_, ACT_, OBF_, TWO_, AUXB_, ((EPI_) > 0)><<<grid, block, 0, s>>>(p, n_slices, n_streams, n_row_tiles); \
+    else                                                                                                                \
+      gemmws_kernel<NB_, EPI_, ACT_, OBF_, TWO_, AUXB_, false><<<grid, block, 0, s>>>(p, n_slices, n_streams, n_row_tiles);   \
+  } while (0)
 
 template <int NB>
 int launch_ws(GemmP& p, hipStream_t s) {
@@ -403,7 +424,10 @@ int launch_ws(GemmP& p, hipStream_t s) {
     n_cu = prop.multiProcessorCount;
   }
   const int n_slices = (a.Nc + 256 * NB - 1) / (256 * NB);
-  const int per_xcd = n_cu / 8;
+  // 32 columns per wavefront with bf16 results: 128 registers and 70 KB of LDS -- two workgroups per CU (four wavefronts
+  // per SIMD: the LDS round trips and the arithmetic of one hide under the others')
+  const int wgs_per_cu = (NB == 1 && (a.io_bf16 & 1)) ? 2 : 1;
+  const int per_xcd = n_cu / 8 * wgs_per_cu;
   if (per_xcd < 1 || n_slices > per_xcd) return FS2HIP_EINVAL;
   const int n_row_tiles = (a.Mc + 31) / 32;
   int streams_per_xcd = per_xcd / n_slices;
@@ -412,10 +436,15 @@ int launch_ws(GemmP& p, hipStream_t s) {
   const int n_streams = streams_per_xcd * 8;
   dim3 grid(8 * streams_per_xcd * n_slices), block(WS_THREADS);
   const bool obf = (a.io_bf16 & 1) != 0, auxb = (a.io_bf16 & 2) != 0, two = a.out_pre != nullptr;
-  // 64 columns per wavefront hold 128 registers of W: the instances with fp32 results AND operand quads (or a second
-  // fp32 output behind a run-time activation switch) do not fit the 256 registers of two wavefronts per SIMD
-  if (NB == 2 && !obf && (a.epi == FS2_EPI_RESID || a.epi == FS2_EPI_DACT || (a.epi == FS2_EPI_ACT && two && a.act != FS2_ACT_SILU)))
-    return FS2HIP_EINVAL;
+  // 64 columns per wavefront hold 128 registers of W: the instances that also carry operand quads or a second fp32
+  // output do not fit the 256 registers of two wavefronts per SIMD (they would spill, and scratch traffic is
+  // vector-memory traffic the counted waits know nothing about) -- those launches take the 32-column form or a tiled kernel
+  if (NB == 2) {
+    const bool drop_on = a.epi > 0 && p.drop.on;
+    const bool fits = a.epi == FS2_EPI_STORE || (a.epi == FS2_EPI_ACT && (obf || !two)) ||
+                      (a.epi == FS2_EPI_DACT && obf && auxb && drop_on && a.act == FS2_ACT_SILU);
+    if (!fits) return FS2HIP_EINVAL;
+  }
   switch (a.epi) {
     case FS2_EPI_ACT:
       if (a.act == FS2_ACT_SILU) {
@@ -456,7 +485,7 @@ int fs2_gemmws_launch(GemmP& p, int tile, hipStream_t s) {
   if (!a.a_kcontig || !a.b_kcontig || a.taps != 1 || a.splitk != 1 || a.R != 64 * WS_KT || a.colsum) return FS2HIP_EINVAL;
   const int per16 = (a.io_bf16 & 1) ? 8 : 4;
   if ((a.Nc % per16) || (a.ldc % per16) || ((uintptr_t)a.C % 16)) return FS2HIP_EINVAL;
-  if (a.out_pre && (a.epi != FS2_EPI_ACT || (a.ldpre % per16) || ((uintptr_t)a.out_pre % 16))) return FS2HIP_EINVAL;
+  if (a.out_pre && (a.epi != FS2_EPI_ACT || a.ldpre != a.ldc || ((uintptr_t)a.out_pre % 16))) return FS2HIP_EINVAL;
   if ((long long)(a.Mc + 64) * a.lda * 2 >= 0x7fffffffLL || (long long)(a.Nc + 64) * a.ldb * 2 >= 0x7fffffffLL) return FS2HIP_EINVAL;
   if ((long long)(a.Mc + 64) * a.ldc * 4 >= 0x7fffffffLL) return FS2HIP_EINVAL;
   switch (tile) {
