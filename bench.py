@@ -65,7 +65,7 @@ def make_config(learn_alignment=False, gst=False):
     return FastSpeech2Config(model=model, text=default_symbols(64))
 
 
-def cpu_baseline(config, batch, sample_B=32, iters=2):
+def cpu_baseline(config, batch, sample_B=32, iters=3):
     """Oracle (CPU port of the reference path) fwd + loss + bwd + AdamW on the first ``sample_B``
     utterances of the benchmark batch."""
     from fastspeech2_lightning_amd.config import Stats
@@ -374,14 +374,15 @@ def roofline_of(sig, precision, prof, ov):
     return r
 
 
-def extra_leg(name, precision, batch_size, learn_alignment, steps, local, want_roofline):
+def extra_leg(name, precision, batch_size, learn_alignment, steps, local, want_roofline, gst=False):
     """One of the secondary configurations: own model, own batch, warm-up (tile tuning), >= 20 timed steps."""
-    rig = Rig(precision, batch_size, learn_alignment=learn_alignment, local=local)
+    rig = Rig(precision, batch_size, learn_alignment=learn_alignment, gst=gst, local=local)
     for _ in range(3):
         rig.step()
     torch.cuda.synchronize()
     dt = rig.timed(steps) / steps
-    out = {"precision": precision, "batch_per_gpu": batch_size, "learn_alignment": learn_alignment, "steps": steps,
+    out = {"precision": precision, "batch_per_gpu": batch_size, "learn_alignment": learn_alignment, "gst_multispeaker": gst,
+           "steps": steps,
            "ms_per_step": round(dt * 1e3, 3), "value": round(rig.frames / dt, 1), "unit": "mel-frames/s",
            "real_frames_per_step": rig.frames, "padded_frames_per_step": rig.padded}
     tf = rig.step_flops() / dt / 1e12
@@ -392,7 +393,7 @@ def extra_leg(name, precision, batch_size, learn_alignment, steps, local, want_r
         if os.environ.get("FS2_BENCH_GEMM_BREAKDOWN"):
             log_gemm_breakdown(prof)
         # (only the un-split precisions have a counter profile of their own: tools/profile_round.sh)
-        sig = None if precision == "32-split" else {"precision": precision, "batch": batch_size, "gst": False,
+        sig = None if precision == "32-split" else {"precision": precision, "batch": batch_size, "gst": bool(gst),
                                                     "learn_alignment": bool(learn_alignment)}
         out["roofline"] = roofline_of(sig, precision, prof, ov)
     log(f"{name}: {dt * 1e3:.2f} ms/step, {rig.frames / dt:,.0f} mel-frames/s")
@@ -521,7 +522,7 @@ def main():
     #  * 32-split: fp32-accurate GEMMs on the bf16 matrix pipe (tests/test_gemm_split_gpu.py), same model and batch;
     #  * bf16_mixed_b64: BASELINE.json configs[2];
     #  * learn_alignment: the reference's default model (fs2/config/__init__.py:139-142).
-    split = bf16_b64 = align = None
+    split = bf16_b64 = align = gst_leg = None
     default_cfg = config_signature(args) == {"precision": "32-true", "batch": 32, "gst": False, "learn_alignment": False}
     if default_cfg and world == 1 and not args.no_extra_legs and graph is None:
         n_leg = max(20, args.steps // 4)
@@ -545,6 +546,9 @@ def main():
         torch.cuda.empty_cache()
         bf16_b64 = extra_leg("bf16_mixed_b64", "bf16-mixed", 64, False, n_leg, local, not args.no_roofline)
         align = extra_leg("learn_alignment", "32-true", 32, True, n_leg, local, False)
+        # BASELINE.json configs[4] at its per-GPU share: GST reference encoder + 16 speakers, mel up to ~1 250 frames,
+        # bf16-mixed, batch 64 (fs2/gst/model.py:87-100, fs2/model.py:196-213)
+        gst_leg = extra_leg("gst_bf16_b64", "bf16-mixed", 64, False, n_leg, local, not args.no_roofline, gst=True)
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         cpu = cpu_baseline(cpu_cfg, cpu_batch)
         log("cpu baseline done")
@@ -572,7 +576,7 @@ def main():
             "padded_frames_per_s": round(padded_all * args.steps / elapsed, 1),
             "loss_total": round(losses.get("total", float("nan")), 5),
             "roofline": roofline, "cpu_baseline": cpu, "split_fp32": split, "bf16_mixed_b64": bf16_b64,
-            "learn_alignment": align,
+            "learn_alignment": align, "gst_bf16_b64": gst_leg,
         }
         if exchange_wait_ms is not None:
             line["exchange_wait_ms"] = round(exchange_wait_ms, 3)  # max over ranks of the per-step mean

@@ -16,6 +16,21 @@ from fastspeech2_lightning_amd.synthetic import DEFAULT_STATS, default_symbols, 
 from oracle import fs2_oracle as O
 from tests import dropout_masks as DM
 
+def record_errors(name, values):
+    """The measured errors of the full-size cases, kept: appended to
+    ``gpurun_out/fullsize_errors.jsonl`` (copied under ``profiles/`` with the round's other evidence)."""
+    import json
+    import os
+    from pathlib import Path
+    out = Path(os.environ.get("GRAFT_REPO_ROOT", Path(__file__).resolve().parent.parent)) / "gpurun_out"
+    try:
+        out.mkdir(exist_ok=True)
+        with open(out / "fullsize_errors.jsonl", "a") as f:
+            f.write(json.dumps({"case": name, **values}) + "\n")
+    except OSError:
+        pass
+
+
 pytestmark = [pytest.mark.gpu, pytest.mark.tuned_tiles]
 
 
@@ -156,6 +171,53 @@ def test_configs4_bf16_mixed_gst_multispeaker_long_utterances():
     assert torch.equal(out["tgt_mask"].cpu(), ref["tgt_mask"])
 
 
+def test_configs4_per_gpu_share_bf16_mixed_gst_multispeaker_batch64():
+    """BASELINE.json configs[4] at its PER-GPU size (global batch 512 over 8 GPUs = 64 utterances per GPU; what
+    ``bench.py``'s ``gst_bf16_b64`` leg times): bf16-mixed, GST reference encoder + style tokens, 16 speakers, mel up
+    to ~1 250 frames, batch 64, dropout on with the kernels' masks, tuned tiles -- against the fp32 CPU oracle at the
+    stated bf16 tolerances (mel MSE < 1e-3, total loss 0.1 %, every term 1 %, all gradients together 10 % relative L2,
+    the style / speaker branch 15 % per tensor); masks exact.  reference: fs2/gst/model.py:87-100, fs2/model.py:196-213."""
+    from fastspeech2_lightning_amd.model import FastSpeech2
+    config = FastSpeech2Config(model=dict(learn_alignment=False, use_global_style_token_module=True, multispeaker=True),
+                               text=default_symbols(64))
+    spk = {f"spk{i}": i for i in range(16)}
+    batch = synthetic_batch(B=64, ts_lo=96, ts_hi=128, n_symbols=64, n_mels=80, seed=1234, dur_hi=18)  # bench.py --gst --batch 64
+    batch["speaker_id"] = torch.arange(64, dtype=torch.int32) % 16
+    B, Ts, Tm = batch["mel"].shape[0], batch["text"].shape[1], batch["mel"].shape[1]
+    assert 1100 < Tm <= 1400, Tm
+    torch.set_num_threads(max(torch.get_num_threads(), 16))
+    model = FastSpeech2(config, Stats(**DEFAULT_STATS), speaker2id=spk, seed=1234, precision="bf16-mixed")
+    oracle = O.FastSpeech2Oracle(config, Stats(**DEFAULT_STATS), n_symbols=64, n_speakers=16)
+    sd = O.seeded_state_dict(oracle.state_dict())
+    oracle.load_state_dict(sd)
+    model.load_state_dict(sd)
+    model.train(); oracle.train()
+    model.postnet.dropout_p = oracle.postnet.dropout_p = 0.5
+    DM.inject(model, oracle, B, Ts, Tm)
+    ref = oracle(batch)
+    ref_losses = oracle.loss(ref, batch, 0)
+    ref_losses["total"].backward()
+    model.training_step(batch)
+    out = model.last_output
+    o, r = out["postnet_output"].cpu(), ref["postnet_output"].detach()
+    mse = float(((o - r) ** 2).mean())
+    lrel = {k: abs(float(v) - float(ref_losses[k])) / abs(float(ref_losses[k])) for k, v in model.last_losses.items()}
+    got = model.store.grad_state_dict()
+    num = sum(float((got[k].cpu() - p.grad).pow(2).sum()) for k, p in oracle.named_parameters() if p.grad is not None)
+    den = sum(float(p.grad.pow(2).sum()) for p in oracle.parameters() if p.grad is not None)
+    gerr = (num / den) ** 0.5
+    record_errors("configs4_gst_bf16_b64", dict(mel_mse=mse, loss_rel=lrel, grad_rel_l2=gerr, B=B, Ts=Ts, Tm=Tm))
+    print(f"\n[configs[4] per-GPU share: bf16-mixed, GST, 16 speakers, batch 64, Tm {Tm}] mel MSE {mse:.3e}, loss errors {lrel}, "
+          f"gradient relative L2 {gerr:.4f}")
+    assert mse < 1e-3, mse
+    assert all(v < 1e-2 for v in lrel.values()) and lrel["total"] < 1e-3, lrel
+    assert gerr < 0.1, gerr
+    for k in ("speaker_embedding.weight", "gst.stl.gst_embs", "gst.ref_enc.gru.weight_hh_l0"):
+        g, w = got[k].cpu(), dict(oracle.named_parameters())[k].grad
+        assert float((g - w).norm() / w.norm()) < 0.15, k
+    assert torch.equal(out["tgt_mask"].cpu(), ref["tgt_mask"]) and torch.equal(out["src_mask"].cpu(), ref["src_mask"])
+
+
 def test_configs1_full_size_learned_alignment_vs_oracle():
     """The reference's DEFAULT model (``learn_alignment=True``, fs2/config/__init__.py:139-142) at the benchmark's size
     -- batch 32, Tm = 648, tuned tiles, dropout on with the kernels' masks, epoch 10 so that the binarisation loss is on
@@ -230,6 +292,7 @@ def test_configs2_bf16_mixed_batch64_full_size():
     num = sum(float((got[k].cpu() - p.grad).pow(2).sum()) for k, p in oracle.named_parameters() if p.grad is not None)
     den = sum(float(p.grad.pow(2).sum()) for p in oracle.parameters() if p.grad is not None)
     print(f"\n[bf16-mixed, batch 64] mel MSE {mse:.3e}, loss errors {lrel}, gradient relative L2 {(num / den) ** 0.5:.4f}")
+    record_errors("configs2_bf16_b64", dict(mel_mse=mse, loss_rel=lrel, grad_rel_l2=(num / den) ** 0.5, B=B, Ts=Ts, Tm=Tm))
     assert mse < 1e-3, mse
     assert all(v < 1e-2 for v in lrel.values()) and lrel["total"] < 1e-3, lrel
     assert (num / den) ** 0.5 < 0.1, (num / den) ** 0.5
