@@ -472,6 +472,26 @@ class FastSpeech2(_Base):
             b["duration"] = self._dev(b["duration"], torch.float32 if prior else torch.int32)
         return b
 
+    # ---- per-block precision (measurement aid: tools/bf16_error_budget.py) ---------------------------------
+    #: {"encoder" | "decoder" | "postnet" | "adaptor" | "mel_linear" | "gst": precision} -- the named block's GEMMs run in
+    #: that precision instead of the model's (forward and backward alike).  Empty in every product path.
+    precision_overrides: dict = {}
+
+    def _prec(self, block):
+        import contextlib
+        over = self.precision_overrides.get(block)
+        if over is None:
+            return contextlib.nullcontext()
+
+        @contextlib.contextmanager
+        def ctx():
+            H.set_precision(over)
+            try:
+                yield
+            finally:
+                H.set_precision(self.precision)
+        return ctx()
+
     # ---- forward (fs2/model.py:153-268) -------------------------------------------------------------
     def forward(self, batch, control=None, inference=False):
         with torch.cuda.device(self.device_):  # kernels launch on the current device: it must be the model's
@@ -508,9 +528,11 @@ class FastSpeech2(_Base):
                 elif inference and not teacher_forcing:
                     style = self.gst.condition_on_gst_tokens(B)
                 else:
-                    style, gst_ctx = self.gst.fwd(batch["mel"])
+                    with self._prec("gst"):
+                        style, gst_ctx = self.gst.fwd(batch["mel"])
         x = H.add_posenc(inputs, self._table(Ts), src_lens, B, Ts)
-        x, enc_ctx = self.encoder.fwd(x, src_lens)
+        with self._prec("encoder"):
+            x, enc_ctx = self.encoder.fwd(x, src_lens)
         if self.gst is not None:
             self.env.join()
             x = H.add_rowvec(x, style, B, Ts)
@@ -519,8 +541,9 @@ class FastSpeech2(_Base):
         if m.multilingual:
             x = H.add_rowvec(x, H.embedding_fwd(batch["language_id"], S.p("language_embedding.weight")), B, Ts)
         Tm = batch["max_mel_len"]
-        va, va_ctx = self.variance_adaptor.fwd(x, batch, src_lens, self._table, int(Tm), control, inference,
-                                               teacher_forcing, text_emb=inputs)
+        with self._prec("adaptor"):
+            va, va_ctx = self.variance_adaptor.fwd(x, batch, src_lens, self._table, int(Tm), control, inference,
+                                                   teacher_forcing, text_emb=inputs)
         self._hard_idx = va_ctx.get("hard_idx")
         if va_ctx.get("bad") is not None:
             self._pending_bad.append((va_ctx["bad"], list(batch.get("basename") or [])))
@@ -540,11 +563,14 @@ class FastSpeech2(_Base):
         Tm, tgt_lens = va["Tm"], va["tgt_lens"]
         if (teacher_forcing or not inference) and batch.get("mel") is not None and batch["mel"].shape[1] != Tm:
             raise ValueError("max_mel_len must equal the padded mel length")
-        y, dec_ctx = self.decoder.fwd(va["output"], tgt_lens)
-        output = H.linear_fwd(y, S.p("mel_linear.weight"), S.p("mel_linear.bias"))
+        with self._prec("decoder"):
+            y, dec_ctx = self.decoder.fwd(va["output"], tgt_lens)
+        with self._prec("mel_linear"):
+            output = H.linear_fwd(y, S.p("mel_linear.weight"), S.p("mel_linear.bias"))
         postnet_output, post_ctx = None, None
         if m.use_postnet:
-            post, post_ctx = self.postnet.fwd(output)
+            with self._prec("postnet"):
+                post, post_ctx = self.postnet.fwd(output)
             postnet_output = H.axpby(output, post)
         if save:
             self._ctx = dict(text=text, enc=enc_ctx, va=va_ctx, dec=dec_ctx, dec_out=y, post=post_ctx, B=B, Ts=Ts, Tm=Tm,
@@ -586,27 +612,34 @@ class FastSpeech2(_Base):
         H.set_precision(self.precision)
         S, c, g, m = self.store, self._ctx, self._loss_grads, self.config.model
         sync = self.grad_sync
-        self.variance_adaptor.bwd_predictors_early(g, c["va"])
+        with self._prec("adaptor"):
+            self.variance_adaptor.bwd_predictors_early(g, c["va"])
         d_out = g["spec"]
         if m.use_postnet:
             d_post = g["postnet"]
             d_out = H.axpby(d_out, d_post)
-            d_out = H.axpby(d_out, self.postnet.bwd(d_post, c["post"]))
-        H.linear_bwd_weight(d_out, c["dec_out"], S.g("mel_linear.weight"), bias_grad=S.g("mel_linear.bias"))
-        d = H.linear_bwd_data(d_out, S.p("mel_linear.weight"))
+            with self._prec("postnet"):
+                d_out = H.axpby(d_out, self.postnet.bwd(d_post, c["post"]))
+        with self._prec("mel_linear"):
+            H.linear_bwd_weight(d_out, c["dec_out"], S.g("mel_linear.weight"), bias_grad=S.g("mel_linear.bias"))
+            d = H.linear_bwd_data(d_out, S.p("mel_linear.weight"))
         self._bucket_done(self._bucket_head)                              # mel head + PostNet
-        d = self.decoder.bwd(d, c["dec"], layer_done=self._bucket_done)   # one bucket per decoder layer but the first
+        with self._prec("decoder"):
+            d = self.decoder.bwd(d, c["dec"], layer_done=self._bucket_done)   # one bucket per decoder layer but the first
         self._bucket_done(self.decoder.buckets[0])
-        d, d_text = self.variance_adaptor.bwd(d, g, c["va"])
+        with self._prec("adaptor"):
+            d, d_text = self.variance_adaptor.bwd(d, g, c["va"])
         if c.get("gst") is not None:
             with self.env.side(d):  # parameter gradients only: beside the encoder's backward pass
-                self.gst.bwd(self._rowsum(d), c["gst"])
+                with self._prec("gst"):
+                    self.gst.bwd(self._rowsum(d), c["gst"])
         if m.multispeaker:
             self._rowvec_embedding_bwd("speaker_embedding.weight", c["batch"]["speaker_id"], d)
         if m.multilingual:
             self._rowvec_embedding_bwd("language_embedding.weight", c["batch"]["language_id"], d)
         self._bucket_done(self._bucket_va)                                # variance adaptor, GST, speaker / language
-        d = self.encoder.bwd(d, c["enc"], layer_done=self._bucket_done)
+        with self._prec("encoder"):
+            d = self.encoder.bwd(d, c["enc"], layer_done=self._bucket_done)
         if d_text is not None:  # the aligner's keys are the raw text embedding (fs2/variance_adaptor.py:254)
             d = H.axpby(d, d_text)
         if self.use_pfs:
