@@ -49,7 +49,6 @@ __global__ __launch_bounds__(256) void transpose_cast_bf16_multi_kernel(Transpos
   if ((int)blockIdx.x >= tc * tr) return;  // uniform per workgroup
   const int r0 = ((int)blockIdx.x / tc) * 64, c0 = ((int)blockIdx.x % tc) * 64;
   const float* __restrict__ src = jb.src;
-  __bf16* __restrict__ dst = (__bf16*)jb.dst;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int i = ty; i < 64; i += 4) {
     const int r = r0 + i, c = c0 + tx;
@@ -58,7 +57,10 @@ __global__ __launch_bounds__(256) void transpose_cast_bf16_multi_kernel(Transpos
   __syncthreads();
   for (int i = ty; i < 64; i += 4) {
     const int c = c0 + i, r = r0 + tx;
-    if (c < jb.cols && r < jb.rows) dst[(long long)c * jb.rows + r] = (__bf16)tile[tx][i];
+    if (c < jb.cols && r < jb.rows) {
+      if (jb.fp32_out) ((float*)jb.dst)[(long long)c * jb.rows + r] = tile[tx][i];
+      else ((__bf16*)jb.dst)[(long long)c * jb.rows + r] = (__bf16)tile[tx][i];
+    }
   }
 }
 

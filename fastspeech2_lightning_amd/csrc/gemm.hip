@@ -313,6 +313,7 @@ extern "C" int fs2hip_gemm(const Fs2GemmArgs* args, void* stream) {
     tile = v2_ok ? (odd_taps ? (v1_ok && !a.operand_bf16 && !a.colsum ? 3 : 7) : (narrow ? 5 : 4)) : (narrow ? 2 : 1);  // (core v1 is fp32 only)
   }
   if (a.operand_bf16 == 3 && (tile < 4 || tile > 9)) return FS2HIP_EINVAL;  // the one-tile-per-workgroup direct-to-LDS core only
+  if (tile == 32) return fs2_gemmws32_launch(p, s);
   if (tile >= 4) {
     if (!v2_ok) return FS2HIP_EINVAL;
     return tile >= 10 ? fs2_gemm2p_launch(p, tile, nz, s) : fs2_gemm2_launch(p, tile, nz, s);

@@ -298,8 +298,10 @@ def get_precision() -> str:
 GEMM_TILES_B = (20, 21, 22, 23, 24, 25, 26, 30, 31)  # bf16-storage core (operand_bf16 == 4): 128x128, 128x64, 64x64;
 #                                      24 / 25: persistent 128x128 / 128x64; 30 / 31: weights-stationary streaming form
 #                                      (K = 256, forward orientation: csrc/gemm_ws.hip), 512 / 256 columns per workgroup
-GEMM_TILES = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)  # 1-3: register-staged BK=16 core; 4-9: direct-to-LDS BK=32 core;
-#                                                      10-12: persistent direct-to-LDS core; 13-15: + split tail
+GEMM_TILES = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 32)  # 1-3: register-staged BK=16 core; 4-9: direct-to-LDS BK=32 core;
+#                                                      10-12: persistent direct-to-LDS core; 13-15: + split tail;
+#                                                      32: weights-stationary streaming form (exact fp32, K = 256, forward
+#                                                      orientation: csrc/gemm_ws32.hip)
 _TILE_CACHE = {}
 #: per signature: [(isolated ms for 4 launches, tile), ...] sorted, and how often the signature was launched --
 #: what ``refine_tiles_in_step`` works from
@@ -542,7 +544,7 @@ def linear_bwd_data(dy, w, *, epi=EPI_STORE, act=None, aux=None, alpha=1.0, drop
     bf16 core); ``aux`` may be fp32 or bf16, the result is ``out_dtype``.
     ``wt`` (bf16 [K, N] = w transposed, from ``ParamStore.pbt``): the product runs in the forward orientation -- both
     operands k-contiguous -- which the weights-stationary streaming kernel takes for N = 256 (csrc/gemm_ws.hip)."""
-    if wt is not None and dy.dtype == torch.bfloat16 and taps == 1:
+    if wt is not None and wt.dtype == dy.dtype and taps == 1 and (dy.dtype == torch.bfloat16 or GEMM_BF16 == 0):
         return _bwd_data_transposed(dy, wt, epi, act, aux, alpha, drop, out, out_dtype)
     stored = dy.dtype == torch.bfloat16
     _chk(dy, dy.dtype if stored else torch.float32, "dy"); _chk(w, dy.dtype if stored else torch.float32, "w")
@@ -580,9 +582,11 @@ def linear_bwd_data(dy, w, *, epi=EPI_STORE, act=None, aux=None, alpha=1.0, drop
 
 
 def _bwd_data_transposed(dy, wt, epi, act, aux, alpha, drop, out, out_dtype):
-    _chk(dy, torch.bfloat16, "dy"); _chk(wt, torch.bfloat16, "wt")
+    stored = dy.dtype == torch.bfloat16
+    _chk(dy, dy.dtype if stored else torch.float32, "dy"); _chk(wt, dy.dtype, "wt")
     M, N = _rows(dy), dy.shape[-1]
     _req(wt.dim() == 2 and wt.shape[1] == N and N % 8 == 0, "linear_bwd_data: wt must be [K, N] with N a multiple of 8")
+    _req(stored or out_dtype == torch.float32, "linear_bwd_data: bf16 results need bf16 operands")
     K = wt.shape[0]
     if out is None:
         out = torch.empty(*dy.shape[:-1], K, device=dy.device, dtype=out_dtype)
@@ -598,8 +602,10 @@ def _bwd_data_transposed(dy, wt, epi, act, aux, alpha, drop, out, out_dtype):
         _req(aux.shape == out.shape, "linear_bwd_data: aux shape")
         kw.update(aux=_p(aux), ldaux=K)
         if aux.dtype == torch.bfloat16:
+            _req(stored, "linear_bwd_data: a bf16 aux needs bf16 operands")
             io |= 2
-    kw.update(operand_bf16=4, io_bf16=io)
+    if stored:
+        kw.update(operand_bf16=4, io_bf16=io)
     _gemm(**kw)
     return out
 
@@ -635,7 +641,8 @@ TRANSPOSE_MAX_JOBS = 64
 
 
 class TransposeJob(C.Structure):  # mirrors Fs2TransposeJob (include/fs2hip.h)
-    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int)]
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("fp32_out", C.c_int),
+                ("pad_", C.c_int)]
 
 
 def transpose_cast_bf16_multi(pairs):
@@ -645,9 +652,10 @@ def transpose_cast_bf16_multi(pairs):
         batch = pairs[i:i + TRANSPOSE_MAX_JOBS]
         jobs = (TransposeJob * len(batch))()
         for j, (src, dst) in zip(jobs, batch):
-            _chk(src, name="src"); _chk(dst, torch.bfloat16, "dst")
+            _chk(src, name="src"); _chk(dst, dst.dtype if dst.dtype == torch.float32 else torch.bfloat16, "dst")
             _req(src.dim() == 2 and tuple(dst.shape) == (src.shape[1], src.shape[0]), "transpose_cast_bf16_multi: dst must be src^T")
             j.src, j.dst, j.rows, j.cols = _p(src), _p(dst), src.shape[0], src.shape[1]
+            j.fp32_out = 1 if dst.dtype == torch.float32 else 0
         _ok(lib().fs2hip_transpose_cast_bf16_multi(jobs, len(batch), _stream()), "transpose_cast_bf16_multi")
 
 

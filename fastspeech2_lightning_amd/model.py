@@ -34,6 +34,10 @@ except Exception:  # pragma: no cover - depends on the environment
     _Base = torch.nn.Module
 
 LOSS_KEYS = ("pitch", "energy", "duration", "spec", "postnet", "attn_ctc", "attn_bin")
+#: "32-true": keep fp32 W^T mirrors of the weights whose data gradient reduces over the model width (one transpose launch
+#: per step), so that those GEMMs run in the forward orientation on the streaming kernel.  FS2_FP32_TRANSPOSED=0: off.
+import os as _os
+FP32_TRANSPOSED = _os.environ.get("FS2_FP32_TRANSPOSED", "1") != "0"
 
 
 class VarianceAdaptor:
@@ -501,6 +505,8 @@ class FastSpeech2(_Base):
         H.set_precision(self.precision)
         if self.env.stored:
             self.store.refresh_bf16()  # the weights as bf16, once per step: every GEMM orientation reads this mirror
+        elif H.GEMM_BF16 == 0 and self.training and not inference and FP32_TRANSPOSED:
+            self.store.refresh_transposed_fp32()  # W^T of the K = 256 data-gradient weights (streaming fp32 kernel)
         control = control or InferenceControl()
         if "duration_control" in batch and batch["duration_control"] and batch["duration_control"][0]:
             control.duration = batch["duration_control"][0]
@@ -860,7 +866,7 @@ class FastSpeech2(_Base):
                 S.buffers[n] = counters[i]
             S.bn_counters = counters
             S.device = device
-            S._pviews, S._gviews, S._bviews, S._tviews, S.flat_bf16 = {}, {}, {}, {}, None
+            S._pviews, S._gviews, S._bviews, S._tviews, S._tviews32, S.flat_bf16 = {}, {}, {}, {}, {}, None
             self.step_state = self.step_state.to(device, copy=True)
             self.env.step_state = self.step_state
             if getattr(self.env, "_side_stream", None) is not None:

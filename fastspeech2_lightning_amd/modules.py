@@ -231,7 +231,8 @@ class FeedForward:
             dz = H.axpby(dy, None, 0.5, 0.0, env.drop(self.p, self.s2))
         with env.side(dz, c.a):
             H.linear_bwd_weight(dz, c.a, S.g(self.w2), bias_grad=None if fused else S.g(self.b2))
-        du = H.linear_bwd_data(dz, S.p(self.w2), epi=H.EPI_DACT, act="silu", aux=c.u, drop=env.drop(self.p, self.s1))
+        du = H.linear_bwd_data(dz, S.p(self.w2), epi=H.EPI_DACT, act="silu", aux=c.u, drop=env.drop(self.p, self.s1),
+                               wt=S.pt(self.w2))
         with env.side(du, c.h):
             H.linear_bwd_weight(du, c.h, S.g(self.w1), bias_grad=S.g(self.b1))
         dh = H.linear_bwd_data(du, S.p(self.w1))
@@ -318,7 +319,7 @@ class SelfAttention:
             dz = H.axpby(dy, None, 1.0, 0.0, d_o) if d_o.p > 0 else dy
         with env.side(dz, c.o):
             H.linear_bwd_weight(dz, c.o, S.g(self.wo), bias_grad=None if fused else S.g(self.bo))
-        do = H.linear_bwd_data(dz, S.p(self.wo))
+        do = H.linear_bwd_data(dz, S.p(self.wo), wt=S.pt(self.wo))
         dqkv = H.attention_bwd(c.qkv, c.lens, c.o, do, c.lse, B, T, self.heads, env.drop(self.p, self.sa))
         with env.side(dqkv, c.h):
             H.linear_bwd_weight(dqkv, c.h, S.g(self.wi), bias_grad=S.g(self.bi))
@@ -402,7 +403,7 @@ class ConvModule:
             dz = H.axpby(dy, None, 1.0, 0.0, d_o) if d_o.p > 0 else dy
         with env.side(dz, c.s):
             H.linear_bwd_weight(dz, c.s, S.g(self.w2), bias_grad=None if fused else S.g(self.b2))
-        ds = H.linear_bwd_data(dz, S.p(self.w2))
+        ds = H.linear_bwd_data(dz, S.p(self.w2), wt=S.pt(self.w2))
         dc = H.bn_act_bwd(ds, c.c, c.stats, gg, gb, "silu", training=env.training)
         dg2 = H.dwconv_bwd(dc, c.g2, S.p(self.wd), S.g(self.wd), S.g(self.bd), B, T, glu=True)
         with env.side(dg2, c.h):

@@ -112,7 +112,7 @@ class ParamStore:
         self.total = 0
         self._bucket = 0
         self._pviews, self._gviews = {}, {}
-        self._transposed, self._tviews = [], {}
+        self._transposed, self._tviews, self._tviews32 = [], {}, {}
 
     # ---- declaration phase -----------------------------------------------------------------
     def add(self, name, ref_shape, kind="id", init=init_zeros):
@@ -182,6 +182,22 @@ class ParamStore:
                     n, k = native_shape(self.entries[name].ref_shape, self.entries[name].kind)
                     self._tviews[name] = torch.empty(k, n, device=self.flat.device, dtype=torch.bfloat16)
             H.transpose_cast_bf16_multi([(self.p(name), self._tviews[name]) for name in self._transposed])
+
+    def refresh_transposed_fp32(self):
+        """The fp32 form of the same mirrors ("32-true": the K = 256 data gradients in the forward orientation, tile 32
+        of the GEMM): one launch per forward pass."""
+        from . import hip as H
+        if not self._transposed:
+            return
+        if not self._tviews32:
+            for name in self._transposed:
+                n, k = native_shape(self.entries[name].ref_shape, self.entries[name].kind)
+                self._tviews32[name] = torch.empty(k, n, device=self.flat.device, dtype=torch.float32)
+        H.transpose_cast_bf16_multi([(self.p(name), self._tviews32[name]) for name in self._transposed])
+
+    def pt(self, name):
+        """The transposed fp32 mirror of ``name`` (None when it was not declared or not refreshed yet)."""
+        return self._tviews32.get(name)
 
     def want_transposed(self, name):
         """Declares that ``pbt(name)`` -- the weight [N, K] as bf16 [K, N] -- is wanted (kept by ``refresh_bf16``)."""

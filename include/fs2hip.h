@@ -373,6 +373,8 @@ typedef struct {
   const float* src;
   void* dst;
   int rows, cols;
+  int fp32_out; /* 0: dst is bf16; 1: dst is fp32 (the "32-true" mirrors of the same weights, tile 32 of fs2hip_gemm) */
+  int pad_;
 } Fs2TransposeJob;
 int fs2hip_transpose_cast_bf16_multi(const Fs2TransposeJob* jobs, int njobs, void* stream);
 

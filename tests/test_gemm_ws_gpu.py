@@ -202,3 +202,109 @@ def test_train_step_is_the_same_with_and_without_the_streaming_kernel(H):
     num = sum(float((g1[k] - g).pow(2).sum()) for k, g in g0.items())
     den = sum(float(g.pow(2).sum()) for g in g0.values())
     assert (num / den) ** 0.5 < 1e-3, (num / den) ** 0.5
+
+
+# ---- the exact-fp32 form (csrc/gemm_ws32.hip, tile 32) ---------------------------------------------------------------------
+class only_tile32:
+    """fp32 GEMMs on one tile id (``GEMM_TILES``)."""
+    def __init__(self, H, tile):
+        self.H, self.tile = H, tile
+
+    def __enter__(self):
+        self.saved = self.H.GEMM_TILES
+        self.H.GEMM_TILES = (self.tile,)
+        self.H._TILE_CACHE.clear()
+        return self
+
+    def __exit__(self, *exc):
+        self.H.GEMM_TILES = self.saved
+        self.H._TILE_CACHE.clear()
+        return False
+
+
+def forms32(H, M, N, drop):
+    K = 256
+    x = rnd(M, K, seed=1).cuda()
+    w = rnd(N, K, seed=2, scale=K ** -0.5).cuda()
+    b = rnd(N, seed=3).cuda()
+    r = rnd(M, N, seed=4).cuda()
+    aux = rnd(M, N, seed=5).cuda()
+    out = {}
+    out["store"] = H.linear_fwd(x, w, b)
+    out["nobias"] = H.linear_fwd(x, w, None)
+    u = torch.empty(M, N, device="cuda")
+    out["silu"] = H.linear_fwd(x, w, b, epi=H.EPI_ACT, act="silu", out_pre=u, drop=drop)
+    out["pre"] = u
+    out["relu"] = H.linear_fwd(x, w, b, epi=H.EPI_ACT, act="relu", drop=drop)
+    out["resid"] = H.linear_fwd(x, w, b, epi=H.EPI_RESID, resid=r, res_scale=0.5, drop=drop)
+    out["dact"] = H.linear_bwd_data(x, None, epi=H.EPI_DACT, act="silu", aux=aux, drop=drop, wt=w)
+    out["dgrad"] = H.linear_bwd_data(x, None, wt=w)
+    return out
+
+
+@pytest.mark.parametrize("M,N", [(1, 256), (33, 256), (1000, 512), (4100, 1024), (20736, 768), (20736, 1024), (777, 260),
+                                 (2048, 1284), (70000, 256)])
+def test_fp32_streaming_kernel_equals_the_tiled_kernel_bit_for_bit(H, M, N):
+    """Tile 32 against tile 7 (64 x 64, one accumulation chain per output over ascending K-tiles with the same
+    lane-to-k map): the same fp32 sums in the same order, the same epilogue function -- equal to the last bit, dropout on;
+    and both against float64 at the fp32 kernels' tolerance."""
+    import torch.nn.functional as F
+    assert H.get_precision() == "32-true"
+    K = 256
+    x, w, b = rnd(M, K, seed=1).double(), rnd(N, K, seed=2, scale=K ** -0.5).double(), rnd(N, seed=3).double()
+    r, aux = rnd(M, N, seed=4).double(), rnd(M, N, seed=5).double().requires_grad_(True)
+    u = x @ w.t() + b
+    g = x @ w.t()
+    F.silu(aux).backward(g)
+    ref = {"store": u, "nobias": g, "silu": F.silu(u), "pre": u, "relu": torch.relu(u), "resid": r + 0.5 * u,
+           "dact": aux.grad, "dgrad": g}
+    with only_tile32(H, 32):
+        got = forms32(H, M, N, H.NO_DROP)
+        assert set(H._TILE_CACHE.values()) == {32}, H._TILE_CACHE
+    for name, want in ref.items():
+        err = float((got[name].double().cpu() - want).abs().max())
+        assert err < 4e-6 * 16 * max(1.0, float(want.abs().max())), (name, err)
+    step = torch.full((1,), 5, dtype=torch.int64, device="cuda")
+    drop = H.Drop(0.2, 0xabcde, step)
+    with only_tile32(H, 7):
+        want = forms32(H, M, N, drop)
+    with only_tile32(H, 32):
+        got = forms32(H, M, N, drop)
+    for name, wv in want.items():
+        assert torch.equal(got[name], wv), (name, float((got[name] - wv).abs().max()))
+
+
+def test_fp32_train_step_with_the_transposed_mirrors():
+    """32-true, d = 256: the K = 256 data gradients run in the forward orientation from the fp32 W^T mirrors
+    (``ParamStore.pt``, refreshed once per forward pass) -- losses and gradients equal the run without the mirrors up to the
+    fp32 summation order (1e-6 relative)."""
+    from fastspeech2_lightning_amd import hip as H
+    from fastspeech2_lightning_amd import model as MM
+    from fastspeech2_lightning_amd.config import FastSpeech2Config, Stats
+    from fastspeech2_lightning_amd.synthetic import DEFAULT_STATS, synthetic_batch
+    conf = dict(layers=1, dropout=0.1)
+    vp = dict(dropout=0.0)
+    config = FastSpeech2Config(model=dict(encoder=conf, decoder=conf, learn_alignment=False,
+                                          variance_predictors=dict(energy=vp, pitch=vp, duration=vp)),
+                               text=dict(symbols=dict(letters=[f"s{i}" for i in range(40)])))
+    batch = synthetic_batch(B=3, ts_lo=20, ts_hi=40, n_symbols=41, n_mels=80, seed=3, dur_hi=6)
+    res = {}
+    saved = MM.FP32_TRANSPOSED
+    try:
+        for on in (False, True):
+            MM.FP32_TRANSPOSED = on
+            H._TILE_CACHE.clear()
+            model = MM.FastSpeech2(config, Stats(**DEFAULT_STATS), seed=11)
+            model.train()
+            with torch.no_grad():
+                model.training_step(batch)
+            assert (model.store.pt("decoder.conformer_layers.0.ffn1.sequential.4.weight") is not None) == on
+            res[on] = (dict(model.last_losses), {k: v.clone() for k, v in model.store.grad_state_dict().items()})
+    finally:
+        MM.FP32_TRANSPOSED = saved
+        H._TILE_CACHE.clear()
+    for k, v in res[False][0].items():
+        assert abs(float(res[True][0][k]) - float(v)) <= 1e-6 * max(1.0, abs(float(v))), k
+    num = sum(float((res[True][1][k] - g).pow(2).sum()) for k, g in res[False][1].items())
+    den = sum(float(g.pow(2).sum()) for g in res[False][1].values())
+    assert (num / den) ** 0.5 < 1e-5, (num / den) ** 0.5
