@@ -78,3 +78,16 @@ def test_product_refuses_cpu_tensors(built):
     from fastspeech2_lightning_amd import hip
     with pytest.raises(RuntimeError, match="no CPU path"):
         hip.layernorm_fwd(torch.zeros(4, 8), torch.ones(8), torch.zeros(8))
+
+
+def test_documents_quote_the_real_entry_point_count():
+    """the number of C-ABI entry points quoted in DESIGN.md / README.md is ``len(hip.EXPORTS)`` (which
+    ``test_library_exports_every_declared_symbol`` ties to the header and the built library), not a hand-kept figure."""
+    import re
+    from pathlib import Path
+    from fastspeech2_lightning_amd import hip
+    root = Path(__file__).resolve().parent.parent
+    for name in ("DESIGN.md", "README.md"):
+        quoted = re.findall(r"(\d+) entry points", (root / name).read_text())
+        assert quoted, name
+        assert all(int(q) == len(hip.EXPORTS) for q in quoted), (name, quoted, len(hip.EXPORTS))
