@@ -19,14 +19,18 @@ __device__ __forceinline__ float4 ln_unpack_bf16(uint2 u) {
 }
 
 // YB: y is bf16 (the operand a bf16-storage GEMM reads: the normalised activations exist only in that form)
-template <int NCH, bool YB>
+// DROP: y = dropout(LayerNorm(x)) -- the variance predictors' Conv -> ReLU -> LayerNorm -> Dropout layers
+// (fs2/layers.py:30-48): the mask is drawn at the element index row * C + c, as the separate pass over y drew it
+template <int NCH, bool YB, bool DROP = false>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, void* __restrict__ y,
                                                       float* __restrict__ mean, float* __restrict__ rstd, int M,
-                                                      int C, float eps) {
+                                                      int C, float eps, Fs2Drop drop_in = Fs2Drop{}) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
+  Fs2Drop drop = drop_in;
+  if constexpr (DROP) drop = fs2_resolve_drop(drop_in);
   const int c4 = C >> 2;
   float4 v[NCH];
   float s = 0.f;
@@ -62,6 +66,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
       o.y = (v[j].y - mu) * rs * g.y + b.y;
       o.z = (v[j].z - mu) * rs * g.z + b.z;
       o.w = (v[j].w - mu) * rs * g.w + b.w;
+      if constexpr (DROP) {
+        float f[4];  // (C is a multiple of 4: row * C + 4 i is even, the quad is two whole hash pairs)
+        fs2_drop_quad(drop, (unsigned)(row * C + 4 * i), f);
+        o.x *= f[0]; o.y *= f[1]; o.z *= f[2]; o.w *= f[3];
+      }
       if constexpr (YB) reinterpret_cast<uint2*>((unsigned short*)y + (long long)row * C)[i] = ln_pack_bf16(o);
       else reinterpret_cast<float4*>((float*)y + (long long)row * C)[i] = o;
     }
@@ -75,7 +84,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // (the gradient of that sub-module's last bias: what would otherwise be a column-sum launch over dz)
 // DYB: dy is bf16 (the result of a bf16-storage data-gradient GEMM); ZB: dz is written as bf16 (the operand of the next
 // data-gradient and weight-gradient GEMMs; its column sums are those of the rounded values)
-template <int NCH, bool DZ, bool DYB = false, bool ZB = false>
+// PRED: the backward of such a predictor layer in one pass -- dy is first multiplied by the layer's dropout mask
+// (`drop_in`), and dx by relu'(pre-activation) = (x > 0), x being the ReLU's output that the LayerNorm normalised
+// (what were an axpby launch in front of this kernel and a dact_mul launch behind it)
+template <int NCH, bool DZ, bool DYB = false, bool ZB = false, bool PRED = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, const float* __restrict__ x,
                                                       const float* __restrict__ gamma, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, const float* __restrict__ dx_add,
@@ -101,6 +113,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     if (row >= M) break;
     const float mu = mean[row], rs = rstd[row];
     float4 xh[NCH], d[NCH];
+    unsigned pos[PRED ? NCH : 1];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
@@ -110,6 +123,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         if constexpr (DYB) d[j] = ln_unpack_bf16(reinterpret_cast<const uint2*>((const unsigned short*)dy + (long long)row * C)[i]);
         else d[j] = reinterpret_cast<const float4*>((const float*)dy + (long long)row * C)[i];
         xh[j] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+        if constexpr (PRED) {
+          float f[4];
+          fs2_drop_quad(drop, (unsigned)(row * C + 4 * i), f);
+          d[j].x *= f[0]; d[j].y *= f[1]; d[j].z *= f[2]; d[j].w *= f[3];
+          pos[j] = (xv.x > 0.f ? 1u : 0u) | (xv.y > 0.f ? 2u : 0u) | (xv.z > 0.f ? 4u : 0u) | (xv.w > 0.f ? 8u : 0u);
+        }
       } else {
         d[j] = make_float4(0, 0, 0, 0);
         xh[j] = make_float4(0, 0, 0, 0);
@@ -134,6 +153,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         if (dx_add) {
           float4 r = reinterpret_cast<const float4*>(dx_add + (long long)row * C)[i];
           o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        if constexpr (PRED) {
+          if (!(pos[j] & 1u)) o.x = 0.f;
+          if (!(pos[j] & 2u)) o.y = 0.f;
+          if (!(pos[j] & 4u)) o.z = 0.f;
+          if (!(pos[j] & 8u)) o.w = 0.f;
         }
         reinterpret_cast<float4*>(dx + (long long)row * C)[i] = o;
         if constexpr (DZ) {
@@ -186,6 +211,43 @@ extern "C" int fs2hip_layernorm_fwd(const float* x, const float* gamma, const fl
   }
   FS2_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int fs2hip_layernorm_fwd_drop(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                                         float* rstd, int M, int C, float eps, float drop_p, unsigned long long drop_seed,
+                                         const unsigned long long* drop_step, void* stream) {
+  if (M <= 0 || C <= 0 || (C % 4) || C > LN_MAX_CH * 256 || (long long)M * C >= 0x7fffffffLL) return FS2HIP_EINVAL;
+  if (((uintptr_t)x % 16) || ((uintptr_t)y % 16) || ((uintptr_t)gamma % 16) || ((uintptr_t)beta % 16)) return FS2HIP_EINVAL;
+  if (!(drop_p > 0.f)) return fs2hip_layernorm_fwd(x, gamma, beta, y, mean, rstd, M, C, eps, stream);
+  dim3 grid((M + 3) / 4), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  const Fs2Drop drop = fs2_make_drop(drop_p, drop_seed, drop_step);
+  const int nch = (C / 4 + 63) / 64;
+  switch (nch) {
+    case 1: ln_fwd_kernel<1, false, true><<<grid, block, 0, s>>>(x, gamma, beta, y, mean, rstd, M, C, eps, drop); break;
+    case 2: ln_fwd_kernel<2, false, true><<<grid, block, 0, s>>>(x, gamma, beta, y, mean, rstd, M, C, eps, drop); break;
+    default: ln_fwd_kernel<4, false, true><<<grid, block, 0, s>>>(x, gamma, beta, y, mean, rstd, M, C, eps, drop); break;
+  }
+  FS2_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fs2hip_layernorm_bwd_pred(const float* dy, const float* x, const float* gamma, const float* mean,
+                                         const float* rstd, float* dx, float* partial, int M, int C, float drop_p,
+                                         unsigned long long drop_seed, const unsigned long long* drop_step, void* stream) {
+  if (M <= 0 || C <= 0 || (C % 4) || C > LN_MAX_CH * 256 || !partial || (long long)M * C >= 0x7fffffffLL) return FS2HIP_EINVAL;
+  if (((uintptr_t)x % 16) || ((uintptr_t)dy % 16) || ((uintptr_t)dx % 16) || ((uintptr_t)gamma % 16)) return FS2HIP_EINVAL;
+  const int nblk = fs2hip_layernorm_bwd_blocks(M);
+  hipStream_t s = (hipStream_t)stream;
+  const Fs2Drop drop = fs2_make_drop(drop_p, drop_seed, drop_step);  // (p = 0: every factor is 1)
+  const int nch = (C / 4 + 63) / 64;
+  switch (nch) {
+    case 1: ln_bwd_kernel<1, false, false, false, true><<<dim3(nblk), dim3(256), 0, s>>>(dy, x, gamma, mean, rstd, nullptr, dx, partial, M, C, nullptr, 0.f, drop); break;
+    case 2: ln_bwd_kernel<2, false, false, false, true><<<dim3(nblk), dim3(256), 0, s>>>(dy, x, gamma, mean, rstd, nullptr, dx, partial, M, C, nullptr, 0.f, drop); break;
+    default: ln_bwd_kernel<4, false, false, false, true><<<dim3(nblk), dim3(256), 0, s>>>(dy, x, gamma, mean, rstd, nullptr, dx, partial, M, C, nullptr, 0.f, drop); break;
+  }
+  FS2_LAUNCH_CHECK();
+  return 0;  // partial is [nblk][2][C]: dgamma | dbeta partial sums, finished by fs2hip_reduce_rows_multi
 }
 
 extern "C" int fs2hip_layernorm_fwd_b(const float* x, const float* gamma, const float* beta, void* y_bf16,

@@ -63,6 +63,8 @@ SIGNATURES = {
     "fs2hip_layernorm_bwd": "ppppppppppiip",
     "fs2hip_layernorm_bwd_dz": "ppppppppffQppiip",
     "fs2hip_layernorm_fwd_b": "ppppppiifp",
+    "fs2hip_layernorm_fwd_drop": "ppppppiiffQpp",
+    "fs2hip_layernorm_bwd_pred": "pppppppiifQpp",
     "fs2hip_layernorm_bwd_x": "ppppppppffQppiiip",
     "fs2hip_dwconv_bwd_b": "ppippipppiiiiip",
     "fs2hip_attention_fwd": "ppppiiiifQpip",
@@ -848,6 +850,36 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, out_dtype=torch.float32):
     fn = lib().fs2hip_layernorm_fwd_b if out_dtype == torch.bfloat16 else lib().fs2hip_layernorm_fwd
     _ok(fn(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, Cc, eps, _stream()), "layernorm_fwd")
     return y, mean, rstd
+
+
+def layernorm_fwd_drop(x, gamma, beta, drop: Drop, eps=1e-5):
+    """dropout(LayerNorm(x)) in one launch (the variance predictors' layers); the mask is ``axpby``'s over the result."""
+    _chk(x, name="x"); _chk(gamma, name="gamma"); _chk(beta, name="beta")
+    M, Cc = _rows(x), x.shape[-1]
+    _req(gamma.numel() == Cc and beta.numel() == Cc, "layernorm_fwd_drop: parameter size")
+    y = torch.empty_like(x)
+    mean = torch.empty(M, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+    _ok(lib().fs2hip_layernorm_fwd_drop(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, Cc, eps, drop.p,
+                                        drop.seed, drop.step_ptr, _stream()), "layernorm_fwd_drop")
+    return y, mean, rstd
+
+
+def layernorm_bwd_pred(dy, x, gamma, mean, rstd, dgamma, dbeta, drop: Drop):
+    """relu'(x) * LayerNormBackward(dropmask * dy): the backward of a predictor layer's Dropout, LayerNorm and ReLU in one
+    launch (x = the ReLU output).  dgamma / dbeta arrive at the next ``flush_grad_reductions()``."""
+    for n, t in (("dy", dy), ("x", x), ("gamma", gamma), ("mean", mean), ("rstd", rstd), ("dgamma", dgamma), ("dbeta", dbeta)):
+        _chk(t, name=n)
+    M, Cc = _rows(x), x.shape[-1]
+    _req(dy.shape == x.shape and mean.numel() == M and rstd.numel() == M and dgamma.numel() == Cc and dbeta.numel() == Cc,
+         "layernorm_bwd_pred: shape mismatch")
+    dx = torch.empty_like(x)
+    nblk = lib().fs2hip_layernorm_bwd_blocks(M)
+    part = torch.empty(nblk * 2 * Cc, device=x.device, dtype=torch.float32)
+    _ok(lib().fs2hip_layernorm_bwd_pred(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(part), M, Cc, drop.p,
+                                        drop.seed, drop.step_ptr, _stream()), "layernorm_bwd_pred")
+    _defer_reduction(part, nblk, 2 * Cc, 2 * Cc, dgamma, Cc, dbeta)
+    return dx
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dx_add=None, defer=False, dz_scale=None,

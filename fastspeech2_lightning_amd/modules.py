@@ -511,10 +511,10 @@ class VariancePredictor:
             else:
                 c = None
                 r = H.linear_fwd(x, S.p(L["wc"]), S.p(L["bc"]), epi=H.EPI_ACT, act="relu", taps=self.k, T=T)
-            n, ln_saved = L["ln"].fwd(r)
-            d = env.drop(self.p, L["site"])
-            out = H.axpby(n, None, 1.0, 0.0, d) if d.p > 0 else n
-            saved.append((x, c, r, ln_saved))
+            # LayerNorm + Dropout in one launch; the backward takes Dropout, LayerNorm and ReLU in one (norm.hip)
+            ln = L["ln"]
+            out, mean, rstd = H.layernorm_fwd_drop(r, S.p(ln.w), S.p(ln.b), env.drop(self.p, L["site"]))
+            saved.append((x, c, r, (r, mean, rstd)))
             x = out
         pred = H.rowdot_fwd(x, S.p(self.wl), S.p(self.bl), lens, B, T)
         return pred, (saved, x, lens)
@@ -525,11 +525,9 @@ class VariancePredictor:
         B, T, _ = xl.shape
         d = H.rowdot_bwd(dpred, xl, S.p(self.wl), lens, S.g(self.wl), S.g(self.bl), B, T)
         for L, (x, c, r, ln_saved) in zip(reversed(self.layers), reversed(saved)):
-            dr = env.drop(self.p, L["site"])
-            if dr.p > 0:
-                d = H.axpby(d, None, 1.0, 0.0, dr)
-            d = L["ln"].bwd(d, ln_saved)
-            d = H.dact_mul(d, r, "relu")
+            ln = L["ln"]
+            d = H.layernorm_bwd_pred(d, r, S.p(ln.w), ln_saved[1], ln_saved[2], S.g(ln.w), S.g(ln.b),
+                                     env.drop(self.p, L["site"]))
             if self.depthwise:
                 H.linear_bwd_weight(d, c, S.g(L["wp"]), bias_grad=S.g(L["bp"]))
                 dc = H.linear_bwd_data(d, S.p(L["wp"]))

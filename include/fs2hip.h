@@ -182,6 +182,17 @@ int fs2hip_layernorm_bwd_dz(const float* dy, const float* x, const float* gamma,
                             const float* rstd, const float* dx_add, float* dx, float* dz, float dz_scale,
                             float drop_p, unsigned long long drop_seed, const unsigned long long* drop_step,
                             float* partial, int M, int C, void* stream);
+/* The variance predictors' Conv -> ReLU -> LayerNorm -> Dropout layers (fs2/layers.py:30-48, five per predictor, three
+ * predictors: fs2/variance_adaptor.py:18-62) in two launches instead of five:
+ *   fwd_drop: y = dropout(LayerNorm(x)) (mask at element index row * C + c, as fs2hip_axpby draws it over y);
+ *   bwd_pred: dx = relu'(x) . LayerNormBackward(dropmask . dy) with x = the ReLU output the LayerNorm normalised
+ *             (relu' = (x > 0)); partial is [fs2hip_layernorm_bwd_blocks(M)][2][C] (dgamma | dbeta partial sums). */
+int fs2hip_layernorm_fwd_drop(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                              float* rstd, int M, int C, float eps, float drop_p, unsigned long long drop_seed,
+                              const unsigned long long* drop_step, void* stream);
+int fs2hip_layernorm_bwd_pred(const float* dy, const float* x, const float* gamma, const float* mean,
+                              const float* rstd, float* dx, float* partial, int M, int C, float drop_p,
+                              unsigned long long drop_seed, const unsigned long long* drop_step, void* stream);
 /* bf16 on either side of a LayerNorm ("bf16-mixed" with bf16 activation storage: the normalised activations and the
  * gradients between GEMMs exist only as the bf16 operands those GEMMs read).
  *   fwd_b: y is bf16.

@@ -259,3 +259,31 @@ def test_split_reduction_finished_in_kernel_is_bit_identical(H, monkeypatch, M, 
     finally:
         H.GEMM_TILES = saved
         H._TILE_CACHE.clear()
+
+
+def test_predictor_layer_layernorm_fusions_equal_the_separate_launches():
+    """``fs2hip_layernorm_fwd_drop`` = LayerNorm then the dropout pass; ``fs2hip_layernorm_bwd_pred`` = the dropout pass over
+    dy, LayerNorm backward, then relu' of the normalised ReLU output -- the variance predictors' layers
+    (fs2/layers.py:30-48) in two launches instead of five, bit for bit (same mask element index, same arithmetic)."""
+    import torch
+    from fastspeech2_lightning_amd import hip as H
+    g = torch.Generator().manual_seed(5)
+    for M, C in ((4096, 256), (777, 64), (33, 1024)):
+        x = torch.relu(torch.randn(M, C, generator=g)).cuda()
+        gamma, beta = (1 + 0.1 * torch.randn(C, generator=g)).cuda(), (0.1 * torch.randn(C, generator=g)).cuda()
+        dy = torch.randn(M, C, generator=g).cuda()
+        step = torch.full((1,), 7, dtype=torch.int64, device="cuda")
+        for p in (0.5, 0.0):
+            drop = H.Drop(p, 0x1234, step) if p else H.NO_DROP
+            n, mean, rstd = H.layernorm_fwd(x, gamma, beta)
+            want = H.axpby(n, None, 1.0, 0.0, drop) if p else n
+            got, mean2, rstd2 = H.layernorm_fwd_drop(x, gamma, beta, drop)
+            assert torch.equal(got, want) and torch.equal(mean, mean2) and torch.equal(rstd, rstd2)
+            dg1, db1, dg2, db2 = (torch.zeros(C, device="cuda") for _ in range(4))
+            d = H.axpby(dy, None, 1.0, 0.0, drop) if p else dy
+            d = H.layernorm_bwd(d, x, gamma, mean, rstd, dg1, db1)
+            want_dx = H.dact_mul(d, x, "relu")
+            got_dx = H.layernorm_bwd_pred(dy, x, gamma, mean, rstd, dg2, db2, drop)
+            H.flush_grad_reductions()
+            assert torch.equal(got_dx, want_dx)
+            assert torch.allclose(dg1, dg2, rtol=1e-5, atol=1e-5) and torch.allclose(db1, db2, rtol=1e-5, atol=1e-5)
