@@ -178,30 +178,39 @@ __global__ __launch_bounds__(256) void rowdot_fwd_kernel(const float* __restrict
   }
 }
 
-constexpr int RD_ROWS = 64;
+constexpr int RD_ROWS = 16;
 // dx[m,:] = g[m]*w ; partial[blk][C+1] = (sum_m g[m]*x[m,:], sum_m g[m]),  g = dout * mask
+// (16 rows per workgroup: 256 workgroups at the encoder's 4 096 rows; the masked gradients of the rows are staged once)
 __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ x,
                                                           const float* __restrict__ w, const int* __restrict__ lens,
                                                           float* __restrict__ dx, float* __restrict__ partial, int M,
                                                           int T, int C) {
-  const int r0 = blockIdx.x * RD_ROWS, r1 = min(M, r0 + RD_ROWS);
+  __shared__ float gs[RD_ROWS];
+  const int r0 = blockIdx.x * RD_ROWS, nr = min(M - r0, RD_ROWS);
+  if (threadIdx.x < RD_ROWS) {
+    const int r = r0 + threadIdx.x;
+    float g = 0.f;
+    if (r < M) {
+      const bool on = !lens || (r % T) < lens[r / T];
+      g = on ? dout[r] : 0.f;
+    }
+    gs[threadIdx.x] = g;
+  }
+  __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
     const float wc = w[c];
     float acc = 0.f;
-    for (int r = r0; r < r1; ++r) {
-      const bool on = !lens || (r % T) < lens[r / T];
-      const float g = on ? dout[r] : 0.f;
-      dx[(long long)r * C + c] = g * wc;
-      acc += g * x[(long long)r * C + c];
+#pragma unroll 4
+    for (int i = 0; i < nr; ++i) {
+      const float g = gs[i];
+      dx[(long long)(r0 + i) * C + c] = g * wc;
+      acc += g * x[(long long)(r0 + i) * C + c];
     }
     partial[(long long)blockIdx.x * (C + 1) + c] = acc;
   }
   if (threadIdx.x == 0) {
     float acc = 0.f;
-    for (int r = r0; r < r1; ++r) {
-      const bool on = !lens || (r % T) < lens[r / T];
-      acc += on ? dout[r] : 0.f;
-    }
+    for (int i = 0; i < nr; ++i) acc += gs[i];
     partial[(long long)blockIdx.x * (C + 1) + C] = acc;
   }
 }
