@@ -23,6 +23,12 @@ namespace {
 
 constexpr int W32_THREADS = 512, W32_KT = 8;         // K = 256: eight 32-deep K-tile images per row tile
 constexpr int W32_TILE_FLOATS = W32_KT * 32 * 32;    // [KT][32 rows][32 floats]
+// (measured and rejected: two accumulation chains per wavefront -- 105.0 us against 103.6 us for the 20 736 x 1024 store
+// form: the second wavefront of the SIMD already fills the gaps behind a dependent MFMA.  -DW32_TWO_CHAINS=1 rebuilds it;
+// the sums then differ from the tiled kernels' in the last bit.)
+#ifndef W32_TWO_CHAINS
+#define W32_TWO_CHAINS 0
+#endif
 
 // STORES: vector-memory stores of one epilogue per wavefront (16 accumulator registers, twice with a pre-activation output)
 template <int EPI, bool TWO>
@@ -74,16 +80,21 @@ __global__ __launch_bounds__(W32_THREADS) void gemmws32_kernel(GemmP p, int n_sl
     if (i == 0) wait_vmcnt_barrier<0>(); else wait_vmcnt_barrier<STORES>();
     dma(i + 1);
     const unsigned sb = (i & 1) * (W32_TILE_FLOATS * 4);
+    f32x16 acc2;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[0][0][r] = acc2[r] = 0.f;
     // 32 groups of four K-steps; the fragment of group q + 2 is requested while group q is in the MFMAs
     f32x4 af[3];
 #define W32_RD(Q_) lds_rd128<((Q_) >> 2) * 4096>(af[(Q_) % 3], ard[(Q_) & 3] + sb);
 #define W32_MM(Q_, PENDING)                                                                                        \
   lds_wait<PENDING>();                                                                                             \
   pin(af[(Q_) % 3]);                                                                                               \
-  _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                    \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[(Q_) % 3][j], wf[Q_][j], acc[0][0], 0, 0, 0);
+  _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                  \
+    if (W32_TWO_CHAINS && (j & 1))                                                                                 \
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[(Q_) % 3][j], wf[Q_][j], acc2, 0, 0, 0);                       \
+    else                                                                                                           \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[(Q_) % 3][j], wf[Q_][j], acc[0][0], 0, 0, 0);            \
+  }
 #define W32_STEP(Q_) W32_RD((Q_) + 2) W32_MM(Q_, 2)
     W32_RD(0) W32_RD(1)
     W32_STEP(0) W32_STEP(1) W32_STEP(2) W32_STEP(3) W32_STEP(4) W32_STEP(5) W32_STEP(6) W32_STEP(7)
@@ -94,6 +105,10 @@ __global__ __launch_bounds__(W32_THREADS) void gemmws32_kernel(GemmP p, int n_sl
 #undef W32_STEP
 #undef W32_RD
 #undef W32_MM
+    if (W32_TWO_CHAINS) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][0][r] += acc2[r];
+    }
     gemm_epilogue_impl<64, 64, EPI>(p, acc, C, a.ldc, (stream + i * n_streams) * 32, ns0, 0, wave, lane);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
