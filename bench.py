@@ -242,6 +242,7 @@ class Rig:
         t0 = time.perf_counter()
         for _ in range(steps):
             run()
+        self.host_enqueue_s = time.perf_counter() - t0  # the host's share: everything enqueued, nothing waited for
         torch.cuda.synchronize()
         return time.perf_counter() - t0
 
@@ -396,7 +397,8 @@ def extra_leg(name, precision, batch_size, learn_alignment, steps, local, want_r
         sig = None if precision == "32-split" else {"precision": precision, "batch": batch_size, "gst": bool(gst),
                                                     "learn_alignment": bool(learn_alignment)}
         out["roofline"] = roofline_of(sig, precision, prof, ov)
-    log(f"{name}: {dt * 1e3:.2f} ms/step, {rig.frames / dt:,.0f} mel-frames/s")
+    log(f"{name}: {dt * 1e3:.2f} ms/step, {rig.frames / dt:,.0f} mel-frames/s (host enqueue {rig.host_enqueue_s / steps * 1e3:.2f} ms/step)")
+    out["host_enqueue_ms_per_step"] = round(rig.host_enqueue_s / steps * 1e3, 3)
     del rig
     torch.cuda.empty_cache()
     return out
@@ -488,6 +490,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run()
+    host_enqueue = time.perf_counter() - t0  # the host's share of the timed region: all launches enqueued, no wait yet
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -507,7 +510,7 @@ def main():
     else:
         frames_all, padded_all = frames, padded
     losses = {k: float(v) for k, v in model.last_losses.items()}
-    log(f"timed region: {elapsed / args.steps * 1e3:.2f} ms/step")
+    log(f"timed region: {elapsed / args.steps * 1e3:.2f} ms/step (host enqueue {host_enqueue / args.steps * 1e3:.2f} ms/step)")
 
     roofline = None
     if not args.no_roofline:

@@ -245,6 +245,7 @@ extern "C" int fs2hip_gemm(const Fs2GemmArgs* args, void* stream) {
     const int nzb = (a.shift_operand == 1 ? a.taps : 1) * a.splitk;
     int tb = a.tile;
     if (tb == 0) tb = (long long)((a.Mc + 127) / 128) * ((a.Nc + 127) / 128) * nzb >= 256 ? 20 : 23;
+    if (tb == 33) return nzb == 1 ? fs2_gemmws4_launch(p, (hipStream_t)stream) : FS2HIP_EINVAL;
     if (tb >= 30) return nzb == 1 ? fs2_gemmws_launch(p, tb, (hipStream_t)stream) : FS2HIP_EINVAL;
     return fs2_gemmb_launch(p, tb, nzb, (hipStream_t)stream);
   }

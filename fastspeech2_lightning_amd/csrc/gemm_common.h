@@ -265,6 +265,8 @@ int fs2_gemmb_launch(GemmP& p, int tile, int nz, hipStream_t s);
 int fs2_gemmws_launch(GemmP& p, int tile, hipStream_t s);
 // the same structure in exact fp32 (gemm_ws32.hip): tile 32
 int fs2_gemmws32_launch(GemmP& p, hipStream_t s);
+// bf16-storage core, K = 1024, tile id 33 (gemm_ws4.hip)
+int fs2_gemmws4_launch(GemmP& p, hipStream_t s);
 // finishes the reduction-split tail tiles of a persistent launch (reduce.hip)
 int fs2_tail_fixup(const float* ws, int S, long long slab, float* C, int ldc, const float* bias, float alpha, int m0,
                    int Mc, int Nc, hipStream_t s);

@@ -297,13 +297,19 @@ def get_precision() -> str:
     return {0: "32-true", 1: "bf16-mixed", 2: "32-split"}[int(GEMM_BF16)]
 
 
-GEMM_TILES_B = (20, 21, 22, 23, 24, 25, 26, 30, 31)  # bf16-storage core (operand_bf16 == 4): 128x128, 128x64, 64x64;
+GEMM_TILES_B = (20, 21, 22, 23, 24, 25, 26, 30, 31, 33)  # bf16-storage core (operand_bf16 == 4): 128x128, 128x64, 64x64;
 #                                      24 / 25: persistent 128x128 / 128x64; 30 / 31: weights-stationary streaming form
-#                                      (K = 256, forward orientation: csrc/gemm_ws.hip), 512 / 256 columns per workgroup
+#                                      (K = 256, forward orientation: csrc/gemm_ws.hip), 512 / 256 columns per workgroup;
+#                                      33: the same for K = 1024 (csrc/gemm_ws4.hip), 128 columns per workgroup
 GEMM_TILES = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 32)  # 1-3: register-staged BK=16 core; 4-9: direct-to-LDS BK=32 core;
 #                                                      10-12: persistent direct-to-LDS core; 13-15: + split tail;
 #                                                      32: weights-stationary streaming form (exact fp32, K = 256, forward
 #                                                      orientation: csrc/gemm_ws32.hip)
+#: FS2_GEMM_EXCLUDE_TILES=33,30 (measurement aid): tile ids the tuner leaves out -- same-box A/B runs of a kernel family
+_EXCLUDED = {int(t) for t in os.environ.get("FS2_GEMM_EXCLUDE_TILES", "").split(",") if t.strip()}
+if _EXCLUDED:
+    GEMM_TILES_B = tuple(t for t in GEMM_TILES_B if t not in _EXCLUDED)
+    GEMM_TILES = tuple(t for t in GEMM_TILES if t not in _EXCLUDED)
 _TILE_CACHE = {}
 #: per signature: [(isolated ms for 4 launches, tile), ...] sorted, and how often the signature was launched --
 #: what ``refine_tiles_in_step`` works from

@@ -185,6 +185,8 @@ class FeedForward:
         self.f, self.d = f, d
         if dims_ok and d == 256:  # the data gradient through the second Linear reduces over d: forward orientation on W2^T
             S.want_transposed(self.w2)
+            if f == 1024:  # ... and through the first one over f: the K = 1024 streaming kernel (bf16 operand storage)
+                S.want_transposed(self.w1, bf16_only=True)
 
     def fwd(self, x):
         S, env = self.S, self.env
@@ -225,7 +227,7 @@ class FeedForward:
                                    drop=env.drop(self.p, self.s1), out_dtype=bf, wt=S.pbt(self.w2))
             with env.side(du, c.h):
                 H.linear_bwd_weight(du, c.h, S.g(self.w1), bias_grad=S.g(self.b1))
-            dh = H.linear_bwd_data(du, S.pb(self.w1), out_dtype=bf)
+            dh = H.linear_bwd_data(du, S.pb(self.w1), out_dtype=bf, wt=S.pbt(self.w1))
             return self.ln.bwd(dh, c.ln, dx_add=dy, nxt=nxt, dz_dtype=bf)
         if not fused:
             dz = H.axpby(dy, None, 0.5, 0.0, env.drop(self.p, self.s2))

@@ -113,6 +113,7 @@ class ParamStore:
         self._bucket = 0
         self._pviews, self._gviews = {}, {}
         self._transposed, self._tviews, self._tviews32 = [], {}, {}
+        self._transposed_bf16_only = set()
 
     # ---- declaration phase -----------------------------------------------------------------
     def add(self, name, ref_shape, kind="id", init=init_zeros):
@@ -191,20 +192,26 @@ class ParamStore:
             return
         if not self._tviews32:
             for name in self._transposed:
+                if name in self._transposed_bf16_only:
+                    continue
                 n, k = native_shape(self.entries[name].ref_shape, self.entries[name].kind)
                 self._tviews32[name] = torch.empty(k, n, device=self.flat.device, dtype=torch.float32)
-        H.transpose_cast_bf16_multi([(self.p(name), self._tviews32[name]) for name in self._transposed])
+        if self._tviews32:
+            H.transpose_cast_bf16_multi([(self.p(name), v) for name, v in self._tviews32.items()])
 
     def pt(self, name):
         """The transposed fp32 mirror of ``name`` (None when it was not declared or not refreshed yet)."""
         return self._tviews32.get(name)
 
-    def want_transposed(self, name):
-        """Declares that ``pbt(name)`` -- the weight [N, K] as bf16 [K, N] -- is wanted (kept by ``refresh_bf16``)."""
+    def want_transposed(self, name, bf16_only=False):
+        """Declares that ``pbt(name)`` -- the weight [N, K] as bf16 [K, N] -- is wanted (kept by ``refresh_bf16``);
+        ``bf16_only``: no fp32 form (``pt``) of it."""
         if len(native_shape(self.entries[name].ref_shape, self.entries[name].kind)) != 2:
             raise ValueError(f"{name}: only matrices have a transposed mirror")
         if name not in self._transposed:
             self._transposed.append(name)
+            if bf16_only:
+                self._transposed_bf16_only.add(name)
 
     def pbt(self, name):
         """The transposed bf16 mirror of ``name`` (None when it was not declared or not refreshed yet)."""

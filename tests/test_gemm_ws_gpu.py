@@ -308,3 +308,73 @@ def test_fp32_train_step_with_the_transposed_mirrors():
     num = sum(float((res[True][1][k] - g).pow(2).sum()) for k, g in res[False][1].items())
     den = sum(float(g.pow(2).sum()) for g in res[False][1].values())
     assert (num / den) ** 0.5 < 1e-5, (num / den) ** 0.5
+
+
+# ---- K = 1024 (csrc/gemm_ws4.hip, tile 33) --------------------------------------------------------------------------------
+def forms_k1024(H, M, N, drop):
+    """The two K = 1024 GEMMs of a feed-forward module under bf16 operand storage: the second Linear with its residual +
+    dropout epilogue (fp32 result), and the first Linear's data gradient through the transposed mirror (bf16 / fp32)."""
+    K = 1024
+    x = rnd(M, K, seed=1).bfloat16().cuda()
+    w = rnd(N, K, seed=2, scale=K ** -0.5).bfloat16().cuda()
+    b = rnd(N, seed=3).cuda()
+    r = rnd(M, N, seed=4).cuda()
+    bf = torch.bfloat16
+    return {
+        "resid32": H.linear_fwd(x, w, b, epi=H.EPI_RESID, resid=r, res_scale=0.5, drop=drop),
+        "store32": H.linear_fwd(x, w, b),
+        "store16": H.linear_fwd(x, w, b, out_dtype=bf),
+        "dgrad16": H.linear_bwd_data(x, None, out_dtype=bf, wt=w),
+        "dgrad32": H.linear_bwd_data(x, None, wt=w),
+    }
+
+
+@pytest.mark.parametrize("M,N", [(1, 256), (33, 256), (1000, 128), (4100, 256), (8192, 256), (43008, 256), (777, 264),
+                                 (2048, 1000), (70000, 256)])
+def test_k1024_streaming_kernel_equals_the_tiled_kernel_bit_for_bit(H, M, N):
+    """Tile 33: four wavefronts, W[32 columns][1024] per wavefront in 224 accumulation + 32 vector registers (inline-asm
+    MFMAs), A in 16 KB chunks through an eight-stage ring, counted waits.  The same 64 MFMAs per output block in the same
+    order as the tiled kernels, their epilogue arithmetic and masks: results equal tile 22's bit for bit, and both are
+    checked against float64."""
+    K = 1024
+    x = rnd(M, K, seed=1).bfloat16().double()
+    w = rnd(N, K, seed=2, scale=K ** -0.5).bfloat16().double()
+    u = x @ w.t() + rnd(N, seed=3).double()
+    ref = {"resid32": rnd(M, N, seed=4).double() + 0.5 * u, "store32": u, "store16": u, "dgrad16": x @ w.t(), "dgrad32": x @ w.t()}
+    for t in (22, 33):
+        with only_tile(H, t) as ot:
+            got = forms_k1024(H, M, N, H.NO_DROP)
+            assert ot.ran(), (t, dict(H._TILE_CACHE))
+        for name, want in ref.items():
+            g = got[name].double().cpu()
+            tol = (2.0 ** -7 if got[name].dtype == torch.bfloat16 else 2e-4) * max(1.0, float(want.abs().max()))
+            assert float((g - want).abs().max()) < tol, (t, name, float((g - want).abs().max()))
+    step = torch.full((1,), 3, dtype=torch.int64, device="cuda")
+    drop = H.Drop(0.2, 0x5eed, step)
+    with only_tile(H, 22):
+        want = forms_k1024(H, M, N, drop)
+    with only_tile(H, 33) as ot:
+        got = forms_k1024(H, M, N, drop)
+        assert ot.ran(), dict(H._TILE_CACHE)
+    for name, w_ in want.items():
+        g = got[name]
+        assert g.dtype == w_.dtype and g.shape == w_.shape
+        assert torch.equal(g, w_), (name, float((g.float() - w_.float()).abs().max()))
+
+
+def test_k1024_streaming_kernel_refuses_what_it_does_not_take(H):
+    """K != 1024, an activation epilogue or a pre-activation output: tile 33 answers EINVAL and the launch takes the
+    library's heuristic tile -- the result is still right."""
+    x = rnd(500, 512, seed=1).bfloat16().cuda()
+    w = rnd(256, 512, seed=2, scale=1 / 22).bfloat16().cuda()
+    with only_tile(H, 33) as ot:
+        y = H.linear_fwd(x, w, None)
+        assert not ot.ran()
+    assert float((y.double().cpu() - x.double().cpu() @ w.double().cpu().t()).abs().max()) < 1e-3
+    x = rnd(500, 1024, seed=1).bfloat16().cuda()
+    w = rnd(256, 1024, seed=2, scale=1 / 32).bfloat16().cuda()
+    with only_tile(H, 33) as ot:
+        y = H.linear_fwd(x, w, None, epi=H.EPI_ACT, act="silu", out_dtype=torch.bfloat16)
+        assert not ot.ran()
+    want = torch.nn.functional.silu(x.double().cpu() @ w.double().cpu().t())
+    assert float((y.double().cpu() - want).abs().max()) < 2.0 ** -7 * max(1.0, float(want.abs().max()))
