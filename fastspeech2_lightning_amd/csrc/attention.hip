@@ -523,6 +523,24 @@ extern "C" int fs2hip_attention_fwd(const float* qkv, const int* lens, float* o,
   return 0;
 }
 
+extern "C" int fs2hip_attention_bwd_spill_supported(int HD) {
+  static const bool old_only = getenv("FS2_ATTN_GEN1") != nullptr;
+  return (!old_only && (HD == 64 || HD == 128)) ? 1 : 0;
+}
+
+extern "C" int fs2hip_attention_bwd_spill(const float* qkv, const int* lens, const float* o, const float* dout,
+                                          const float* lse, float* aux, float* ds, long long ds_floats, float* dqkv, int B,
+                                          int T, int H, int HD, float drop_p, unsigned long long drop_seed,
+                                          const unsigned long long* drop_step, void* stream) {
+  if (!attn_args_ok(qkv, B, T, H, HD) || ((uintptr_t)o % 16) || ((uintptr_t)dout % 16) || ((uintptr_t)dqkv % 16) ||
+      ((uintptr_t)ds % 16) || !fs2hip_attention_bwd_spill_supported(HD))
+    return FS2HIP_EINVAL;
+  Attn2Args a2{qkv, lens, B, T, H, HD, 1.f / sqrtf((float)HD), fs2_make_drop(drop_p, drop_seed, drop_step), 0, nullptr};
+  const long long need = fs2_attn2_bwd_spill_elems(a2);
+  if (need == 0 || ds_floats < need) return FS2HIP_EINVAL;
+  return fs2_attn2_bwd_spill(a2, o, dout, lse, aux, ds, dqkv, (hipStream_t)stream);
+}
+
 extern "C" int fs2hip_attention_bwd(const float* qkv, const int* lens, const float* o, const float* dout,
                                     const float* lse, float* delta, float* dqkv, int B, int T, int H, int HD,
                                     float drop_p, unsigned long long drop_seed,

@@ -18,6 +18,12 @@ int fs2_attn2_fwd(const Attn2Args& a, float* o, float* lse, hipStream_t s);
 int fs2_attn2_bwd(const Attn2Args& a, const float* o, const float* dout, const float* lse, float* delta, float* dqkv,
                   hipStream_t s);
 
+// the same backward pass with dS spilled by the dK/dV kernel and dQ = scale * dS . K as a product of its own (fp32 MFMA
+// path); `ds` holds fs2_attn2_bwd_spill_elems(a) floats (0: this shape / operand mode does not take the path)
+long long fs2_attn2_bwd_spill_elems(const Attn2Args& a);
+int fs2_attn2_bwd_spill(const Attn2Args& a, const float* o, const float* dout, const float* lse, float* aux, float* ds,
+                        float* dqkv, hipStream_t s);
+
 // bf16-storage family (attention_bf16.hip): qkv / o / dout / dqkv are bf16 tensors of the same shapes; `a.qkv` is unused
 bool fs2_attnb_supported(int HD);
 int fs2_attnb_fwd(const Attn2Args& a, const void* qkv, void* o, float* lse, hipStream_t s);

@@ -810,11 +810,110 @@ __global__ __launch_bounds__(256, 1) void attn2_bwd_dq_kernel(Attn2Args p, const
   }
 }
 
+// dQ from the spilled dS (see attn2_bwd_dkv_kernel<.., SPILL>): dq^T[d][q] = scale * sum_key K[key][d] * dS[q][key].
+// own = 32 queries per wavefront; tiles = keys (K only: 16 KB per tile, two stages per key group = 64 KB: two workgroups per
+// CU).  A lane's sixteen weights of a key tile -- dS[q][key0 + 8 a + 4 hi + r], the accumulator layout of the other
+// kernels' S -- are four 16-byte loads from its own dS row, requested one tile ahead.
+template <int HD>
+__global__ __launch_bounds__(256, 2) void attn2_bwd_dq_ds_kernel(Attn2Args p, const float* __restrict__ ds,
+                                                                 float* __restrict__ dqkv) {
+  constexpr int NDB = HD / 32, TILE = KT * HD;
+  __shared__ __attribute__((aligned(1024))) float smem[4 * TILE];  // [key group][stage] K
+  static_assert(2 * NDB * 16 * 64 <= 4 * TILE, "parking area");
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5, l32 = lane & 31;
+  const int rb = wave & 1, kg = wave >> 1, gtid = tid & 127;
+  int qb, b, h, len;
+  work_unit(p, (p.T + 63) / 64, qb, b, h, len);
+  const int T = p.T, D = p.H * HD, ld = 3 * D, Tp32 = (T + 31) & ~31;
+  const int q = qb * 64 + rb * 32 + l32;
+  const int kend = min(T, len);
+  const int nt = (kend + KT - 1) / KT, n0 = (nt + 1) / 2;
+  const int tile0 = kg ? n0 : 0, mine = kg ? nt - n0 : n0;
+  const float* base = p.qkv + (long long)b * T * ld;
+  const __amdgpu_buffer_rsrc_t rk = make_rsrc(base + D + h * HD);
+  TileDma<HD, 128> dma;
+  dma.setup(ld, gtid);
+  float* gbuf = smem + kg * 2 * TILE;
+  if (mine > 0) dma.issue(rk, gbuf, tile0 * KT, T, ld, rb);
+  const float* dsrow = ds + (((long long)(b * p.H + h) * T + (q < T ? q : 0)) * Tp32) + 4 * hi;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 wc[4] = {zero4, zero4, zero4, zero4}, wn[4] = {zero4, zero4, zero4, zero4};
+  if (mine > 0 && q < T) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) wc[a] = *reinterpret_cast<const f32x4*>(dsrow + tile0 * KT + 8 * a);
+  }
+  f32x16 dq[NDB];
+#pragma unroll
+  for (int d = 0; d < NDB; ++d)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dq[d][i] = 0.f;
+  ColRd cr;
+  cr.setup<HD>(l32, hi);
+  const unsigned g0 = lds_addr(gbuf);
+  for (int j = 0; j < n0; ++j) {
+    const int key0 = (tile0 + j) * KT;
+    const bool act = j < mine, actn = j + 1 < mine;
+    const int st = j & 1;
+    wait_vmcnt_barrier<0>();  // tile j (and this lane's weights for it) landed; everybody is done with tile j - 1
+    if (!act) continue;
+    const unsigned kb = g0 + st * TILE * 4;
+    if (actn) {
+      dma.issue(rk, gbuf + (st ^ 1) * TILE, key0 + KT, T, ld, rb);
+      if (q < T) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) wn[a] = *reinterpret_cast<const f32x4*>(dsrow + key0 + KT + 8 * a);
+      }
+    }
+    read_mfma_stream<16 * NDB, 8>(
+        [&](auto ic, float& dst) {
+          constexpr int i = decltype(ic)::value, t = i / NDB, db = i % NDB;
+          lds_rd32<col_off<HD, t, db>()>(dst, kb + cr.base[t & 3]);
+        },
+        [&](auto ic, float v) {
+          constexpr int i = decltype(ic)::value, t = i / NDB, db = i % NDB;
+          mfma32_agpr(dq[db], v, wc[t >> 2][t & 3]);
+        });
+#pragma unroll
+    for (int a = 0; a < 4; ++a) wc[a] = wn[a];
+  }
+  mfma_drain();
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  // merge the two key groups: group 1 parks its partial dq, group 0 adds, scales and stores
+  float* park = smem + rb * NDB * 16 * 64;
+  if (kg == 1) {
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) park[(d * 16 + i) * 64 + lane] = dq[d][i];
+  }
+  __syncthreads();
+  if (kg == 0 && q < T) {
+    float* row = dqkv + ((long long)b * T + q) * ld + h * HD;
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (dq[d][4 * a + r] + park[(d * 16 + 4 * a + r) * 64 + lane]) * p.scale;
+        *reinterpret_cast<f32x4*>(row + 32 * d + 8 * a + 4 * hi) = v;
+      }
+  }
+}
+
 // dK, dV: own = 32 keys per wavefront (K' = K * scale * log2e and V in registers), tiles = queries (Q, dO rows and
 // their {lse', delta'} pairs)
-template <int HD, bool DROP, int PL>
+// SPILL (fp32 MFMA path): dS -- the kernel makes it anyway, element by element, for dK -- is also written out as
+// ds[b][h][q][key] (rows of Tp32 = T rounded up to 32 floats), and dQ = scale * dS . K becomes a product of its own
+// (attn2_bwd_dq_ds_kernel) instead of a second kernel that recomputes S, dP and the softmax arithmetic: 5 products per
+// (32 x 32) block instead of 9 in the two gradient kernels together, and the vector work of the recomputation -- which
+// on this chip is added to the fp32 MFMA time -- is gone.  One 4-byte store per lane and step: a step's 32 keys of one
+// query row are 128 contiguous bytes.
+template <int HD, bool DROP, int PL, bool SPILL = false>
 __global__ __launch_bounds__(256, 1) void attn2_bwd_dkv_kernel(Attn2Args p, const float* __restrict__ dout,
-                                                               const float2* __restrict__ aux, float* __restrict__ dqkv) {
+                                                               const float2* __restrict__ aux, float* __restrict__ dqkv,
+                                                               float* __restrict__ ds = nullptr) {
+  static_assert(!SPILL || PL == 0, "dS is spilled by the fp32 MFMA path only");
   constexpr int NJ = HD / 8, NDB = HD / 32, TILE = KT * HD, NP = TileDma<HD, 128>::NP, STAGE = 2 * TILE + 256;
   __shared__ __attribute__((aligned(1024))) float smem[4 * STAGE];  // [query group][stage][Q | dO | aux (1 KB)]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5, l32 = lane & 31;
@@ -903,6 +1002,11 @@ __global__ __launch_bounds__(256, 1) void attn2_bwd_dkv_kernel(Attn2Args p, cons
   const uint32_t Tp = (uint32_t)(T + (T & 1));
   const uint32_t head0 = (uint32_t)((unsigned long long)(b * p.H + h) * T) * Tp;  // (wraps like the other kernels' 32-bit index)
   const int sh16 = 16 * (key & 1);
+  // dS slab of this (utterance, head): [T][Tp32]; rows past T fall to the range check, keys past Tp32 carry the sentinel
+  const int Tp32 = (T + 31) & ~31;
+  const __amdgpu_buffer_rsrc_t rds = __builtin_amdgcn_make_buffer_rsrc(
+      SPILL ? (void*)(ds + ((long long)(b * p.H + h) * T) * Tp32) : (void*)dqkv, 0, SPILL ? T * Tp32 * 4 : 0, 0x00020000);
+  const int ds_voff = key < Tp32 ? (4 * hi * Tp32 + key) * 4 : FS2_OOB;
   RowRd rd;
   rd.setup<HD>(l32, hi);
   ColRd cr;
@@ -914,7 +1018,8 @@ __global__ __launch_bounds__(256, 1) void attn2_bwd_dkv_kernel(Attn2Args p, cons
     const bool act = j < mine, actn = j + 1 < mine;
     const int st = j & 1;
     STAMP(0)
-    wait_vmcnt_barrier<0>();
+    // tile j landed for everybody; the sixteen dS stores of the previous tile are younger than its DMA and may stay in flight
+    if (SPILL && j > 0) wait_vmcnt_barrier<16>(); else wait_vmcnt_barrier<0>();
     STAMP(1)
     if (!act) continue;
     const unsigned qb_ = g0 + st * STAGE * 4, ob = qb_ + TILE * 4, ab = ob + TILE * 4;
@@ -959,6 +1064,9 @@ __global__ __launch_bounds__(256, 1) void attn2_bwd_dkv_kernel(Attn2Args p, cons
       }
       wv = pd;
       wk = fmaf(-pp, axs[t & 1].y, pd * dp[t]);
+      if constexpr (SPILL)  // dS[q0 + 8 (t >> 2) + 4 hi + (t & 3)][key]
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, wk), rds, ds_voff,
+                                              (q0 + 8 * (t >> 2) + (t & 3)) * Tp32 * 4, 0);
     };
     if constexpr (PL == 0) {
       aux_read(std::integral_constant<int, 0>{});
@@ -1097,6 +1205,37 @@ int fs2_attn2_bwd(const Attn2Args& a, const float* o, const float* dout, const f
   }
 #undef FS2_ATTN2_BWD_PL
 #undef FS2_ATTN2_BWD
+  FS2_LAUNCH_CHECK();
+  return 0;
+}
+
+// The backward pass with dS spilled by the dK/dV kernel and dQ as a product of its own (fp32 MFMA path only: the caller
+// checks fs2_attn2_bwd_spill_elems first).  `ds`: B * H * T * (T rounded up to 32) floats of scratch.
+long long fs2_attn2_bwd_spill_elems(const Attn2Args& a) {
+  if (a.planes != 0 || (a.HD != 64 && a.HD != 128)) return 0;
+  const long long n = (long long)a.B * a.H * a.T * ((a.T + 31) & ~31);
+  return n * 4 < 0x7fffffffLL * 16 ? n : 0;
+}
+int fs2_attn2_bwd_spill(const Attn2Args& a, const float* o, const float* dout, const float* lse, float* aux, float* ds,
+                        float* dqkv, hipStream_t s) {
+  if ((double)a.B * a.H * a.T * (a.T + (a.T & 1)) >= 4294967296.0 || fs2_attn2_bwd_spill_elems(a) == 0) return FS2HIP_EINVAL;
+  if ((long long)a.T * ((a.T + 31) & ~31) * 4 >= 0x7fffffffLL) return FS2HIP_EINVAL;  // one (utterance, head) slab per resource
+  const float dscale = a.drop.on ? a.drop.scale : 1.f;
+  attn2_prep_kernel<<<dim3((a.B * a.T + 3) / 4), dim3(256), 0, s>>>(dout, o, lse, reinterpret_cast<float2*>(aux), a.B, a.T,
+                                                                     a.H, a.HD, log2f(dscale), 1.f / dscale);
+  FS2_LAUNCH_CHECK();
+  dim3 grid(((a.T + 63) / 64) * a.H * a.B);
+  const float2* ax = reinterpret_cast<const float2*>(aux);
+#define FS2_ATTN2_SPILL(HD_, DROP_)                                                                   \
+  attn2_bwd_dkv_kernel<HD_, DROP_, 0, true><<<grid, dim3(256), 0, s>>>(a, dout, ax, dqkv, ds);        \
+  FS2_LAUNCH_CHECK();                                                                                 \
+  attn2_bwd_dq_ds_kernel<HD_><<<grid, dim3(256), 0, s>>>(a, ds, dqkv);
+  if (a.HD == 128) {
+    if (a.drop.on) { FS2_ATTN2_SPILL(128, true) } else { FS2_ATTN2_SPILL(128, false) }
+  } else {
+    if (a.drop.on) { FS2_ATTN2_SPILL(64, true) } else { FS2_ATTN2_SPILL(64, false) }
+  }
+#undef FS2_ATTN2_SPILL
   FS2_LAUNCH_CHECK();
   return 0;
 }

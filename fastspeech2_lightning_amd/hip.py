@@ -69,6 +69,8 @@ SIGNATURES = {
     "fs2hip_dwconv_bwd_b": "ppippipppiiiiip",
     "fs2hip_attention_fwd": "ppppiiiifQpip",
     "fs2hip_attention_bwd": "pppppppiiiifQpip",
+    "fs2hip_attention_bwd_spill_supported": "i",
+    "fs2hip_attention_bwd_spill": "pppppppqpiiiifQpp",
     "fs2hip_attention_fwd_b": "ppppiiiifQpp",
     "fs2hip_attention_bwd_b": "pppppppiiiifQpp",
     "fs2hip_attention_b_supported": "i",
@@ -956,6 +958,21 @@ def attention_fwd(qkv, lens, B, T, H, drop: Drop = NO_DROP):
     return o, lse
 
 
+#: FS2_ATTN_SPILL=0: the fp32 attention backward recomputes S and dP in both gradient kernels (the round-2 structure)
+ATTN_SPILL = os.environ.get("FS2_ATTN_SPILL", "1") != "0"
+_SCRATCH = {}
+
+
+def reserve_scratch(name, floats):
+    """A float32 scratch buffer per (name, device, stream) that only grows: contents are dead between the launches of one
+    call, and calls on one stream are ordered."""
+    key = (name, _current_device(), _stream())
+    t = _SCRATCH.get(key)
+    if t is None or t.numel() < floats:
+        t = _SCRATCH[key] = torch.empty(int(floats), device="cuda", dtype=torch.float32)
+    return t
+
+
 def attention_bwd(qkv, lens, o, dout, lse, B, T, H, drop: Drop = NO_DROP):
     for n, t in (("qkv", qkv), ("o", o), ("dout", dout), ("lse", lse)):
         _chk(t, name=n)
@@ -965,6 +982,14 @@ def attention_bwd(qkv, lens, o, dout, lse, B, T, H, drop: Drop = NO_DROP):
          and lens.numel() == B, "attention_bwd: shape mismatch")
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(2 * lse.numel() + 4, device=lse.device, dtype=torch.float32)  # scratch: see fs2hip.h
+    if GEMM_BF16 in (0, 2) and ATTN_SPILL and lib().fs2hip_attention_bwd_spill_supported(D // H):
+        # exact fp32 and "32-split" (whose dK/dV kernel is the fp32 one): the dK/dV kernel writes dS out and dQ is a product
+        # of its own on the fp32 MFMAs (5 products per block instead of 9)
+        n = B * H * T * ((T + 31) // 32 * 32)
+        ds = reserve_scratch("attn_ds", n)
+        _ok(lib().fs2hip_attention_bwd_spill(_p(qkv), _p(lens), _p(o), _p(dout), _p(lse), _p(delta), _p(ds), n, _p(dqkv), B, T, H,
+                                             D // H, drop.p, drop.seed, drop.step_ptr, _stream()), "attention_bwd_spill")
+        return dqkv
     _ok(lib().fs2hip_attention_bwd(_p(qkv), _p(lens), _p(o), _p(dout), _p(lse), _p(delta), _p(dqkv), B, T, H, D // H,
                                    drop.p, drop.seed, drop.step_ptr, int(GEMM_BF16), _stream()), "attention_bwd")
     return dqkv

@@ -228,6 +228,18 @@ int fs2hip_attention_bwd(const float* qkv, const int* lens, const float* o, cons
                          float drop_p, unsigned long long drop_seed,
                          const unsigned long long* drop_step, int operand_bf16, void* stream);
 
+/* The fp32 backward pass (operand_bf16 = 0) with dS written out by the dK/dV kernel and dQ = scale * dS . K as a product
+ * of its own -- 5 products per block instead of the 9 of two kernels that each recompute S and dP.
+ * Head dims for which fs2hip_attention_bwd_spill_supported() returns 1 (64, 128).
+ *   aux: 2*B*H*T + 4 floats; ds: scratch of at least B*H*T*(T rounded up to 32) floats (ds_floats = its size).
+ * Same results as fs2hip_attention_bwd up to the rounding of S (the scale is folded into K there, into Q in the
+ * recomputing dQ kernel). */
+int fs2hip_attention_bwd_spill_supported(int HD);
+int fs2hip_attention_bwd_spill(const float* qkv, const int* lens, const float* o, const float* dout,
+                               const float* lse, float* aux, float* ds, long long ds_floats, float* dqkv,
+                               int B, int T, int H, int HD, float drop_p, unsigned long long drop_seed,
+                               const unsigned long long* drop_step, void* stream);
+
 /* The same attention on tensors that ARE bf16 in memory (precision "bf16-mixed" with bf16 activation
  * storage; torch.autocast(bfloat16) around nn.MultiheadAttention, call sites fs2/model.py:193, :241):
  * qkv, o, dout, dqkv are bf16 with the shapes above, lse and the scratch `aux` (2*B*H*T + 4 floats)

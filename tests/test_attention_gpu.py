@@ -160,3 +160,33 @@ def test_attention_plane_modes_share_the_dropout_mask(H, precision, tol, T, hd):
     assert eo < tol and eg < tol, (eo, eg)
     if precision == "bf16-mixed":
         assert eo > 1e-4, "bf16 operands requested, fp32-exact result"
+
+
+@pytest.mark.parametrize("B,T,Hh,hd,lens", [
+    (1, 1, 2, 128, [1]), (2, 5, 2, 64, [5, 2]), (2, 31, 2, 128, [31, 17]), (3, 130, 2, 128, [130, 64, 1]),
+    (2, 200, 1, 64, [200, 33]), (4, 648, 2, 128, [648, 500, 40, 333]),
+    (32, 648, 2, 128, [648, 430, 40] + [430 + 7 * i for i in range(29)]),
+])
+def test_spilled_ds_backward_equals_the_recomputing_backward(H, B, T, Hh, hd, lens, monkeypatch):
+    """``fs2hip_attention_bwd_spill`` (default in "32-true"): the dK/dV kernel writes dS out, dQ = scale * dS . K is its own
+    product.  dK and dV are the recomputing kernels' bit for bit (same kernel, one store more); dQ differs only by the rounding
+    of S (scale folded into K instead of Q): 2e-5 of its scale -- with attention dropout on, ragged lengths, T not a multiple of
+    the tile, utterances shorter than one key tile."""
+    g = torch.Generator().manual_seed(B * 77 + T)
+    D = Hh * hd
+    qkv = torch.randn(B, T, 3 * D, generator=g).cuda()
+    dout = torch.randn(B, T, D, generator=g).cuda()
+    lens_t = torch.tensor(lens, dtype=torch.int32).cuda()
+    assert H.GEMM_BF16 == 0 and H.lib().fs2hip_attention_bwd_spill_supported(hd) == 1
+    for drop in (H.NO_DROP, H.Drop(0.2, 1234)):
+        o, lse = H.attention_fwd(qkv, lens_t, B, T, Hh, drop)
+        monkeypatch.setattr(H, "ATTN_SPILL", False)
+        want = H.attention_bwd(qkv, lens_t, o, dout, lse, B, T, Hh, drop)
+        monkeypatch.setattr(H, "ATTN_SPILL", True)
+        H._SCRATCH.clear()
+        got = H.attention_bwd(qkv, lens_t, o, dout, lse, B, T, Hh, drop)
+        assert torch.isfinite(got).all()
+        assert torch.equal(got[..., D:], want[..., D:]), "dK / dV changed"
+        scale = float(want.abs().max())  # (the whole gradient's scale: with one key dQ is zero up to the rounding of p * dP - p * delta)
+        err = float((got[..., :D] - want[..., :D]).abs().max())
+        assert err < 2e-5 * scale, (drop.p, err, scale)
