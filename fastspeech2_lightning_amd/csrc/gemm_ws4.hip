@@ -16,8 +16,11 @@
 //     sit on one XCD and share its L2;
 //   * vector-memory bookkeeping is by hand (counted s_waitcnt vmcnt, no compiler-visible memory access in the loop), and
 //     so are the MFMA hazards the compiler cannot see through inline asm (wait states after the last MFMA of a tile).
-// One wavefront per SIMD: the epilogue's vector work is not hidden behind another wavefront's MFMAs (it is ~a quarter of a
-// row tile's MFMA time with dropout on); what is bought is the register file for W.
+// One wavefront per SIMD: the epilogue's vector work and the DMA issue are not hidden behind another wavefront's MFMAs; what
+// is bought is the register file for W.  (A two-role form -- eight wavefronts, the two of a SIMD splitting K and handing the
+// accumulator over through LDS, so that one always feeds the matrix pipe -- was built, is bit-identical, and runs exactly as
+// fast: tools/probes/gemm_ws4_two_role.hip.txt.  Whatever bounds this kernel at ~3.7 TB/s of operand + result traffic, it is
+// not what a single wavefront per SIMD fails to overlap.)
 // Epilogues, dropout masks and rounding are those of gemm_bf16_core.h, element for element.
 #include "gemm_bf16_core.h"
 #include "gemm_ws_util.h"
