@@ -93,14 +93,23 @@ def test_automatic_optimization_reproduces_the_native_steps(clip):
     else:
         # torch's clip_grad_norm_ rounds its coefficient differently (last bit), so weights differ by ~1e-7 after a
         # step -- and a parameter whose TRUE gradient is zero (a bias in front of a BatchNorm: depthwise-conv and
-        # PostNet conv biases) has only rounding noise for a gradient, which Adam normalises to steps of +-lr whose
-        # sign is chaotic.  Those tensors are held to "moved by at most the five learning rates"; everything else to 2e-6.
+        # PostNet conv biases; the key third of an attention in-projection bias) has only rounding noise for a gradient,
+        # which Adam normalises to steps of +-lr whose sign is chaotic.  Those are held to "moved by at most the five
+        # learning rates"; everything else to 2e-6.
         sd, sd_ref, g = model.state_dict(), ref_model.state_dict(), ref_model.store.grad_state_dict()
         gmax = max(float(v.abs().max()) for v in g.values())
         lr_sum = sum(lrs)
         checked = 0
         for k, v in g.items():
-            d = float((sd[k] - sd_ref[k]).abs().max())
+            diff = (sd[k] - sd_ref[k]).abs()
+            if k.endswith("self_attn.in_proj_bias"):
+                # the KEY third of the attention in-projection bias is such a parameter too: a constant added to every key
+                # shifts all of a query's scores alike and cancels in the softmax, so its true gradient is zero and what the
+                # kernels produce is the rounding of dK's column sums
+                n = v.numel() // 3
+                assert float(diff[n:2 * n].max()) <= 2.0 * lr_sum, (k, float(diff[n:2 * n].max()))
+                diff = torch.cat([diff[:n], diff[2 * n:]])
+            d = float(diff.max())
             if float(v.abs().max()) < 1e-5 * gmax:
                 assert d <= 2.0 * lr_sum, (k, d)
             else:
