@@ -166,6 +166,7 @@ def test_attention_plane_modes_share_the_dropout_mask(H, precision, tol, T, hd):
     (1, 1, 2, 128, [1]), (2, 5, 2, 64, [5, 2]), (2, 31, 2, 128, [31, 17]), (3, 130, 2, 128, [130, 64, 1]),
     (2, 200, 1, 64, [200, 33]), (4, 648, 2, 128, [648, 500, 40, 333]),
     (32, 648, 2, 128, [648, 430, 40] + [430 + 7 * i for i in range(29)]),
+    (3, 1291, 2, 128, [1291, 700, 64]),  # BASELINE configs[4]'s longest utterance: 41 key tiles, a 6.8 MB dS slab per head
 ])
 def test_spilled_ds_backward_equals_the_recomputing_backward(H, B, T, Hh, hd, lens, monkeypatch):
     """``fs2hip_attention_bwd_spill`` (default in "32-true"): the dK/dV kernel writes dS out, dQ = scale * dS . K is its own
