@@ -523,6 +523,24 @@ extern "C" int fs2hip_attention_fwd(const float* qkv, const int* lens, float* o,
   return 0;
 }
 
+// The forward pass that also writes the masked scores out (fp32 MFMA path, head dims 64 / 128) for
+// fs2hip_attention_bwd_spill_s: `scores` holds at least B * H * T * (T rounded up to 32) floats.
+extern "C" int fs2hip_attention_fwd_s(const float* qkv, const int* lens, float* o, float* lse, float* scores,
+                                      long long score_floats, int B, int T, int H, int HD, float drop_p,
+                                      unsigned long long drop_seed, const unsigned long long* drop_step, void* stream) {
+  if (!attn_args_ok(qkv, B, T, H, HD) || ((uintptr_t)o % 16) || ((uintptr_t)scores % 16) || !scores) return FS2HIP_EINVAL;
+  static const bool old_only = getenv("FS2_ATTN_GEN1") != nullptr;
+  if (old_only || (HD != 64 && HD != 128)) return FS2HIP_EINVAL;
+  if (score_floats < (long long)B * H * T * ((T + 31) & ~31)) return FS2HIP_EINVAL;
+  Attn2Args a2{qkv, lens, B, T, H, HD, 1.f / sqrtf((float)HD), fs2_make_drop(drop_p, drop_seed, drop_step), 0, nullptr};
+  return fs2_attn2_fwd(a2, o, lse, (hipStream_t)stream, scores);
+}
+
+extern "C" int fs2hip_attention_bwd_spill_s(const float* qkv, const int* lens, const float* o, const float* dout,
+                                            const float* lse, const float* scores, float* aux, float* ds, long long ds_floats,
+                                            float* dqkv, int B, int T, int H, int HD, float drop_p,
+                                            unsigned long long drop_seed, const unsigned long long* drop_step, void* stream);
+
 extern "C" int fs2hip_attention_bwd_spill_supported(int HD) {
   static const bool old_only = getenv("FS2_ATTN_GEN1") != nullptr;
   return (!old_only && (HD == 64 || HD == 128)) ? 1 : 0;
@@ -563,4 +581,19 @@ extern "C" int fs2hip_attention_bwd(const float* qkv, const int* lens, const flo
   ATTN_DISPATCH(HD, operand_bf16 == 1, (attn_bwd_dkv_kernel<HDc, BFc><<<grid, dim3(256), 0, s>>>(p, dout, lse, delta, dqkv)));
   FS2_LAUNCH_CHECK();
   return 0;
+}
+
+// fs2hip_attention_bwd_spill with the scores of fs2hip_attention_fwd_s: the dK/dV kernel reads them instead of recomputing
+// K.Q^T (3 products instead of 4, the forward pass's probabilities to the bit)
+extern "C" int fs2hip_attention_bwd_spill_s(const float* qkv, const int* lens, const float* o, const float* dout,
+                                            const float* lse, const float* scores, float* aux, float* ds, long long ds_floats,
+                                            float* dqkv, int B, int T, int H, int HD, float drop_p,
+                                            unsigned long long drop_seed, const unsigned long long* drop_step, void* stream) {
+  if (!attn_args_ok(qkv, B, T, H, HD) || ((uintptr_t)o % 16) || ((uintptr_t)dout % 16) || ((uintptr_t)dqkv % 16) ||
+      ((uintptr_t)ds % 16) || ((uintptr_t)scores % 16) || !scores || !fs2hip_attention_bwd_spill_supported(HD))
+    return FS2HIP_EINVAL;
+  Attn2Args a2{qkv, lens, B, T, H, HD, 1.f / sqrtf((float)HD), fs2_make_drop(drop_p, drop_seed, drop_step), 0, nullptr};
+  const long long need = fs2_attn2_bwd_spill_elems(a2);
+  if (need == 0 || ds_floats < need) return FS2HIP_EINVAL;
+  return fs2_attn2_bwd_spill(a2, o, dout, lse, aux, ds, dqkv, (hipStream_t)stream, scores);
 }

@@ -14,7 +14,8 @@ struct Attn2Args {
 
 // true when the second-generation kernels take the shape (HD in {64, 128}; operand_bf16: 0 fp32, 1 bf16, 2 split)
 bool fs2_attn2_supported(int HD, int operand_bf16);
-int fs2_attn2_fwd(const Attn2Args& a, float* o, float* lse, hipStream_t s);
+// s_out (fp32 MFMA path, may be null): the masked scores for fs2_attn2_bwd_spill's s_in, B * H * T * (T rounded up to 32) floats
+int fs2_attn2_fwd(const Attn2Args& a, float* o, float* lse, hipStream_t s, float* s_out = nullptr);
 int fs2_attn2_bwd(const Attn2Args& a, const float* o, const float* dout, const float* lse, float* delta, float* dqkv,
                   hipStream_t s);
 
@@ -22,7 +23,7 @@ int fs2_attn2_bwd(const Attn2Args& a, const float* o, const float* dout, const f
 // path); `ds` holds fs2_attn2_bwd_spill_elems(a) floats (0: this shape / operand mode does not take the path)
 long long fs2_attn2_bwd_spill_elems(const Attn2Args& a);
 int fs2_attn2_bwd_spill(const Attn2Args& a, const float* o, const float* dout, const float* lse, float* aux, float* ds,
-                        float* dqkv, hipStream_t s);
+                        float* dqkv, hipStream_t s, const float* s_in = nullptr);
 
 // bf16-storage family (attention_bf16.hip): qkv / o / dout / dqkv are bf16 tensors of the same shapes; `a.qkv` is unused
 bool fs2_attnb_supported(int HD);

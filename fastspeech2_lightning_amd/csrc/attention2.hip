@@ -444,8 +444,14 @@ struct SoftmaxWeights {
 // -> the next V tile's DMA starts and lands under K.Q^T + softmax) and barrier Y (start of P.V; everybody is done
 // with the K tile -> the next K tile's DMA starts and lands under P.V).
 // ------------------------------------------------------------------------------------------------------------
-template <int HD, bool DROP, int PL>
-__global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(Attn2Args p, float* __restrict__ o, float* __restrict__ lse) {
+// SS (fp32 MFMA path, training): the masked scores -- log2 units, scale folded in -- are also written out as
+// s_out[b][h][q][key] (rows of Tp32 = T rounded up to 32 floats) for the dK/dV kernel, which then needs neither the S product
+// nor its own K rows (attn2_bwd_dkv_kernel<.., SIN>).  Four 16-byte stores per lane and key tile, younger than the V tile's
+// DMA: the barrier behind the row maximum waits with vmcnt(4).
+template <int HD, bool DROP, int PL, bool SS = false>
+__global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(Attn2Args p, float* __restrict__ o, float* __restrict__ lse,
+                                                           float* __restrict__ s_out = nullptr) {
+  static_assert(!SS || PL == 0, "scores are written out by the fp32 MFMA path only");
   constexpr int NJ = HD / 8, NDB = HD / 32;
   // K tile, V tile of key group 0; then of group 1: 64 KB, two workgroups per CU.  (fp32 MFMAs and fp32 vector
   // instructions share the arithmetic, so the second wavefront per SIMD overlaps no arithmetic -- but it does cover
@@ -503,6 +509,10 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(Attn2Args p, float* _
   ColRd cr;
   cr.setup<HD>(l32, hi);
   const unsigned ks = lds_addr(Kt), vs = lds_addr(Vt);
+  const int Tp32 = (T + 31) & ~31;
+  const __amdgpu_buffer_rsrc_t rss = __builtin_amdgcn_make_buffer_rsrc(
+      SS ? (void*)(s_out + ((long long)(b * p.H + h) * T) * Tp32) : (void*)o, 0, SS ? T * Tp32 * 4 : 0, 0x00020000);
+  const int ss_voff = q < T ? (q * Tp32 + 4 * hi) * 4 : FS2_OOB;
   STAMP_DECL;
   for (int j = 0; j < n0; ++j) {
     const int key0 = (tile0 + j) * KT;
@@ -529,6 +539,13 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(Attn2Args p, float* _
         for (int i = 0; i < 16; ++i)
           if (key0 + 8 * (i >> 2) + 4 * hi + (i & 3) >= len) s[i] = -INFINITY;
       }
+      if constexpr (SS) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const f32x4 v = {s[4 * a], s[4 * a + 1], s[4 * a + 2], s[4 * a + 3]};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rss, ss_voff, (key0 + 8 * a) * 4, 0);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[i]);
       mx = pair_max(mx);
@@ -544,7 +561,8 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(Attn2Args p, float* _
       }
     }
     STAMP(3)  // row maximum
-    wait_vmcnt_barrier<0>();    // Y: the V tile landed everywhere, and the K tile is free
+    // Y: the V tile landed everywhere, and the K tile is free (SS: the four score stores are younger than its DMA)
+    if (SS && act) wait_vmcnt_barrier<4>(); else wait_vmcnt_barrier<0>();
     STAMP(4)  // wait at Y
     if (act) {
       if (actn) dma.issue(rk, Kt, key0 + KT, T, ld, rb);
@@ -610,6 +628,10 @@ __global__ __launch_bounds__(256) void attn2_prep_kernel(const float* __restrict
                                                          int T, int H, int HD, float lg_dscale, float inv_dscale) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // The two pairs of slack behind the last row: the dK/dV kernel fetches pairs two at a time, and with T odd the last
+  // piece of the last (utterance, head) reads one pair past the end.  Its row is padding (dO = 0 there), but 0 * NaN is
+  // NaN: the slack must hold numbers, not whatever the allocator left (seen with poisoned memory: NaN gradients).
+  if (blockIdx.x == 0 && threadIdx.x < 2) aux[(long long)B * H * T + threadIdx.x] = make_float2(0.f, 0.f);
   if (row >= B * T) return;
   const int D = H * HD, f4 = D / 4, per_head = HD / 4;
   const int b = row / T, t = row % T;
@@ -909,11 +931,17 @@ __global__ __launch_bounds__(256, 2) void attn2_bwd_dq_ds_kernel(Attn2Args p, co
 // (32 x 32) block instead of 9 in the two gradient kernels together, and the vector work of the recomputation -- which
 // on this chip is added to the fp32 MFMA time -- is gone.  One 4-byte store per lane and step: a step's 32 keys of one
 // query row are 128 contiguous bytes.
-template <int HD, bool DROP, int PL, bool SPILL = false>
+// SIN (with SPILL): the scores come from memory -- s_in[b][h][q][key], written by attn2_fwd_kernel<.., SS> -- instead of from
+// a K.Q^T product of this kernel's own: 3 products per block instead of 4, no own K rows in registers, and the
+// probabilities are the forward pass's to the bit.  A tile's sixteen scores per lane are requested right behind the tile
+// barrier and used behind the dP product.
+template <int HD, bool DROP, int PL, bool SPILL = false, bool SIN = false>
 __global__ __launch_bounds__(256, 1) void attn2_bwd_dkv_kernel(Attn2Args p, const float* __restrict__ dout,
                                                                const float2* __restrict__ aux, float* __restrict__ dqkv,
-                                                               float* __restrict__ ds = nullptr) {
+                                                               float* __restrict__ ds = nullptr,
+                                                               const float* __restrict__ s_in = nullptr) {
   static_assert(!SPILL || PL == 0, "dS is spilled by the fp32 MFMA path only");
+  static_assert(!SIN || SPILL, "scores from memory: only in the spilled-dS form");
   constexpr int NJ = HD / 8, NDB = HD / 32, TILE = KT * HD, NP = TileDma<HD, 128>::NP, STAGE = 2 * TILE + 256;
   __shared__ __attribute__((aligned(1024))) float smem[4 * STAGE];  // [query group][stage][Q | dO | aux (1 KB)]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5, l32 = lane & 31;
@@ -970,10 +998,10 @@ __global__ __launch_bounds__(256, 1) void attn2_bwd_dkv_kernel(Attn2Args p, cons
     for (int j = 0; j < NJ; ++j) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f}, w = {0.f, 0.f, 0.f, 0.f};
       if (key < T) {
-        v = *reinterpret_cast<const f32x4*>(base + (long long)key * ld + D + h * HD + 8 * j + 4 * hi);
+        if constexpr (!SIN) v = *reinterpret_cast<const f32x4*>(base + (long long)key * ld + D + h * HD + 8 * j + 4 * hi);
         w = *reinterpret_cast<const f32x4*>(base + (long long)key * ld + 2 * D + h * HD + 8 * j + 4 * hi);
       }
-      kv[j] = to_agpr(v * kscale);
+      if constexpr (!SIN) kv[j] = to_agpr(v * kscale);
       vv[j] = to_agpr(w);
     }
   } else {
@@ -1007,6 +1035,8 @@ __global__ __launch_bounds__(256, 1) void attn2_bwd_dkv_kernel(Attn2Args p, cons
   const __amdgpu_buffer_rsrc_t rds = __builtin_amdgcn_make_buffer_rsrc(
       SPILL ? (void*)(ds + ((long long)(b * p.H + h) * T) * Tp32) : (void*)dqkv, 0, SPILL ? T * Tp32 * 4 : 0, 0x00020000);
   const int ds_voff = key < Tp32 ? (4 * hi * Tp32 + key) * 4 : FS2_OOB;
+  const __amdgpu_buffer_rsrc_t rsi = __builtin_amdgcn_make_buffer_rsrc(
+      SIN ? (void*)(s_in + ((long long)(b * p.H + h) * T) * Tp32) : (void*)dqkv, 0, SIN ? T * Tp32 * 4 : 0, 0x00020000);
   RowRd rd;
   rd.setup<HD>(l32, hi);
   ColRd cr;
@@ -1039,11 +1069,26 @@ __global__ __launch_bounds__(256, 1) void attn2_bwd_dkv_kernel(Attn2Args p, cons
       }
     };
     f32x16 s, dp;
-    if constexpr (PL == 0) s = dot_rows<HD, true>(rd, qb_, kv, qdma);
-    else s = dot_rows_pl<HD, PL>(l32, hi, qb_, kp, qdma);
-    STAMP(2)
-    if constexpr (PL == 0) dp = dot_rows<HD, true>(rd, ob, vv, odma);
-    else dp = dot_rows_pl<HD, PL>(l32, hi, ob, vp, odma);
+    if constexpr (SIN) {
+      // S[q0 + 8 (t >> 2) + 4 hi + (t & 3)][key]: the layout of the dS stores below; rows past T and keys past Tp32 read zeros
+      // (such keys are masked by key_ok, such rows' gradients are never stored)
+      sfor<16>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        s[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsi, ds_voff, (q0 + 8 * (t >> 2) + (t & 3)) * Tp32 * 4, 0));
+      });
+      // both operand tiles' DMA pieces go out under the one product that is left in front of the gradient stream
+      auto qodma = [&](auto jc) {
+        qdma(jc);
+        odma(jc);
+      };
+      dp = dot_rows<HD, true>(rd, ob, vv, qodma);
+    } else {
+      if constexpr (PL == 0) s = dot_rows<HD, true>(rd, qb_, kv, qdma);
+      else s = dot_rows_pl<HD, PL>(l32, hi, qb_, kp, qdma);
+      STAMP(2)
+      if constexpr (PL == 0) dp = dot_rows<HD, true>(rd, ob, vv, odma);
+      else dp = dot_rows_pl<HD, PL>(l32, hi, ob, vp, odma);
+    }
     STAMP(3)
     const uint32_t rowkey = head0 + (uint32_t)(q0 + 4 * hi) * Tp + (uint32_t)key;  // element index of (row q0 + 4hi, own key)
     float wv = 0.f, wk = 0.f;
@@ -1157,14 +1202,16 @@ __global__ __launch_bounds__(256, 1) void attn2_bwd_dkv_kernel(Attn2Args p, cons
 
 bool fs2_attn2_supported(int HD, int operand_bf16) { return (operand_bf16 >= 0 && operand_bf16 <= 2) && (HD == 64 || HD == 128); }
 
-int fs2_attn2_fwd(const Attn2Args& a, float* o, float* lse, hipStream_t s) {
+int fs2_attn2_fwd(const Attn2Args& a, float* o, float* lse, hipStream_t s, float* s_out) {
   // 32-bit dropout element index; the mask's rows are padded to an even length (one hash serves two neighbouring keys),
   // so the index stride is T + (T & 1) -- the same bound in the forward and the backward launcher
   if ((double)a.B * a.H * a.T * (a.T + (a.T & 1)) >= 4294967296.0) return FS2HIP_EINVAL;
   dim3 grid(((a.T + 63) / 64) * a.H * a.B);
+  if (s_out && (a.planes != 0 || (long long)a.T * ((a.T + 31) & ~31) * 4 >= 0x7fffffffLL)) return FS2HIP_EINVAL;
 #define FS2_ATTN2_FWD(HD_, DROP_)                                                                 \
   if (a.planes == 3) attn2_fwd_kernel<HD_, DROP_, 3><<<grid, dim3(256), 0, s>>>(a, o, lse);         \
   else if (a.planes == 1) attn2_fwd_kernel<HD_, DROP_, 1><<<grid, dim3(256), 0, s>>>(a, o, lse);    \
+  else if (s_out) attn2_fwd_kernel<HD_, DROP_, 0, true><<<grid, dim3(256), 0, s>>>(a, o, lse, s_out); \
   else attn2_fwd_kernel<HD_, DROP_, 0><<<grid, dim3(256), 0, s>>>(a, o, lse);
   if (a.HD == 128) {
     if (a.drop.on) { FS2_ATTN2_FWD(128, true) } else { FS2_ATTN2_FWD(128, false) }
@@ -1217,7 +1264,7 @@ long long fs2_attn2_bwd_spill_elems(const Attn2Args& a) {
   return n * 4 < 0x7fffffffLL * 16 ? n : 0;
 }
 int fs2_attn2_bwd_spill(const Attn2Args& a, const float* o, const float* dout, const float* lse, float* aux, float* ds,
-                        float* dqkv, hipStream_t s) {
+                        float* dqkv, hipStream_t s, const float* s_in) {
   if ((double)a.B * a.H * a.T * (a.T + (a.T & 1)) >= 4294967296.0 || fs2_attn2_bwd_spill_elems(a) == 0) return FS2HIP_EINVAL;
   if ((long long)a.T * ((a.T + 31) & ~31) * 4 >= 0x7fffffffLL) return FS2HIP_EINVAL;  // one (utterance, head) slab per resource
   const float dscale = a.drop.on ? a.drop.scale : 1.f;
@@ -1226,9 +1273,10 @@ int fs2_attn2_bwd_spill(const Attn2Args& a, const float* o, const float* dout, c
   FS2_LAUNCH_CHECK();
   dim3 grid(((a.T + 63) / 64) * a.H * a.B);
   const float2* ax = reinterpret_cast<const float2*>(aux);
-#define FS2_ATTN2_SPILL(HD_, DROP_)                                                                   \
-  attn2_bwd_dkv_kernel<HD_, DROP_, 0, true><<<grid, dim3(256), 0, s>>>(a, dout, ax, dqkv, ds);        \
-  FS2_LAUNCH_CHECK();                                                                                 \
+#define FS2_ATTN2_SPILL(HD_, DROP_)                                                                              \
+  if (s_in) attn2_bwd_dkv_kernel<HD_, DROP_, 0, true, true><<<grid, dim3(256), 0, s>>>(a, dout, ax, dqkv, ds, s_in); \
+  else attn2_bwd_dkv_kernel<HD_, DROP_, 0, true><<<grid, dim3(256), 0, s>>>(a, dout, ax, dqkv, ds);                  \
+  FS2_LAUNCH_CHECK();                                                                                            \
   attn2_bwd_dq_ds_kernel<HD_><<<grid, dim3(256), 0, s>>>(a, ds, dqkv);
   if (a.HD == 128) {
     if (a.drop.on) { FS2_ATTN2_SPILL(128, true) } else { FS2_ATTN2_SPILL(128, false) }

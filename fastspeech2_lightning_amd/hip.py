@@ -71,6 +71,8 @@ SIGNATURES = {
     "fs2hip_attention_bwd": "pppppppiiiifQpip",
     "fs2hip_attention_bwd_spill_supported": "i",
     "fs2hip_attention_bwd_spill": "pppppppqpiiiifQpp",
+    "fs2hip_attention_fwd_s": "pppppqiiiifQpp",
+    "fs2hip_attention_bwd_spill_s": "ppppppppqpiiiifQpp",
     "fs2hip_attention_fwd_b": "ppppiiiifQpp",
     "fs2hip_attention_bwd_b": "pppppppiiiifQpp",
     "fs2hip_attention_b_supported": "i",
@@ -946,13 +948,33 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dx_add=None, defer=Fa
 # ------------------------------------------------------------------------------------------
 # attention
 # ------------------------------------------------------------------------------------------
-def attention_fwd(qkv, lens, B, T, H, drop: Drop = NO_DROP):
+#: FS2_ATTN_SCORES=0: the training forward does not keep its scores (the dK/dV kernel recomputes K.Q^T)
+ATTN_SCORES = os.environ.get("FS2_ATTN_SCORES", "1") != "0"
+
+
+def attention_scores_kept(HD: int) -> bool:
+    """True when ``attention_fwd(save_scores=True)`` writes the scores out for ``attention_bwd(scores=...)``: exact fp32, head
+    dims of the second-generation kernels, spilled-dS backward on."""
+    return GEMM_BF16 == 0 and ATTN_SPILL and ATTN_SCORES and bool(lib().fs2hip_attention_bwd_spill_supported(int(HD)))
+
+
+def attention_fwd(qkv, lens, B, T, H, drop: Drop = NO_DROP, save_scores=False):
+    """``save_scores`` (training forward): returns (o, lse, scores) -- scores [B, H, T, T rounded up to 32] for the backward
+    pass, or None where ``attention_scores_kept`` says no."""
     _chk(qkv, name="qkv"); _chk(lens, torch.int32, "lens")
     D = qkv.shape[-1] // 3
     _req(_rows(qkv) == B * T and qkv.shape[-1] == 3 * D and D % H == 0 and lens.numel() == B,
          "attention_fwd: shape mismatch")
     o = torch.empty(B, T, D, device=qkv.device, dtype=torch.float32)
     lse = torch.empty(B, H, T, device=qkv.device, dtype=torch.float32)
+    if save_scores:
+        if not attention_scores_kept(D // H):
+            o, lse = attention_fwd(qkv, lens, B, T, H, drop)
+            return o, lse, None
+        sc = torch.empty(B, H, T, (T + 31) // 32 * 32, device=qkv.device, dtype=torch.float32)
+        _ok(lib().fs2hip_attention_fwd_s(_p(qkv), _p(lens), _p(o), _p(lse), _p(sc), sc.numel(), B, T, H, D // H, drop.p, drop.seed,
+                                         drop.step_ptr, _stream()), "attention_fwd_s")
+        return o, lse, sc
     _ok(lib().fs2hip_attention_fwd(_p(qkv), _p(lens), _p(o), _p(lse), B, T, H, D // H, drop.p, drop.seed,
                                    drop.step_ptr, int(GEMM_BF16), _stream()), "attention_fwd")
     return o, lse
@@ -973,7 +995,7 @@ def reserve_scratch(name, floats):
     return t
 
 
-def attention_bwd(qkv, lens, o, dout, lse, B, T, H, drop: Drop = NO_DROP):
+def attention_bwd(qkv, lens, o, dout, lse, B, T, H, drop: Drop = NO_DROP, scores=None):
     for n, t in (("qkv", qkv), ("o", o), ("dout", dout), ("lse", lse)):
         _chk(t, name=n)
     _chk(lens, torch.int32, "lens")
@@ -987,6 +1009,13 @@ def attention_bwd(qkv, lens, o, dout, lse, B, T, H, drop: Drop = NO_DROP):
         # of its own on the fp32 MFMAs (5 products per block instead of 9)
         n = B * H * T * ((T + 31) // 32 * 32)
         ds = reserve_scratch("attn_ds", n)
+        if scores is not None and GEMM_BF16 == 0:
+            _chk(scores, name="scores")
+            _req(scores.numel() == n, "attention_bwd: scores must be [B, H, T, T rounded up to 32]")
+            _ok(lib().fs2hip_attention_bwd_spill_s(_p(qkv), _p(lens), _p(o), _p(dout), _p(lse), _p(scores), _p(delta), _p(ds), n,
+                                                   _p(dqkv), B, T, H, D // H, drop.p, drop.seed, drop.step_ptr, _stream()),
+                "attention_bwd_spill_s")
+            return dqkv
         _ok(lib().fs2hip_attention_bwd_spill(_p(qkv), _p(lens), _p(o), _p(dout), _p(lse), _p(delta), _p(ds), n, _p(dqkv), B, T, H,
                                              D // H, drop.p, drop.seed, drop.step_ptr, _stream()), "attention_bwd_spill")
         return dqkv

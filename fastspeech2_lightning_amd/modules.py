@@ -289,9 +289,14 @@ class SelfAttention:
             return y, Ctx(ln=ln_saved, h=h, qkv=qkv, o=o, ob=ob, lse=lse, lens=lens, stored=True)
         h, ln_saved = self.ln.fwd(x)
         qkv = H.linear_fwd(h, S.p(self.wi), S.p(self.bi))
-        o, lse = H.attention_fwd(qkv, lens, B, T, self.heads, env.drop(self.p, self.sa))
+        # a training forward keeps its scores for the backward pass's dK/dV kernel (exact fp32: hip.attention_scores_kept)
+        sc = None
+        if env.training:
+            o, lse, sc = H.attention_fwd(qkv, lens, B, T, self.heads, env.drop(self.p, self.sa), save_scores=True)
+        else:
+            o, lse = H.attention_fwd(qkv, lens, B, T, self.heads, env.drop(self.p, self.sa))
         y = H.linear_fwd(o, S.p(self.wo), S.p(self.bo), epi=H.EPI_RESID, resid=x, drop=env.drop(self.p, self.so))
-        return y, Ctx(ln=ln_saved, h=h, qkv=qkv, o=o, lse=lse, lens=lens, stored=False)
+        return y, Ctx(ln=ln_saved, h=h, qkv=qkv, o=o, lse=lse, lens=lens, stored=False, scores=sc)
 
     def dz_spec(self):
         return 1.0, self.env.drop(self.p, self.so), self.S.g(self.bo)
@@ -322,7 +327,7 @@ class SelfAttention:
         with env.side(dz, c.o):
             H.linear_bwd_weight(dz, c.o, S.g(self.wo), bias_grad=None if fused else S.g(self.bo))
         do = H.linear_bwd_data(dz, S.p(self.wo), wt=S.pt(self.wo))
-        dqkv = H.attention_bwd(c.qkv, c.lens, c.o, do, c.lse, B, T, self.heads, env.drop(self.p, self.sa))
+        dqkv = H.attention_bwd(c.qkv, c.lens, c.o, do, c.lse, B, T, self.heads, env.drop(self.p, self.sa), scores=c.scores)
         with env.side(dqkv, c.h):
             H.linear_bwd_weight(dqkv, c.h, S.g(self.wi), bias_grad=S.g(self.bi))
         dh = H.linear_bwd_data(dqkv, S.p(self.wi))

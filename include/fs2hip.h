@@ -240,6 +240,18 @@ int fs2hip_attention_bwd_spill(const float* qkv, const int* lens, const float* o
                                int B, int T, int H, int HD, float drop_p, unsigned long long drop_seed,
                                const unsigned long long* drop_step, void* stream);
 
+/* ... and with the forward pass's masked scores kept for it: fs2hip_attention_fwd_s writes them (log2 units, scale folded
+ * in, -inf at masked keys) into `scores` (at least B*H*T*(T rounded up to 32) floats, kept until the backward pass), and
+ * fs2hip_attention_bwd_spill_s's dK/dV kernel reads them instead of recomputing K.Q^T: 3 + 1 products per block in the
+ * backward pass, and the backward's probabilities are the forward's to the bit. */
+int fs2hip_attention_fwd_s(const float* qkv, const int* lens, float* o, float* lse, float* scores,
+                           long long score_floats, int B, int T, int H, int HD, float drop_p,
+                           unsigned long long drop_seed, const unsigned long long* drop_step, void* stream);
+int fs2hip_attention_bwd_spill_s(const float* qkv, const int* lens, const float* o, const float* dout,
+                                 const float* lse, const float* scores, float* aux, float* ds, long long ds_floats,
+                                 float* dqkv, int B, int T, int H, int HD, float drop_p,
+                                 unsigned long long drop_seed, const unsigned long long* drop_step, void* stream);
+
 /* The same attention on tensors that ARE bf16 in memory (precision "bf16-mixed" with bf16 activation
  * storage; torch.autocast(bfloat16) around nn.MultiheadAttention, call sites fs2/model.py:193, :241):
  * qkv, o, dout, dqkv are bf16 with the shapes above, lse and the scratch `aux` (2*B*H*T + 4 floats)

@@ -191,3 +191,61 @@ def test_spilled_ds_backward_equals_the_recomputing_backward(H, B, T, Hh, hd, le
         scale = float(want.abs().max())  # (the whole gradient's scale: with one key dQ is zero up to the rounding of p * dP - p * delta)
         err = float((got[..., :D] - want[..., :D]).abs().max())
         assert err < 2e-5 * scale, (drop.p, err, scale)
+
+
+@pytest.mark.parametrize("B,T,Hh,hd,lens", [
+    (1, 1, 2, 128, [1]), (2, 5, 2, 64, [5, 2]), (2, 31, 2, 128, [31, 17]), (3, 130, 2, 128, [130, 64, 1]),
+    (2, 200, 1, 64, [200, 33]), (4, 648, 2, 128, [648, 500, 40, 333]),
+    (32, 648, 2, 128, [648, 430, 40] + [430 + 7 * i for i in range(29)]), (3, 1291, 2, 128, [1291, 700, 64]),
+])
+def test_backward_from_the_forward_passes_scores(H, B, T, Hh, hd, lens, monkeypatch):
+    """``attention_fwd(save_scores=True)`` + ``attention_bwd(scores=...)``: the training forward writes its masked scores
+    out, the dK/dV kernel reads them instead of recomputing K.Q^T.  The forward's o / lse are bit-identical with and without the
+    store; the gradients equal the recomputing spilled-dS backward's within the rounding of S (scale folded into Q in the
+    forward, into K in the recomputation): 2e-5 of the gradient's scale -- dropout on, ragged lengths, utterances that end
+    inside a key tile, key blocks whose second half is all padding (scores never written: masked by the key test)."""
+    g = torch.Generator().manual_seed(B * 91 + T)
+    D = Hh * hd
+    qkv = torch.randn(B, T, 3 * D, generator=g).cuda()
+    dout = torch.randn(B, T, D, generator=g).cuda()
+    lens_t = torch.tensor(lens, dtype=torch.int32).cuda()
+    assert H.attention_scores_kept(hd)
+    for drop in (H.NO_DROP, H.Drop(0.2, 4321)):
+        o0, lse0 = H.attention_fwd(qkv, lens_t, B, T, Hh, drop)
+        o, lse, sc = H.attention_fwd(qkv, lens_t, B, T, Hh, drop, save_scores=True)
+        assert sc is not None and sc.shape == (B, Hh, T, (T + 31) // 32 * 32)
+        assert torch.equal(o, o0) and torch.equal(lse, lse0)
+        want = H.attention_bwd(qkv, lens_t, o, dout, lse, B, T, Hh, drop)
+        got = H.attention_bwd(qkv, lens_t, o, dout, lse, B, T, Hh, drop, scores=sc)
+        assert torch.isfinite(got).all()
+        scale = float(want.abs().max())
+        err = float((got - want).abs().max())
+        assert err <= 2e-5 * scale, (drop.p, err, scale)  # (one key and it is dropped: everything is exactly zero)
+    # and against the plain PyTorch reference (no dropout)
+    qr = qkv.cpu().clone().requires_grad_(True)
+    ref, _ = ref_attention(qr, lens_t.cpu(), B, T, Hh)
+    ref.backward(dout.cpu())
+    o, lse, sc = H.attention_fwd(qkv, lens_t, B, T, Hh, save_scores=True)
+    got = H.attention_bwd(qkv, lens_t, o, dout, lse, B, T, Hh, scores=sc)
+    assert float((got.cpu() - qr.grad).abs().max()) < 3e-5 * float(qr.grad.abs().max())
+
+
+def test_backward_does_not_read_uninitialised_scratch(H):
+    """Odd T: the dK/dV kernel's last {lse', delta'} piece of the last (utterance, head) reaches one pair into the scratch's
+    slack.  With the allocator's leftovers poisoned (NaN), every gradient must still be finite and equal the clean run's --
+    recomputing, spilled-dS and kept-scores forms."""
+    B, T, Hh, hd, lens = 2, 5, 2, 64, [5, 2]
+    D = Hh * hd
+    g = torch.Generator().manual_seed(17)
+    qkv = torch.randn(B, T, 3 * D, generator=g).cuda()
+    dout = torch.randn(B, T, D, generator=g).cuda()
+    lens_t = torch.tensor(lens, dtype=torch.int32).cuda()
+    o, lse, sc = H.attention_fwd(qkv, lens_t, B, T, Hh, save_scores=True)
+    clean = H.attention_bwd(qkv, lens_t, o, dout, lse, B, T, Hh, scores=sc)
+    for trial in range(8):
+        junk = torch.full((1 << 20,), float("nan"), device="cuda")  # freed at once: what the next torch.empty hands out
+        del junk
+        for kw in ({}, {"scores": sc}):
+            got = H.attention_bwd(qkv, lens_t, o, dout, lse, B, T, Hh, **kw)
+            assert torch.isfinite(got).all(), (trial, kw.keys())
+            assert float((got - clean).abs().max()) <= 2e-5 * float(clean.abs().max())

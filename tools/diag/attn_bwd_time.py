@@ -17,15 +17,26 @@ qkv = torch.randn(B, T, 3 * D, generator=g).cuda()
 dout = torch.randn(B, T, D, generator=g).cuda()
 lens = torch.tensor([T, 430, 40] + [430 + (7 * i) % (T - 430 + 1) for i in range(B - 3)], dtype=torch.int32)[:B].cuda()
 drop = H.Drop(0.2, 77)
-o, lse = H.attention_fwd(qkv, lens, B, T, Hh, drop)
-for spill in (False, True, False, True):
-    H.ATTN_SPILL = spill
-    H.attention_bwd(qkv, lens, o, dout, lse, B, T, Hh, drop)
+o, lse, sc = H.attention_fwd(qkv, lens, B, T, Hh, drop, save_scores=True)
+
+
+def timed(fn):
+    fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(10):
-        H.attention_bwd(qkv, lens, o, dout, lse, B, T, Hh, drop)
+        fn()
     e1.record()
     torch.cuda.synchronize()
-    print(f"B={B} T={T} spill={spill}: {e0.elapsed_time(e1) / 10 * 1e3:8.1f} us per backward (prep + two gradient kernels)", flush=True)
+    return e0.elapsed_time(e1) / 10 * 1e3
+
+
+for rep in range(2):
+    H.ATTN_SPILL = False
+    print(f"B={B} T={T} recomputing backward:        {timed(lambda: H.attention_bwd(qkv, lens, o, dout, lse, B, T, Hh, drop)):8.1f} us", flush=True)
+    H.ATTN_SPILL = True
+    print(f"B={B} T={T} spilled dS:                  {timed(lambda: H.attention_bwd(qkv, lens, o, dout, lse, B, T, Hh, drop)):8.1f} us", flush=True)
+    print(f"B={B} T={T} spilled dS + forward scores: {timed(lambda: H.attention_bwd(qkv, lens, o, dout, lse, B, T, Hh, drop, scores=sc)):8.1f} us", flush=True)
+    print(f"B={B} T={T} forward:                     {timed(lambda: H.attention_fwd(qkv, lens, B, T, Hh, drop)):8.1f} us", flush=True)
+    print(f"B={B} T={T} forward + score store:       {timed(lambda: H.attention_fwd(qkv, lens, B, T, Hh, drop, save_scores=True)):8.1f} us", flush=True)
