@@ -523,16 +523,19 @@ extern "C" int fs2hip_attention_fwd(const float* qkv, const int* lens, float* o,
   return 0;
 }
 
-// The forward pass that also writes the masked scores out (fp32 MFMA path, head dims 64 / 128) for
+// The forward pass that also writes the masked scores out (operand_bf16 0: fp32 MFMA path, 2: "32-split"; head dims 64 / 128) for
 // fs2hip_attention_bwd_spill_s: `scores` holds at least B * H * T * (T rounded up to 32) floats.
 extern "C" int fs2hip_attention_fwd_s(const float* qkv, const int* lens, float* o, float* lse, float* scores,
                                       long long score_floats, int B, int T, int H, int HD, float drop_p,
-                                      unsigned long long drop_seed, const unsigned long long* drop_step, void* stream) {
+                                      unsigned long long drop_seed, const unsigned long long* drop_step, int operand_bf16,
+                                      void* stream) {
+  if (operand_bf16 != 0 && operand_bf16 != 2) return FS2HIP_EINVAL;  // exact fp32 or three exact bf16 planes
   if (!attn_args_ok(qkv, B, T, H, HD) || ((uintptr_t)o % 16) || ((uintptr_t)scores % 16) || !scores) return FS2HIP_EINVAL;
   static const bool old_only = getenv("FS2_ATTN_GEN1") != nullptr;
   if (old_only || (HD != 64 && HD != 128)) return FS2HIP_EINVAL;
   if (score_floats < (long long)B * H * T * ((T + 31) & ~31)) return FS2HIP_EINVAL;
-  Attn2Args a2{qkv, lens, B, T, H, HD, 1.f / sqrtf((float)HD), fs2_make_drop(drop_p, drop_seed, drop_step), 0, nullptr};
+  Attn2Args a2{qkv, lens, B, T, H, HD, 1.f / sqrtf((float)HD), fs2_make_drop(drop_p, drop_seed, drop_step),
+               operand_bf16 == 2 ? 3 : 0, nullptr};
   return fs2_attn2_fwd(a2, o, lse, (hipStream_t)stream, scores);
 }
 

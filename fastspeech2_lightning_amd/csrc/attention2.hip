@@ -444,14 +444,14 @@ struct SoftmaxWeights {
 // -> the next V tile's DMA starts and lands under K.Q^T + softmax) and barrier Y (start of P.V; everybody is done
 // with the K tile -> the next K tile's DMA starts and lands under P.V).
 // ------------------------------------------------------------------------------------------------------------
-// SS (fp32 MFMA path, training): the masked scores -- log2 units, scale folded in -- are also written out as
+// SS (fp32 MFMA path and the three-plane "32-split" path, training): the masked scores -- log2 units, scale folded in -- are also written out as
 // s_out[b][h][q][key] (rows of Tp32 = T rounded up to 32 floats) for the dK/dV kernel, which then needs neither the S product
 // nor its own K rows (attn2_bwd_dkv_kernel<.., SIN>).  Four 16-byte stores per lane and key tile, younger than the V tile's
 // DMA: the barrier behind the row maximum waits with vmcnt(4).
 template <int HD, bool DROP, int PL, bool SS = false>
 __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(Attn2Args p, float* __restrict__ o, float* __restrict__ lse,
                                                            float* __restrict__ s_out = nullptr) {
-  static_assert(!SS || PL == 0, "scores are written out by the fp32 MFMA path only");
+  static_assert(!SS || PL == 0 || PL == 3, "scores are written out by the fp32-accurate paths only");
   constexpr int NJ = HD / 8, NDB = HD / 32;
   // K tile, V tile of key group 0; then of group 1: 64 KB, two workgroups per CU.  (fp32 MFMAs and fp32 vector
   // instructions share the arithmetic, so the second wavefront per SIMD overlaps no arithmetic -- but it does cover
@@ -1207,9 +1207,10 @@ int fs2_attn2_fwd(const Attn2Args& a, float* o, float* lse, hipStream_t s, float
   // so the index stride is T + (T & 1) -- the same bound in the forward and the backward launcher
   if ((double)a.B * a.H * a.T * (a.T + (a.T & 1)) >= 4294967296.0) return FS2HIP_EINVAL;
   dim3 grid(((a.T + 63) / 64) * a.H * a.B);
-  if (s_out && (a.planes != 0 || (long long)a.T * ((a.T + 31) & ~31) * 4 >= 0x7fffffffLL)) return FS2HIP_EINVAL;
+  if (s_out && (a.planes == 1 || (long long)a.T * ((a.T + 31) & ~31) * 4 >= 0x7fffffffLL)) return FS2HIP_EINVAL;
 #define FS2_ATTN2_FWD(HD_, DROP_)                                                                 \
-  if (a.planes == 3) attn2_fwd_kernel<HD_, DROP_, 3><<<grid, dim3(256), 0, s>>>(a, o, lse);         \
+  if (a.planes == 3 && s_out) attn2_fwd_kernel<HD_, DROP_, 3, true><<<grid, dim3(256), 0, s>>>(a, o, lse, s_out); \
+  else if (a.planes == 3) attn2_fwd_kernel<HD_, DROP_, 3><<<grid, dim3(256), 0, s>>>(a, o, lse);    \
   else if (a.planes == 1) attn2_fwd_kernel<HD_, DROP_, 1><<<grid, dim3(256), 0, s>>>(a, o, lse);    \
   else if (s_out) attn2_fwd_kernel<HD_, DROP_, 0, true><<<grid, dim3(256), 0, s>>>(a, o, lse, s_out); \
   else attn2_fwd_kernel<HD_, DROP_, 0><<<grid, dim3(256), 0, s>>>(a, o, lse);

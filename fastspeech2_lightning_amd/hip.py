@@ -71,7 +71,7 @@ SIGNATURES = {
     "fs2hip_attention_bwd": "pppppppiiiifQpip",
     "fs2hip_attention_bwd_spill_supported": "i",
     "fs2hip_attention_bwd_spill": "pppppppqpiiiifQpp",
-    "fs2hip_attention_fwd_s": "pppppqiiiifQpp",
+    "fs2hip_attention_fwd_s": "pppppqiiiifQpip",
     "fs2hip_attention_bwd_spill_s": "ppppppppqpiiiifQpp",
     "fs2hip_attention_fwd_b": "ppppiiiifQpp",
     "fs2hip_attention_bwd_b": "pppppppiiiifQpp",
@@ -953,9 +953,9 @@ ATTN_SCORES = os.environ.get("FS2_ATTN_SCORES", "1") != "0"
 
 
 def attention_scores_kept(HD: int) -> bool:
-    """True when ``attention_fwd(save_scores=True)`` writes the scores out for ``attention_bwd(scores=...)``: exact fp32, head
-    dims of the second-generation kernels, spilled-dS backward on."""
-    return GEMM_BF16 == 0 and ATTN_SPILL and ATTN_SCORES and bool(lib().fs2hip_attention_bwd_spill_supported(int(HD)))
+    """True when ``attention_fwd(save_scores=True)`` writes the scores out for ``attention_bwd(scores=...)``: exact fp32 or
+    "32-split", head dims of the second-generation kernels, spilled-dS backward on."""
+    return GEMM_BF16 in (0, 2) and ATTN_SPILL and ATTN_SCORES and bool(lib().fs2hip_attention_bwd_spill_supported(int(HD)))
 
 
 def attention_fwd(qkv, lens, B, T, H, drop: Drop = NO_DROP, save_scores=False):
@@ -973,7 +973,7 @@ def attention_fwd(qkv, lens, B, T, H, drop: Drop = NO_DROP, save_scores=False):
             return o, lse, None
         sc = torch.empty(B, H, T, (T + 31) // 32 * 32, device=qkv.device, dtype=torch.float32)
         _ok(lib().fs2hip_attention_fwd_s(_p(qkv), _p(lens), _p(o), _p(lse), _p(sc), sc.numel(), B, T, H, D // H, drop.p, drop.seed,
-                                         drop.step_ptr, _stream()), "attention_fwd_s")
+                                         drop.step_ptr, int(GEMM_BF16), _stream()), "attention_fwd_s")
         return o, lse, sc
     _ok(lib().fs2hip_attention_fwd(_p(qkv), _p(lens), _p(o), _p(lse), B, T, H, D // H, drop.p, drop.seed,
                                    drop.step_ptr, int(GEMM_BF16), _stream()), "attention_fwd")
@@ -1009,7 +1009,7 @@ def attention_bwd(qkv, lens, o, dout, lse, B, T, H, drop: Drop = NO_DROP, scores
         # of its own on the fp32 MFMAs (5 products per block instead of 9)
         n = B * H * T * ((T + 31) // 32 * 32)
         ds = reserve_scratch("attn_ds", n)
-        if scores is not None and GEMM_BF16 == 0:
+        if scores is not None:
             _chk(scores, name="scores")
             _req(scores.numel() == n, "attention_bwd: scores must be [B, H, T, T rounded up to 32]")
             _ok(lib().fs2hip_attention_bwd_spill_s(_p(qkv), _p(lens), _p(o), _p(dout), _p(lse), _p(scores), _p(delta), _p(ds), n,

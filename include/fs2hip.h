@@ -243,10 +243,12 @@ int fs2hip_attention_bwd_spill(const float* qkv, const int* lens, const float* o
 /* ... and with the forward pass's masked scores kept for it: fs2hip_attention_fwd_s writes them (log2 units, scale folded
  * in, -inf at masked keys) into `scores` (at least B*H*T*(T rounded up to 32) floats, kept until the backward pass), and
  * fs2hip_attention_bwd_spill_s's dK/dV kernel reads them instead of recomputing K.Q^T: 3 + 1 products per block in the
- * backward pass, and the backward's probabilities are the forward's to the bit. */
+ * backward pass, and the backward's probabilities are the forward's to the bit.  operand_bf16: 0 (exact fp32) or 2
+ * ("32-split": the scores come from the three-plane products; the backward pass is the fp32 one either way). */
 int fs2hip_attention_fwd_s(const float* qkv, const int* lens, float* o, float* lse, float* scores,
                            long long score_floats, int B, int T, int H, int HD, float drop_p,
-                           unsigned long long drop_seed, const unsigned long long* drop_step, void* stream);
+                           unsigned long long drop_seed, const unsigned long long* drop_step, int operand_bf16,
+                           void* stream);
 int fs2hip_attention_bwd_spill_s(const float* qkv, const int* lens, const float* o, const float* dout,
                                  const float* lse, const float* scores, float* aux, float* ds, long long ds_floats,
                                  float* dqkv, int B, int T, int H, int HD, float drop_p,

@@ -249,3 +249,29 @@ def test_backward_does_not_read_uninitialised_scratch(H):
             got = H.attention_bwd(qkv, lens_t, o, dout, lse, B, T, Hh, **kw)
             assert torch.isfinite(got).all(), (trial, kw.keys())
             assert float((got - clean).abs().max()) <= 2e-5 * float(clean.abs().max())
+
+
+def test_split_precision_keeps_its_scores_too(H, monkeypatch):
+    """"32-split": the three-plane forward writes its scores out as well; the backward pass (fp32 dK/dV kernel + dQ from dS)
+    reads them.  Gradients within 3e-5 of PyTorch fp32 and within 2e-5 of the same precision without kept scores."""
+    B, T, Hh, hd, lens = 3, 130, 2, 128, [130, 64, 1]
+    D = Hh * hd
+    g = torch.Generator().manual_seed(23)
+    qkv = torch.randn(B, T, 3 * D, generator=g).cuda()
+    dout = torch.randn(B, T, D, generator=g).cuda()
+    lens_t = torch.tensor(lens, dtype=torch.int32).cuda()
+    qr = qkv.cpu().clone().requires_grad_(True)
+    ref, _ = ref_attention(qr, lens_t.cpu(), B, T, Hh)
+    ref.backward(dout.cpu())
+    H.set_precision("32-split")
+    try:
+        assert H.attention_scores_kept(hd)
+        o0, lse0 = H.attention_fwd(qkv, lens_t, B, T, Hh)
+        o, lse, sc = H.attention_fwd(qkv, lens_t, B, T, Hh, save_scores=True)
+        assert sc is not None and torch.equal(o, o0) and torch.equal(lse, lse0)
+        want = H.attention_bwd(qkv, lens_t, o, dout, lse, B, T, Hh)
+        got = H.attention_bwd(qkv, lens_t, o, dout, lse, B, T, Hh, scores=sc)
+    finally:
+        H.set_precision("32-true")
+    assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    assert float((got.cpu() - qr.grad).abs().max()) < 3e-5 * float(qr.grad.abs().max())
