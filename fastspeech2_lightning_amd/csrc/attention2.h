@@ -29,4 +29,4 @@ int fs2_attn2_bwd_spill(const Attn2Args& a, const float* o, const float* dout, c
 bool fs2_attnb_supported(int HD);
 int fs2_attnb_fwd(const Attn2Args& a, const void* qkv, void* o, float* lse, hipStream_t s);
 int fs2_attnb_bwd(const Attn2Args& a, const void* qkv, const void* o, const void* dout, const float* lse, float* aux,
-                  void* dqkv, hipStream_t s);
+                  void* dqkv, hipStream_t s, void* ds = nullptr);

@@ -442,14 +442,87 @@ __global__ __launch_bounds__(256, 2) void attnb_bwd_dq_kernel(AttnBArgs p, const
   }
 }
 
+// dQ from the spilled dS (attnb_bwd_dkv_kernel<.., SPILL>): dq^T[d][q] = scale * sum_key K[key][d] * dS[q][key].  A wavefront
+// owns 32 queries; K tiles (64 keys, 16 KB) go through LDS, two stages; a lane's weights of a 32-key block are the 32
+// contiguous bytes the dK/dV kernel laid out for it, requested one block ahead.  No exponentials, no hashes, two products
+// fewer than the recomputing kernel.
+__global__ __launch_bounds__(256, 2) void attnb_bwd_dq_ds_kernel(AttnBArgs p, const u16* __restrict__ ds, u16* __restrict__ dqkv) {
+  constexpr int HD = AB_HD;
+  constexpr int SMEM = 2 * AB_TILE > 4 * AB_STG_BYTES ? 2 * AB_TILE : 4 * AB_STG_BYTES;  // K stages; the rows' way out at the end
+  __shared__ __attribute__((aligned(1024))) char smem[SMEM];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5, l32 = lane & 31;
+  int qb, b, h, len;
+  work_unit(p, (p.T + 127) / 128, qb, b, h, len);
+  const int T = p.T, D = p.H * HD, ld = 3 * D, Tp32 = (T + 31) & ~31;
+  const int q = qb * 128 + wave * 32 + l32;
+  const bool active = qb * 128 + wave * 32 < T;
+  const int kend = min(T, len);
+  const int nt = (kend + AB_KT - 1) / AB_KT;
+  const u16* base = p.qkv + (long long)b * T * ld;
+  const __amdgpu_buffer_rsrc_t rk = b_rsrc(base + D + h * HD);
+  TileDmaB dma;
+  dma.setup(ld, tid);
+  if (nt > 0) dma.issue(rk, smem, 0, T, ld, wave);
+  f32x16 dq[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dq[d][i] = 0.f;
+  const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
+  TrRdB tr;
+  tr.setup(lane, lds0);
+  // this lane's dS row (rows past T: never stored, the loads are skipped)
+  const u16* dsrow = ds + (((long long)(b * p.H + h) * T + (q < T ? q : 0)) * Tp32) + 16 * hi;
+  const u32x4 z4 = {0u, 0u, 0u, 0u};
+  auto load_w = [&](u32x4 (&w)[2], int key0) {  // the sixteen weights of keys key0 .. key0 + 31 (key0 < kend)
+    if (q < T && key0 < kend) {
+      w[0] = *reinterpret_cast<const u32x4*>(dsrow + key0);
+      w[1] = *reinterpret_cast<const u32x4*>(dsrow + key0 + 8);
+    } else {
+      w[0] = z4;
+      w[1] = z4;
+    }
+  };
+  u32x4 wa[2], wb[2];
+  load_w(wa, 0);
+  auto tile = [&](auto stc, int j) {
+    constexpr int ST = decltype(stc)::value;
+    constexpr int KOFF = ST * AB_TILE;
+    b_wait_vmcnt_barrier<0>();
+    if (j + 1 < nt) dma.issue(rk, smem + (ST ^ 1) * AB_TILE, (j + 1) * AB_KT, T, ld, wave);
+    if (!active) return;
+    const int key0 = j * AB_KT;
+    load_w(wb, key0 + 32);
+    ab_acc_cols<KOFF>(tr, wa, dq);
+    load_w(wa, key0 + 64);
+    if (key0 + 32 < kend) ab_acc_cols<KOFF + 32 * AB_ROWB>(tr, wb, dq);
+  };
+  for (int j = 0; j < nt; j += 2) {
+    tile(std::integral_constant<int, 0>{}, j);
+    if (j + 1 < nt) tile(std::integral_constant<int, 1>{}, j + 1);
+  }
+  __syncthreads();
+  if (active) {
+    const int row0 = qb * 128 + wave * 32;
+    ab_store_rows_staged(smem + wave * AB_STG_BYTES, dqkv + ((long long)b * T + row0) * ld + h * HD, ld, T - row0, dq, p.scale,
+                         lane);
+  }
+}
+
 // dK / dV.  Workgroup = 4 wavefronts = 4 x 32 keys sharing the Q / dO tiles (64 queries) and their {lse', delta'} pairs.
 // S and dP come out with the LANE on the key and the registers on the queries, so the per-query statistics are read
 // per register (broadcast reads of the staged pairs) and neighbouring keys -- which share a dropout hash -- sit in
 // neighbouring lanes: each lane hashes its own elements.  One wavefront per SIMD (the two accumulator sets and the two
 // own-row fragment sets are 256 registers by themselves).
-template <bool DROP>
+// SPILL: dS -- masked to the utterance's keys and rounded to bf16, i.e. exactly the operand the dQ product consumes -- is
+// also written out: ds[b][h][q][Tp32] (Tp32 = T rounded up to 32 keys), the 32 keys of a block in the order of the dQ
+// kernel's operand registers (position 16 hi' + 4 a + r for key 8 a + 4 hi' + r), so that a lane of
+// attnb_bwd_dq_ds_kernel fetches its sixteen weights of a key block as 32 contiguous bytes.  That kernel then needs no S,
+// no dP and none of the softmax / dropout vector work the recomputing dQ kernel is bound by.
+template <bool DROP, bool SPILL = false>
 __global__ __launch_bounds__(256, 1) void attnb_bwd_dkv_kernel(AttnBArgs p, const u16* __restrict__ dout,
-                                                               const float2* __restrict__ aux, u16* __restrict__ dqkv) {
+                                                               const float2* __restrict__ aux, u16* __restrict__ dqkv,
+                                                               u16* __restrict__ ds = nullptr) {
   constexpr int HD = AB_HD;
   // the {lse', delta'} pairs of stage s at 1024 s, then the tiles: stage s has its Q tile at 2 s, its dO tile at 2 s + 1
   constexpr int TILES = 2 * 1024;
@@ -499,6 +572,13 @@ __global__ __launch_bounds__(256, 1) void attnb_bwd_dkv_kernel(AttnBArgs p, cons
   const uint32_t unit_row0 = (uint32_t)((unsigned long long)(b * p.H + h) * T);
   const uint32_t pair_lane = (uint32_t)(4 * hi) * half_tp + (uint32_t)(key >> 1);
   const int odd = key & 1;
+  // dS slab of this (utterance, head): rows past T fall to the range check (the SGPR offset is part of it on gfx950)
+  const int Tp32 = (T + 31) & ~31;
+  const __amdgpu_buffer_rsrc_t rds = __builtin_amdgcn_make_buffer_rsrc(
+      SPILL ? (void*)(ds + ((long long)(b * p.H + h) * T) * Tp32) : (void*)dqkv, 0, SPILL ? T * Tp32 * 2 : 0, 0x00020000);
+  const int ds_pos = 16 * ((l32 >> 2) & 1) + 4 * (l32 >> 3) + (l32 & 3);
+  const int ds_voff = (4 * hi * Tp32 + (key & ~31) + ds_pos) * 2;  // (key < Tp32 for every key of an active wavefront)
+  const bool key_valid = key < len;
   const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
   RowRdB rd;
   rd.setup(l32, hi, lds0 + TILES);
@@ -544,6 +624,10 @@ __global__ __launch_bounds__(256, 1) void attnb_bwd_dkv_kernel(AttnBArgs p, cons
       }
       pdv[i] = pd;
       dsv[i] = fmaf(pd, dp[i], -pp * delp);
+      if constexpr (SPILL) {  // dS[q0 + 8 g + 4 hi + r][key], zero at the keys behind the utterance's end
+        const unsigned w = pack_bf16x2(key_valid ? dsv[i] : 0.f, 0.f);
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(w & 0xffffu), rds, ds_voff, (q0 + 8 * g + r) * Tp32 * 2, 0);
+      }
     }
     u32x4 wp[2], wd[2];
 #pragma unroll
@@ -559,7 +643,9 @@ __global__ __launch_bounds__(256, 1) void attnb_bwd_dkv_kernel(AttnBArgs p, cons
   auto tile = [&](auto stc, int j) {
     constexpr int ST = decltype(stc)::value;
     constexpr int QOFF = ST * 2 * AB_TILE, GOFF = QOFF + AB_TILE, AOFF = ST * 1024;
-    b_wait_vmcnt_barrier<0>();
+    // tile j landed for everybody.  SPILL: the 32 dS stores of the previous tile (two blocks: every tile but the last has
+    // both) are younger than this tile's DMA and may stay in flight -- for the wavefronts that made any
+    if (SPILL && active && j > 0) b_wait_vmcnt_barrier<32>(); else b_wait_vmcnt_barrier<0>();
     if (j + 1 < nt) stage_in(ST ^ 1, (j + 1) * AB_KT);
     if (!active) return;
     const int q0 = j * AB_KT;
@@ -600,7 +686,7 @@ int fs2_attnb_fwd(const Attn2Args& a, const void* qkv, void* o, float* lse, hipS
 }
 
 int fs2_attnb_bwd(const Attn2Args& a, const void* qkv, const void* o, const void* dout, const float* lse, float* aux,
-                  void* dqkv, hipStream_t s) {
+                  void* dqkv, hipStream_t s, void* ds) {
   if (a.HD != AB_HD || a.B <= 0 || a.T <= 0 || a.H <= 0) return FS2HIP_EINVAL;
   if ((double)a.B * a.H * a.T * (a.T + (a.T & 1)) >= 4294967296.0) return FS2HIP_EINVAL;
   if ((long long)a.T * 3 * a.H * a.HD * 2 >= 0x7fffffffLL) return FS2HIP_EINVAL;
@@ -613,6 +699,15 @@ int fs2_attnb_bwd(const Attn2Args& a, const void* qkv, const void* o, const void
   FS2_LAUNCH_CHECK();
   dim3 grid(((a.T + 127) / 128) * a.H * a.B);
   const float2* ax = reinterpret_cast<const float2*>(aux);
+  if (ds) {  // dS spilled by the dK/dV kernel, dQ as a product of its own (ds: B * H * T * (T rounded up to 32) bf16)
+    if ((long long)a.T * ((a.T + 31) & ~31) * 2 >= 0x7fffffffLL || ((uintptr_t)ds % 16)) return FS2HIP_EINVAL;
+    if (a.drop.on) attnb_bwd_dkv_kernel<true, true><<<grid, dim3(256), 0, s>>>(p, (const u16*)dout, ax, (u16*)dqkv, (u16*)ds);
+    else attnb_bwd_dkv_kernel<false, true><<<grid, dim3(256), 0, s>>>(p, (const u16*)dout, ax, (u16*)dqkv, (u16*)ds);
+    FS2_LAUNCH_CHECK();
+    attnb_bwd_dq_ds_kernel<<<grid, dim3(256), 0, s>>>(p, (const u16*)ds, (u16*)dqkv);
+    FS2_LAUNCH_CHECK();
+    return 0;
+  }
   if (a.drop.on) {
     attnb_bwd_dq_kernel<true><<<grid, dim3(256), 0, s>>>(p, (const u16*)dout, ax, (u16*)dqkv);
     FS2_LAUNCH_CHECK();
@@ -645,3 +740,18 @@ extern "C" int fs2hip_attention_bwd_b(const void* qkv, const int* lens, const vo
 }
 
 extern "C" int fs2hip_attention_b_supported(int HD) { return fs2_attnb_supported(HD) ? 1 : 0; }
+
+// fs2hip_attention_bwd_b with dS written out by the dK/dV kernel (bf16, B * H * T * (T rounded up to 32) elements of scratch
+// in `ds`) and dQ = scale * dS . K as a product of its own: the recomputing dQ kernel's S, dP and softmax / dropout arithmetic
+// are not run a second time.
+extern "C" int fs2hip_attention_bwd_b_spill(const void* qkv, const int* lens, const void* o, const void* dout, const float* lse,
+                                            float* aux, void* ds, long long ds_elems, void* dqkv, int B, int T, int H, int HD,
+                                            float drop_p, unsigned long long drop_seed, const unsigned long long* drop_step,
+                                            void* stream) {
+  if (!qkv || !lens || !o || !dout || !lse || !aux || !dqkv || !ds || ((uintptr_t)qkv % 16) || ((uintptr_t)o % 16) ||
+      ((uintptr_t)dout % 16) || ((uintptr_t)dqkv % 16) || ((uintptr_t)aux % 16) || ((uintptr_t)ds % 16))
+    return FS2HIP_EINVAL;
+  if (ds_elems < (long long)B * H * T * ((T + 31) & ~31)) return FS2HIP_EINVAL;
+  Attn2Args a{nullptr, lens, B, T, H, HD, 1.f / sqrtf((float)HD), fs2_make_drop(drop_p, drop_seed, drop_step), 1, nullptr};
+  return fs2_attnb_bwd(a, qkv, o, dout, lse, aux, dqkv, (hipStream_t)stream, ds);
+}

@@ -75,6 +75,7 @@ SIGNATURES = {
     "fs2hip_attention_bwd_spill_s": "ppppppppqpiiiifQpp",
     "fs2hip_attention_fwd_b": "ppppiiiifQpp",
     "fs2hip_attention_bwd_b": "pppppppiiiifQpp",
+    "fs2hip_attention_bwd_b_spill": "pppppppqpiiiifQpp",
     "fs2hip_attention_b_supported": "i",
     "fs2hip_dwconv_blocks": "ii",
     "fs2hip_dwconv_part_rows": "",
@@ -1044,6 +1045,10 @@ def attention_fwd_b(qkv, lens, B, T, H, drop: Drop = NO_DROP):
     return o, lse
 
 
+#: FS2_ATTN_SPILL_B=0: the bf16-storage attention backward recomputes S and dP in both gradient kernels
+ATTN_SPILL_B = os.environ.get("FS2_ATTN_SPILL_B", "1") != "0"
+
+
 def attention_bwd_b(qkv, lens, o, dout, lse, B, T, H, drop: Drop = NO_DROP):
     for n, t in (("qkv", qkv), ("o", o), ("dout", dout)):
         _chk(t, torch.bfloat16, n)
@@ -1054,6 +1059,12 @@ def attention_bwd_b(qkv, lens, o, dout, lse, B, T, H, drop: Drop = NO_DROP):
     _req(attention_b_supported(D // H), "attention_bwd_b: head dimension not supported by the bf16-storage kernels")
     dqkv = torch.empty_like(qkv)
     aux = torch.empty(2 * lse.numel() + 4, device=lse.device, dtype=torch.float32)  # {lse', delta'} per row and head
+    if ATTN_SPILL_B:
+        n = B * H * T * ((T + 31) // 32 * 32)  # bf16 elements
+        ds = reserve_scratch("attnb_ds", (n + 1) // 2)
+        _ok(lib().fs2hip_attention_bwd_b_spill(_p(qkv), _p(lens), _p(o), _p(dout), _p(lse), _p(aux), _p(ds), n, _p(dqkv), B, T, H,
+                                               D // H, drop.p, drop.seed, drop.step_ptr, _stream()), "attention_bwd_b_spill")
+        return dqkv
     _ok(lib().fs2hip_attention_bwd_b(_p(qkv), _p(lens), _p(o), _p(dout), _p(lse), _p(aux), _p(dqkv), B, T, H, D // H,
                                      drop.p, drop.seed, drop.step_ptr, _stream()), "attention_bwd_b")
     return dqkv

@@ -268,6 +268,14 @@ int fs2hip_attention_bwd_b(const void* qkv, const int* lens, const void* o, cons
                            float drop_p, unsigned long long drop_seed,
                            const unsigned long long* drop_step, void* stream);
 
+/* fs2hip_attention_bwd_b with dS -- masked and rounded to bf16: the operand the dQ product consumes -- written out by the
+ * dK/dV kernel and dQ = scale * dS . K as a product of its own: S, dP and the softmax / dropout arithmetic are computed once
+ * per backward pass instead of twice.  ds: scratch of at least B*H*T*(T rounded up to 32) bf16 elements (ds_elems). */
+int fs2hip_attention_bwd_b_spill(const void* qkv, const int* lens, const void* o, const void* dout,
+                                 const float* lse, float* aux, void* ds, long long ds_elems, void* dqkv,
+                                 int B, int T, int H, int HD, float drop_p, unsigned long long drop_seed,
+                                 const unsigned long long* drop_step, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Depthwise Conv1d over time on (B, T, C), 'same' padding, K in {3,5,7,9,15,31}; w is [K][C].
  * glu = 1: the input has 2C columns (value | gate) and a = value * sigmoid(gate) is formed on

@@ -111,3 +111,30 @@ def test_attention_bf16_storage_rejects_other_head_dims(H):
     lens = torch.tensor([8], dtype=torch.int32).cuda()
     with pytest.raises(Exception):
         H.attention_fwd_b(qkv, lens, 1, 8, 2)
+
+
+@pytest.mark.parametrize("B,T,lens", CASES + [(3, 1291, [1291, 700, 64])])
+def test_bf16_storage_backward_with_spilled_ds_equals_the_recomputing_one(H, B, T, lens, monkeypatch):
+    """``fs2hip_attention_bwd_b_spill`` (default): the dK/dV kernel writes dS -- masked, rounded to bf16: the operand the dQ
+    product consumes -- and dQ = scale * dS . K is a product of its own.  dK and dV are the recomputing kernels' bit for bit
+    (same kernel, sixteen stores more per block); dQ within bf16 rounding of theirs -- dropout on and off, ragged lengths,
+    utterances that end inside a key block, T not a multiple of the tile, T = 1."""
+    Hh, hd = 2, 128
+    D = Hh * hd
+    g = torch.Generator().manual_seed(B * 313 + T)
+    qkv = torch.randn(B, T, 3 * D, generator=g).bfloat16().cuda()
+    dout = torch.randn(B, T, D, generator=g).bfloat16().cuda()
+    lens_t = torch.tensor(lens, dtype=torch.int32).cuda()
+    for drop in (H.NO_DROP, H.Drop(0.1, 99)):
+        o, lse = H.attention_fwd_b(qkv, lens_t, B, T, Hh, drop)
+        monkeypatch.setattr(H, "ATTN_SPILL_B", False)
+        want = H.attention_bwd_b(qkv, lens_t, o, dout, lse, B, T, Hh, drop).float()
+        monkeypatch.setattr(H, "ATTN_SPILL_B", True)
+        H._SCRATCH.clear()
+        got = H.attention_bwd_b(qkv, lens_t, o, dout, lse, B, T, Hh, drop).float()
+        assert torch.isfinite(got).all()
+        assert torch.equal(got[..., D:], want[..., D:]), "dK / dV changed"
+        scale = float(want.abs().max())
+        err = float((got[..., :D] - want[..., :D]).abs().max())
+        assert err <= 2.0 ** -7 * scale, (drop.p, err, scale)
+        assert rel_l2(got[..., :D], want[..., :D]) < 4e-3 or float(want[..., :D].abs().max()) < 1e-3 * scale
