@@ -545,6 +545,7 @@ extern "C" int fs2hip_dwconv_bwd_b(const void* dy, const void* x, int ldx, const
     }
   }
   FS2_LAUNCH_CHECK();
+  if (!dw) return 0;  // partial sums only: the caller finishes them with fs2hip_reduce_rows_multi (same sums, same order)
   const int nblk = fs2hip_dwconv_blocks(B, T);
   const long long stride = (long long)(K + 1) * C;
   // (one launch for both when they take the row-parallel path of fs2hip_reduce_slabs anyway: same sums, same order)

@@ -1118,7 +1118,16 @@ def dwconv_bwd(dy, x, w, dw, dbias, B, T, *, glu=False, out_dtype=torch.float32)
         _req(dbias.numel() == Cc, "dwconv_bwd: dbias size")
     dx = torch.empty(x.shape, device=x.device, dtype=out_dtype)
     nblk = lib().fs2hip_dwconv_blocks(B, T)
-    ws = _workspace(nblk * (K + 1) * Cc, x.device)
+    stride = (K + 1) * Cc
+    if _DEFER_SLABS and dbias is not None and stride <= 16384 and nblk >= 8:
+        # inside FastSpeech2.backward: the weight / bias gradient's second stage joins the batched finish (the same
+        # row-parallel sum in the same order as the launch it replaces; nothing reads dw / dbias before the flush)
+        part = torch.empty(nblk * stride, device=x.device, dtype=torch.float32)
+        _ok(lib().fs2hip_dwconv_bwd_b(_p(dy), _p(x), ldx, _p(w), _p(dx), int(out_dtype == torch.bfloat16) | (2 if xb else 0), _p(part),
+                                      None, None, B, T, Cc, K, int(glu), _stream()), "dwconv_bwd")
+        _defer_reduction(part, nblk, stride, stride, dw, K * Cc, dbias)
+        return dx
+    ws = _workspace(nblk * stride, x.device)
     _ok(lib().fs2hip_dwconv_bwd_b(_p(dy), _p(x), ldx, _p(w), _p(dx), int(out_dtype == torch.bfloat16) | (2 if xb else 0), _p(ws), _p(dw),
                                   _p(dbias), B, T, Cc, K, int(glu), _stream()), "dwconv_bwd")
     return dx

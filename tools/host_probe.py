@@ -25,3 +25,13 @@ for rep in range(3):
     t_end = time.perf_counter()
     print(f"{prec} b{batch}: host ms per step after a sync: " + " ".join(f"{(b - a) * 1e3:6.2f}" for a, b in zip(ts, ts[1:])) +
           f" | all six on the device after {(t_end - ts[0]) * 1e3:6.2f} ms", flush=True)
+# the host's own cost: ONE step enqueued into an empty queue (nothing to wait for, nothing pushing back), twelve times
+single = []
+for rep in range(12):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rig.step()
+    single.append((time.perf_counter() - t0) * 1e3)
+torch.cuda.synchronize()
+single.sort()
+print(f"{prec} b{batch}: host ms for one step into an empty queue: median {single[6]:.2f}, min {single[0]:.2f}, max {single[-1]:.2f}", flush=True)
