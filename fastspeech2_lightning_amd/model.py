@@ -296,11 +296,16 @@ class FastSpeech2(_Base):
     _VERSION: str = "1.2"
 
     def __init__(self, config, stats=None, lang2id: Optional[dict] = None, speaker2id: Optional[dict] = None,
-                 device: Optional[str] = None, seed: int = 1234, precision: str = "32-true"):
+                 device: Optional[str] = None, seed: int = 1234, precision: Optional[str] = None):
         super().__init__()
         # Lightning's Trainer(precision=...) for this path: "32-true" (the parity path) or "bf16-mixed" (GEMM operands
-        # rounded to bf16 for the bf16 MFMA; parameters, activations, accumulation and the optimizer stay fp32)
-        H.set_precision(precision)
+        # rounded to bf16 for the bf16 MFMA; parameters, activations, accumulation and the optimizer stay fp32).
+        # An explicit constructor value (or FS2_PRECISION) outranks a Trainer left at its default -- see
+        # ``_adopt_trainer_precision``; "32-split" can only be chosen this way (Trainer rejects the string).
+        if precision is None:
+            precision = _os.environ.get("FS2_PRECISION") or None
+        self._precision_explicit = precision is not None
+        H.set_precision(precision or "32-true")
         self.precision = H.get_precision()
         if not isinstance(config, FastSpeech2Config):
             from pydantic import ValidationError
@@ -805,7 +810,14 @@ class FastSpeech2(_Base):
     def _adopt_trainer_precision(self):
         """``Trainer(precision=...)`` reaches a LightningModule as ``self.trainer.precision`` ("32-true", "bf16-mixed",
         ...), not as a constructor argument: take it from there when a trainer is attached (fs2/cli/train.py:33-41
-        passes the precision to the Trainer).  A precision this path has no arithmetic for is refused."""
+        passes the precision to the Trainer).  A precision this path has no arithmetic for is refused.
+
+        Precedence: ``Trainer()`` defaults to "32-true", so a trainer value of "32-true" cannot be told from
+        "nothing was asked for".  A precision given explicitly to the constructor (or through ``FS2_PRECISION``)
+        therefore survives a trainer left at that default -- ``FastSpeech2(config, precision="bf16-mixed")`` under a
+        plain ``Trainer()`` stays bf16-mixed, "32-split" stays reachable -- with one warning naming both values.  A
+        NON-default trainer value is what the user asked the Trainer for and is adopted (warning when it overrides an
+        explicit constructor value); a module built without a precision follows the trainer either way."""
         try:
             trainer = self.trainer
         except Exception:  # LightningModule.trainer raises while detached
@@ -818,7 +830,16 @@ class FastSpeech2(_Base):
             raise ValueError(f"Trainer(precision={prec!r}): this path runs \"32-true\" and \"bf16-mixed\" "
                              f"(and \"32-split\"); other precisions have no kernels here")
         self._trainer_precision_seen = key
-        H.set_precision(key)
+        want = {0: "32-true", 1: "bf16-mixed", 2: "32-split"}[H.PRECISIONS[key]]
+        if self._precision_explicit and want != self.precision:
+            import warnings
+            if want == "32-true":  # the Trainer's default: the explicit constructor value stands
+                warnings.warn(f"FastSpeech2 was built with precision={self.precision!r} and the attached Trainer reports "
+                              f"its default {key!r}: keeping {self.precision!r} (pass the precision to the Trainer, or "
+                              "build the module without one, to follow the Trainer)", stacklevel=2)
+                return
+            warnings.warn(f"Trainer(precision={key!r}) overrides the module's precision={self.precision!r}", stacklevel=2)
+        H.set_precision(want)
         self.precision = H.get_precision()
 
     def setup(self, stage=None):

@@ -240,6 +240,35 @@ def test_monitored_validation_metric_and_trainer_precision():
         model.setup("fit")
 
 
+def test_constructor_precision_survives_a_default_trainer():
+    """``Trainer()`` defaults to "32-true".  A module built with an explicit precision keeps it under such a
+    trainer (with a warning) -- ``FastSpeech2(config, precision="bf16-mixed")`` under a plain Trainer was the documented
+    usage and "32-split" is not a string Trainer accepts; a non-default trainer value still wins."""
+    import warnings
+    from types import SimpleNamespace
+    from fastspeech2_lightning_amd import hip as H
+    from fastspeech2_lightning_amd.config import Stats
+    from fastspeech2_lightning_amd.model import FastSpeech2
+    _, batch = _model()
+    for chosen in ("bf16-mixed", "32-split"):
+        model = FastSpeech2(C.small_config(learn_alignment=False), Stats(**C.STATS), precision=chosen)
+        model.train()
+        model.trainer = SimpleNamespace(precision="32-true")
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            model.setup("fit")
+            model.on_fit_start()
+        assert model.precision == chosen and H.get_precision() == chosen
+        assert any("keeping" in str(x.message) for x in w)
+        model.training_step(batch)
+        assert model.precision == chosen and H.get_precision() == chosen
+    model.trainer = SimpleNamespace(precision="bf16-mixed")      # asked of the Trainer explicitly: adopted
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        model.setup("fit")
+    assert model.precision == "bf16-mixed" and any("overrides" in str(x.message) for x in w)
+
+
 def test_module_casts_keep_or_refuse_the_flat_parameter_alias():
     """``nn.Module._apply`` (``.half()``, ``.to(dtype)``, Lightning's precision plugins) would replace ``flat_param``
     with a converted copy and cut its alias with ``store.flat``: dtype casts raise, same-device moves are no-ops, and
