@@ -236,6 +236,30 @@ class Rig:
                 self.sync.wait()
         self.opt.step()
 
+    def settle(self, max_steps=6):
+        """Untimed steps until the step replays from its recorded launch plan (fastspeech2_lightning_amd/plan.py: the
+        first step of a geometry tunes tiles, the next one with an unchanged tile table is recorded, later ones replay).
+        Returns the number of extra steps run; 0 with FS2_PLAN=0 or when the step already replays."""
+        plans = self.model.plans
+        n = 0
+        from fastspeech2_lightning_amd import plan as PL
+        if not PL.ENABLED:
+            return 0
+        while n < max_steps:
+            before = plans.replayed
+            self.step()
+            n += 1
+            if plans.replayed > before:
+                break
+        torch.cuda.synchronize()
+        return n
+
+    def plan_info(self):
+        plans = self.model.plans
+        p = next(reversed(plans.plans.values()), None) if plans.plans else None
+        return {"replayed_steps": plans.replayed, "recorded": plans.recorded, "eager_steps": plans.eager,
+                "launches_per_step": p.launches if p else None, "segments": len(p.segments) if p else None}
+
     def timed(self, steps, run=None):
         run = run or self.step
         torch.cuda.synchronize()
@@ -381,6 +405,7 @@ def extra_leg(name, precision, batch_size, learn_alignment, steps, local, want_r
     for _ in range(3):
         rig.step()
     torch.cuda.synchronize()
+    rig.settle()
     dt = rig.timed(steps) / steps
     out = {"precision": precision, "batch_per_gpu": batch_size, "learn_alignment": learn_alignment, "gst_multispeaker": gst,
            "steps": steps,
@@ -399,6 +424,7 @@ def extra_leg(name, precision, batch_size, learn_alignment, steps, local, want_r
         out["roofline"] = roofline_of(sig, precision, prof, ov)
     log(f"{name}: {dt * 1e3:.2f} ms/step, {rig.frames / dt:,.0f} mel-frames/s (host enqueue {rig.host_enqueue_s / steps * 1e3:.2f} ms/step)")
     out["host_enqueue_ms_per_step"] = round(rig.host_enqueue_s / steps * 1e3, 3)
+    out["launch_plan"] = rig.plan_info()
     del rig
     torch.cuda.empty_cache()
     return out
@@ -441,8 +467,9 @@ def main():
             dist.init_process_group(backend)
 
     from fastspeech2_lightning_amd import hip as H
-    from fastspeech2_lightning_amd.parallel import share_tile_table
+    from fastspeech2_lightning_amd.parallel import apply_host_budget, share_tile_table
 
+    host = apply_host_budget(int(os.environ.get("LOCAL_WORLD_SIZE", world)))  # this rank's share of the host's cores
     force_sync = bool(os.environ.get("FS2_BENCH_FORCE_SYNC"))  # one rank, collectives issued anyway (RCCL call path)
     if force_sync and world == 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -482,6 +509,9 @@ def main():
         torch.cuda.synchronize()
         log("hipGraph captured and replayed once")
     run = graph.replay if graph is not None else step
+    if graph is None:
+        n_settle = rig.settle()
+        log(f"launch plan: {rig.plan_info()} after {n_settle} more untimed step(s)")
 
     if rig.sync is not None:
         rig.wait_events = []
@@ -510,6 +540,7 @@ def main():
     else:
         frames_all, padded_all = frames, padded
     losses = {k: float(v) for k, v in model.last_losses.items()}
+    plan_info = rig.plan_info()
     log(f"timed region: {elapsed / args.steps * 1e3:.2f} ms/step (host enqueue {host_enqueue / args.steps * 1e3:.2f} ms/step)")
 
     roofline = None
@@ -532,6 +563,7 @@ def main():
         model.precision = "32-split"
         for _ in range(2):
             step()  # (tunes the tiles of the split instances)
+        rig.settle()
         dt = rig.timed(n_leg) / n_leg
         model.precision = "32-true"
         split = {"precision": "32-split", "ms_per_step": round(dt * 1e3, 3), "value": round(frames / dt, 1), "unit": "mel-frames/s",
@@ -578,6 +610,9 @@ def main():
             "per_gpu_value": round(frames_all * args.steps / elapsed / world, 1),
             "padded_frames_per_s": round(padded_all * args.steps / elapsed, 1),
             "loss_total": round(losses.get("total", float("nan")), 5),
+            "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 3),
+            "host_threads_per_rank": host["threads"],
+            "launch_plan": plan_info,
             "roofline": roofline, "cpu_baseline": cpu, "split_fp32": split, "bf16_mixed_b64": bf16_b64,
             "learn_alignment": align, "gst_bf16_b64": gst_leg,
         }

@@ -277,6 +277,8 @@ class Trainer:
     def validate(self) -> float:
         from .data import validate
         cfg = self.model.config
+        if self.sync is not None:
+            self.sync.broadcast_buffers(0)  # DDP broadcast_buffers: every rank evaluates with rank 0's running statistics
         means = validate(self.model, self.batches(self.val_set, False, 0, cfg.training.val_data_workers))
         self.model.train()
         self.log(means)
@@ -436,6 +438,12 @@ def train(args, argv) -> int:
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
         else:
             dist.init_process_group(backend)
+    # this rank's share of the host: intra-op threads, and a cap on the DataLoader workers the config asks for
+    from .parallel import apply_host_budget
+    budget = apply_host_budget(int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+    t = p["config"].training
+    t.train_data_workers = min(int(t.train_data_workers), budget["workers"])
+    t.val_data_workers = min(int(t.val_data_workers), budget["workers"])
     trainer = Trainer(args, p, rank, world, local)
     steps = trainer.fit()
     if world > 1:

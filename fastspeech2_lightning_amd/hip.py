@@ -135,6 +135,12 @@ SIGNATURES = {
     "fs2hip_gst_attn_fwd": "pppppiiip",
     "fs2hip_gst_attn_bwd": "ppppppppiiip",
     "fs2hip_act_apply": "ppqip",
+    "fs2hip_memset": "piqp",
+    "fs2hip_plan_op_count": "",
+    "fs2hip_plan_op_id": None,      # (const char*)
+    "fs2hip_plan_events_create": None,   # (void**, int)
+    "fs2hip_plan_events_destroy": None,  # (void* const*, int)
+    "fs2hip_plan_replay": None,     # (const Fs2PlanCmd*, int, int, void*, void*, void* const*, int, int*)
 }
 EXPORTS = list(SIGNATURES)
 
@@ -157,8 +163,50 @@ def lib():
         L.fs2hip_reduce_rows_multi.argtypes = [C.POINTER(ReduceJob), C.c_int, C.c_void_p]
         L.fs2hip_reduce_slabs_multi.argtypes = [C.POINTER(SlabJob), C.c_int, C.c_void_p]
         L.fs2hip_transpose_cast_bf16_multi.argtypes = [C.POINTER(TransposeJob), C.c_int, C.c_void_p]
+        L.fs2hip_plan_op_id.argtypes = [C.c_char_p]
+        L.fs2hip_plan_events_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+        L.fs2hip_plan_events_destroy.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+        L.fs2hip_plan_replay.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p),
+                                         C.c_int, C.POINTER(C.c_int)]
         _lib = L
+    # while a launch plan is being recorded (plan.Recorder), every entry-point call also lands in the plan
+    return _lib if _REC is None else _REC.lib
+
+
+def real_lib():
+    """The library itself, never the recording proxy (the tuner's timing launches, the plan replayer)."""
+    lib()
     return _lib
+
+
+#: the active ``plan.Recorder`` (None outside a recording step)
+_REC = None
+
+
+def plan_flags() -> tuple:
+    """The module-level switches that choose kernels or launch counts: part of a launch plan's signature (tests and
+    measurement tools flip them between steps of one model)."""
+    return (int(GEMM_BF16), bool(BF16_STORAGE), bool(GEMM_TUNE), TILE_GEN[0], len(_TILE_CACHE), bool(ATTN_SPILL),
+            bool(ATTN_SCORES), bool(ATTN_SPILL_B), bool(SPLITK_IN_KERNEL), int(SPLITK_MAX),
+            os.environ.get("FS2_GEMM_TILE"), os.environ.get("FS2_DEFER_SLABS"), os.environ.get("FS2_CONV_DW_SPLITK"),
+            os.environ.get("FS2_DWCONV_TILE"), os.environ.get("FS2_ATTN_GEN1"))
+
+
+def plan_callback(fn):
+    """Host-side work that belongs at THIS point of the step's launch sequence (a gradient bucket's hand-off to the
+    all-reduce): runs now, and at the same point -- under the same current stream -- of every replay of a recorded plan."""
+    fn()
+    if _REC is not None:
+        _REC.callback(fn, _stream())
+
+
+def plan_host_op(fn):
+    """Order-free host-side work of a step that launches through ATen (not an entry point, so invisible to a recorded
+    plan): runs now, or -- while a plan is recorded -- right after the recorded step and after every replay."""
+    if _REC is not None:
+        _REC.host_op(fn)
+    else:
+        fn()
 
 
 _raw_stream = torch._C._cuda_getCurrentRawStream  # (device index) -> hipStream_t of torch's current stream
@@ -316,6 +364,9 @@ if _EXCLUDED:
     GEMM_TILES_B = tuple(t for t in GEMM_TILES_B if t not in _EXCLUDED)
     GEMM_TILES = tuple(t for t in GEMM_TILES if t not in _EXCLUDED)
 _TILE_CACHE = {}
+#: bumped by every write to the tile table: a recorded launch plan (plan.py) carries the tiles of its recording and is
+#: re-recorded when the table has changed since
+TILE_GEN = [0]
 #: per signature: [(isolated ms for 4 launches, tile), ...] sorted, and how often the signature was launched --
 #: what ``refine_tiles_in_step`` works from
 _TILE_TIMINGS = {}
@@ -349,12 +400,14 @@ def refine_tiles_in_step(step, rounds: int = 5, candidates: int = 2, top: int = 
         keep = _TILE_CACHE[key]
         for ms_iso, tile in _TILE_TIMINGS[key][1:1 + candidates]:
             _TILE_CACHE[key] = tile
+            TILE_GEN[0] += 1
             t = min(timed(), timed())
             if t < base * (1.0 - min_gain):
                 if log:
                     log(f"in-step tile refinement {key[:3]}: tile {keep} -> {tile}, step {base:.3f} -> {t:.3f} ms")
                 base, keep, changed = t, tile, changed + 1
         _TILE_CACHE[key] = keep
+        TILE_GEN[0] += 1
     return base, changed
 
 
@@ -394,6 +447,7 @@ def load_tile_table(table: dict) -> None:
     import ast
     for k, v in table.items():
         _TILE_CACHE[ast.literal_eval(k) if isinstance(k, str) else tuple(k)] = int(v)
+    TILE_GEN[0] += 1
 
 
 def save_tile_cache(path) -> None:
@@ -431,9 +485,9 @@ def _tune_tile(a) -> int:
         if c is not None:
             c[0] += 1
         return t
-    if not GEMM_TUNE or torch.cuda.is_current_stream_capturing():
+    if not GEMM_TUNE or _REC is not None or torch.cuda.is_current_stream_capturing():
         return 0
-    L, s = lib(), _stream()
+    L, s = real_lib(), _stream()
     best, best_ms = 0, float("inf")
     timings = []
     # the BK=16 core has no bf16 instance (it runs in fp32): last resort in bf16-mixed mode
@@ -461,6 +515,7 @@ def _tune_tile(a) -> int:
         if ms < best_ms:
             best, best_ms = tile, ms
     _TILE_CACHE[key] = best
+    TILE_GEN[0] += 1
     if timings:
         _TILE_TIMINGS[key] = sorted(timings)
         _TILE_CALLS[key] = [1]
@@ -1331,6 +1386,15 @@ def masked_loss(pred, target, lens, B, T, Cc, *, kind="mse", weight=1.0, loss_ou
 # ------------------------------------------------------------------------------------------
 # optimizer and elementwise
 # ------------------------------------------------------------------------------------------
+def zeros(*shape, device, dtype=torch.float32) -> torch.Tensor:
+    """``torch.zeros`` as an entry-point launch (``fs2hip_memset`` on the current stream): inside a training step the
+    fill must be part of a recorded launch plan, which an ATen kernel is not."""
+    t = torch.empty(*shape, device=device, dtype=dtype)
+    _req(t.is_cuda and t.device.index == _current_device(), "zeros: the tensor must live on the current GPU")
+    _ok(lib().fs2hip_memset(_p(t), 0, t.numel() * t.element_size(), _stream()), "memset")
+    return t
+
+
 def new_step_state(device) -> torch.Tensor:
     """32-byte device record {uint64 step; float lr, bc1, bc2, clip_coef, grad_norm, pad} as 4 x int64."""
     st = torch.zeros(4, device=device, dtype=torch.int64)

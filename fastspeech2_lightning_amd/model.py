@@ -23,6 +23,7 @@ import torch
 from . import hip as H
 from . import modules as M
 from . import params as P
+from . import plan as PL
 from .config import (BadDataError, FastSpeech2Config, InferenceControl, N_PHONOLOGICAL_FEATURES, Stats,
                      TargetTrainingTextRepresentationLevel, TextProcessor)
 
@@ -210,7 +211,7 @@ class FastSpeech2Loss:
         m.env.join()  # variance predictors run on the side stream during a training forward
         cfg, t = m.config.model, m.config.training
         dev = m.device_
-        slots = torch.zeros(len(LOSS_KEYS) + 1, device=dev, dtype=torch.float32)
+        slots = H.zeros(len(LOSS_KEYS) + 1, device=dev)
         want = m.training
         B = output["src_lens"].numel()
         Ts, Tm = output["src_mask"].shape[1], output["tgt_mask"].shape[1]
@@ -387,6 +388,8 @@ class FastSpeech2(_Base):
         self._tables = {}
         self._ctx = self._loss_grads = self._loss_slots = self._hard_idx = None
         self.grad_sync = None  # set by parallel.GradSync for data-parallel training
+        self.plans = PL.PlanCache()  # recorded launch plans of training steps, per batch geometry (plan.py)
+        self.plan_enabled = True     # False: every step of THIS model eager (FS2_PLAN=0: of every model)
         self.training = False
         self.env.training = False
 
@@ -566,7 +569,7 @@ class FastSpeech2(_Base):
             # utterance (1.4 ms on 32 wavefronts): started now on the side stream, it runs under the decoder and
             # PostNet instead of between forward and backward.  fs2/loss.py:109-116 gives weight and inputs.
             lp = va["attn_logprob"]
-            slot = torch.zeros(1, device=lp.device, dtype=torch.float32)
+            slot = H.zeros(1, device=lp.device)
             with self.env.side(lp, slot, batch["src_lens"], batch["mel_lens"]):
                 g_ctc = H.attn_ctc_loss(lp.view(lp.shape[0], lp.shape[2], lp.shape[3]), batch["src_lens"],
                                         batch["mel_lens"], self.config.training.attn_ctc_loss_weight, slot, want_grad=True)
@@ -587,7 +590,9 @@ class FastSpeech2(_Base):
             self._ctx = dict(text=text, enc=enc_ctx, va=va_ctx, dec=dec_ctx, dec_out=y, post=post_ctx, B=B, Ts=Ts, Tm=Tm,
                              batch=batch, gst=gst_ctx)
         if self.env.training and self.store.bn_counters.numel():
-            self.store.bn_counters.add_(1)  # every BatchNorm of the model has run once in train mode
+            # every BatchNorm of the model has run once in train mode (an ATen add: order-free, so a recorded launch
+            # plan re-runs it after each replay instead of containing it)
+            H.plan_host_op(lambda c=self.store.bn_counters: c.add_(1))
         self.env.join()  # variance predictors of a teacher-forced forward ran on the side stream under the decoder
         if not self._in_step:  # called directly (evaluation, teacher forcing): raise at once, as the reference does
             self.check_bad_data()
@@ -672,10 +677,10 @@ class FastSpeech2(_Base):
         if env.side_enabled:
             with env.side():
                 env._side_held.extend(H.flush_grad_reductions())
-                sync.bucket_ready(bucket)
+                H.plan_callback(lambda: sync.bucket_ready(bucket))
         else:
             H.flush_grad_reductions()
-            sync.bucket_ready(bucket)
+            H.plan_callback(lambda: sync.bucket_ready(bucket))
 
     def _rowsum(self, d):
         """[B, T, D] -> [B, D]: gradient of a per-utterance vector that was broadcast over time (one launch)."""
@@ -709,9 +714,7 @@ class FastSpeech2(_Base):
                 p.grad = p.grad.clone()
         self._in_step = True
         try:
-            output = self(batch)
-            losses = self.loss(output, self._ctx["batch"], self.current_epoch)
-            self.backward()
+            losses, output = self._planned_step(batch)
         finally:
             self._in_step = False
         self.last_losses, self.last_output = losses, output
@@ -723,6 +726,63 @@ class FastSpeech2(_Base):
         if torch.is_grad_enabled():
             return _DeliverGrad.apply(p, losses["total"], self)
         return losses["total"]
+
+    # ---- the step itself: eager, recorded, or replayed from its launch plan (plan.py) ------------------------------------
+    def _run_step(self, batch):
+        output = self(batch)
+        losses = self.loss(output, self._ctx["batch"], self.current_epoch)
+        self.backward()
+        return losses, output
+
+    def _plan_signature(self, batch):
+        """Everything a recorded step's launch sequence depends on: the batch's geometry (tensor shapes, which optional
+        entries are there), and the model-side switches that choose kernels, streams or arguments.  None: not plannable."""
+        if not (PL.ENABLED and self.plan_enabled and H.GEMM_PROFILE is None and not self.precision_overrides and H._REC is None
+                and self.variance_adaptor is not None) or torch.cuda.is_current_stream_capturing():
+            return None
+        geo = []
+        for k in sorted(batch):
+            v = batch[k]
+            if torch.is_tensor(v):
+                geo.append((k, tuple(v.shape)) if v.dim() else (k, int(v)))
+            elif isinstance(v, (int, float)) or v is None:
+                geo.append((k, v))
+        t = self.config.training
+        bin_w = min(self.current_epoch / t.attn_bin_loss_warmup_epochs, 1.0) if self.config.model.learn_alignment else 0.0
+        sync = self.grad_sync
+        weights = (t.pitch_loss_weight, t.energy_loss_weight, t.duration_loss_weight, t.mel_loss_weight,
+                   t.postnet_loss_weight, t.attn_ctc_loss_weight, t.attn_bin_loss_weight)
+        return (tuple(geo), self.precision, bool(self.env.side_enabled), id(sync) if sync else 0, bin_w, weights,
+                getattr(self.postnet, "dropout_p", None), M.BF16_CHAIN, FP32_TRANSPOSED, self.env.seed, H.plan_flags())
+
+    def _planned_step(self, batch):
+        sig = self._plan_signature(batch)
+        if sig is None:
+            return self._run_step(batch)
+        plans = self.plans
+        plan = plans.lookup(sig)
+        if plan is not None:
+            with torch.cuda.device(self.device_):
+                plan.feed(self.prepare_batch(batch))
+                losses, output = plan.replay(getattr(self.env, "_side_stream", None))
+            self._loss_slots, self._hard_idx = plan.extra["loss_slots"], plan.extra["hard_idx"]
+            if plan.extra["bad"] is not None:
+                self._pending_bad.append((plan.extra["bad"], list(batch.get("basename") or [])))
+            plans.replayed += 1
+            return losses, output
+        if not plans.should_record(sig):
+            plans.eager += 1
+            return self._run_step(batch)
+        with torch.cuda.device(self.device_):
+            pb = self.prepare_batch(batch)
+            inputs = {k: v for k, v in pb.items() if torch.is_tensor(v) and v.is_cuda}
+            n_bad = len(self._pending_bad)
+            plan, (losses, output) = PL.record(lambda: self._run_step(pb), inputs, self.device_)
+        bad = self._pending_bad[-1][0] if len(self._pending_bad) > n_bad else None
+        plan.extra = dict(loss_slots=self._loss_slots, hard_idx=self._hard_idx, bad=bad)
+        plans.store(sig, plan)
+        plans.recorded += 1
+        return losses, output
 
     def losses_to_host(self, losses=None) -> dict:
         """Every term of the last ``loss()`` as Python floats with ONE device-to-host copy (the slot vector)."""
@@ -799,6 +859,13 @@ class FastSpeech2(_Base):
             mean = stat[:-1] / stat[-1]
             for i, k in enumerate(keys):
                 self.callback_metrics[k] = mean[i]
+
+    def on_validation_start(self):
+        """Lightning's hook in front of a validation pass.  Data parallel through ``parallel.GradSync``: every rank
+        evaluates with rank 0's BatchNorm running statistics, as under torch DDP's ``broadcast_buffers=True``
+        (``GradSync.broadcast_buffers``; under Lightning's own DDP strategy the wrapper does it and ``grad_sync`` is None)."""
+        if self.grad_sync is not None:
+            self.grad_sync.broadcast_buffers(0)
 
     def on_train_batch_end(self, outputs=None, batch=None, batch_idx=0):
         """Lightning's per-step hook: the reference raises ``BadDataError`` inside the step's forward

@@ -79,6 +79,8 @@ class Env:
         ev = torch.cuda.Event()
         ev.record(st)
         torch.cuda.current_stream().wait_event(ev)
+        if H._REC is not None:
+            H._REC.sync(st.cuda_stream, H._stream())
         self._side_dirty = False
         self._side_held = []
 
@@ -98,6 +100,8 @@ class _SideSection:
         ev = torch.cuda.Event()
         ev.record()
         env._side_stream.wait_event(ev)
+        if H._REC is not None:
+            H._REC.sync(H._stream(), env._side_stream.cuda_stream)
         env._side_held.extend(self.tensors)
         env._side_dirty = True
         self.ctx = torch.cuda.stream(env._side_stream)
@@ -671,7 +675,7 @@ class StyleEncoder:
         _, Hh, Ww, C = x.shape
         feat = x.view(B * Hh, Ww * C)
         gi = H.linear_fwd(feat, S.p(self.wih), S.p(self.bih))            # rows (b, t)
-        hs = torch.zeros(Hh + 1, B, U, device=mel.device, dtype=torch.float32)
+        hs = H.zeros(Hh + 1, B, U, device=mel.device)
         gates = []
         for t in range(Hh):
             gh = H.linear_fwd(hs[t], S.p(self.whh), S.p(self.bhh))

@@ -58,6 +58,18 @@ class GradSync:
         for b in self.store.buffers.values():
             dist.broadcast(b, src, group=self.group)
 
+    def broadcast_buffers(self, src: int = 0):
+        """torch DDP's ``broadcast_buffers=True`` (Lightning's default strategy, fs2/cli/train.py:33-41; SURVEY.md 2.4
+        (2)): rank 0's BatchNorm running statistics and step counters reach every rank at the start of each forward.  A
+        TRAINING forward never reads them (batch statistics), so the only places a rank's own running statistics could
+        be observed are an evaluation forward and a checkpoint -- this is called in front of both (``validation_step``
+        's first batch, ``on_save_checkpoint``, the native trainer's validate / save), which gives DDP's observable
+        state, rank 0's buffers on every rank, for two dozen tiny broadcasts per validation instead of per step."""
+        if self.world == 1 and not self.force:
+            return
+        for b in self.store.buffers.values():  # (the num_batches_tracked entries are views of store.bn_counters)
+            dist.broadcast(b, src, group=self.group)
+
     @property
     def grad_scale(self) -> float:
         return 1.0 / self.world
@@ -75,3 +87,25 @@ def share_tile_table(src: int = 0, process_group=None) -> int:
     if dist.get_rank(process_group) != src:
         H.load_tile_table(box[0])
     return len(box[0])
+
+
+def host_budget(local_world: int) -> dict:
+    """What one rank may use of the host when ``local_world`` ranks share it.  A rank is one Python
+    thread that enqueues launches plus RCCL's proxy thread; torch's intra-op pool defaults to EVERY core, and eight ranks
+    each spinning up a 128-thread pool for a stray host-side op (collation, ``.cpu()`` reductions, checkpoint
+    conversion) starve one another's enqueue threads.  ``threads`` = cores // ranks, at least 1; ``workers`` = the most
+    DataLoader worker processes a rank should start (cores // ranks - 2 for the enqueue and proxy threads, at least 0)."""
+    import os
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:  # pragma: no cover
+        cores = os.cpu_count() or 1
+    share = max(1, cores // max(1, int(local_world)))
+    return {"cores": cores, "threads": share, "workers": max(0, share - 2)}
+
+
+def apply_host_budget(local_world: int) -> dict:
+    """``torch.set_num_threads`` to this rank's share (call once per rank, before the first step)."""
+    b = host_budget(local_world)
+    torch.set_num_threads(b["threads"])
+    return b

@@ -503,6 +503,48 @@ int fs2hip_gst_attn_bwd(const float* dctx, const float* q, const float* k, const
                         float* dq, float* dk_part, float* dv_part, int B, int NT, int heads, void* stream);
 int fs2hip_act_apply(const float* x, float* out, long long n, int act, void* stream);
 
+/* dst[0 .. nbytes) = byte, enqueued on the stream (what torch.zeros / Tensor.zero_() did inside a step: the loss slot
+ * vector of fs2/model.py:387-389's terms, the GRU's initial state fs2/gst/model.py:140-147).  A launch-plan command like
+ * every other entry point, which an ATen fill is not. */
+int fs2hip_memset(void* dst, int byte, long long nbytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Launch plans: a training step's whole launch sequence enqueued by ONE call.
+ *
+ * The reference's step is Python all the way down (Lightning -> nn.Module.forward -> ATen dispatch,
+ * fs2/model.py:153-268, :384-390); this build's eager step is Python down to the entry points above (~590 launches,
+ * ~18 us of interpreter time each: the host needs 10 ms to enqueue an 11 ms bf16 step).  A plan is that sequence
+ * recorded once per batch geometry -- every entry-point call with its arguments, on which of the two streams it
+ * ran, and the fork / join events between them -- and replayed by fs2hip_plan_replay: the host cost of a step
+ * becomes the launches themselves.  The recorded step's temporaries live in a memory pool of the plan's own (the
+ * caller's business: fastspeech2_lightning_amd/plan.py), so the recorded addresses stay valid; inputs are copied into
+ * the recorded input buffers; dropout masks, the learning-rate schedule and BatchNorm statistics advance through
+ * device memory exactly as in the eager step, which is why a replay is bit-identical to it (tests/test_plan_gpu.py).
+ *
+ * op >= 0: index of an entry point (fs2hip_plan_op_id(name); the table is generated from this header by
+ *          tools/gen_plan_thunks.py -> csrc/plan_thunks.inc); a[i] = its i-th argument, the stream excluded:
+ *          pointers and integers as they are (int sign-extended), a float as its bit pattern in the low 32 bits;
+ *          struct arguments (Fs2GemmArgs, job arrays) point to HOST copies the plan's owner keeps alive.
+ * FS2_PLAN_SYNC: record events[a[0]] on stream a[1], make stream a[2] wait for it (stream indices: 0 main, 1 side).
+ * ------------------------------------------------------------------------------------ */
+#define FS2_PLAN_SLOTS 20
+#define FS2_PLAN_SYNC (-1)
+typedef struct {
+  int op;      /* entry-point id or FS2_PLAN_SYNC */
+  int stream;  /* 0: main stream, 1: side stream */
+  unsigned long long a[FS2_PLAN_SLOTS];
+} Fs2PlanCmd;
+
+int fs2hip_plan_op_count(void);
+/* id of an entry point by name, -1 when it is not a plan op (no stream parameter, unknown) */
+int fs2hip_plan_op_id(const char* name);
+/* n events for FS2_PLAN_SYNC commands (created without timing) into out[0..n); destroy frees them */
+int fs2hip_plan_events_create(void** out, int n);
+int fs2hip_plan_events_destroy(void* const* events, int n);
+/* enqueues cmds[first .. last); on failure returns the failing command's code and writes its index to *failed_at */
+int fs2hip_plan_replay(const Fs2PlanCmd* cmds, int first, int last, void* main_stream, void* side_stream,
+                       void* const* events, int n_events, int* failed_at);
+
 #ifdef __cplusplus
 }
 #endif

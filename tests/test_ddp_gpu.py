@@ -44,10 +44,15 @@ def _rank(rank, world, port, q, variant="plain"):
     sync = GradSync(model.store)
     sync.broadcast_parameters(0)
     model.grad_sync = sync
-    for _ in range(2):  # twice: the second pass reuses cached scratch / stream state
+    # four times: eager, then RECORDED into a launch plan (the bucket hand-offs become the plan's host callbacks, run
+    # between its segments under the side stream), then replayed twice -- the exchanged gradient must come out the same
+    for _ in range(4):
         model.training_step(batches[rank])
         sync.wait()
         torch.cuda.synchronize()
+    assert model.plans.recorded == 1 and model.plans.replayed == 2
+    segs = next(iter(model.plans.plans.values())).segments
+    assert sum(1 for s in segs if s[2] is not None) == len(sync.by_id)  # one hand-off per gradient bucket
     got = model.store.grad
     err = float((got - want).abs().max() / want.abs().max())
     q.put((rank, err, len(sync.ranges)))

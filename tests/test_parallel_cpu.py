@@ -46,8 +46,13 @@ def _worker(rank, world, port, out):
         for b in (3, 2, 1, 0):  # the backward pass completes buckets from the last to the first
             sync.bucket_ready(b)
         sync.wait()
-        out[rank] = dict(flat=S.flat.clone(), grad=S.grad.clone(), buf=S.buffers["b.running_mean"].clone(),
-                         scale=sync.grad_scale, ranges=sync.ranges)
+        buf_after_start = S.buffers["b.running_mean"].clone()
+        # ranks then keep their own running statistics (per-rank batches) until an evaluation / checkpoint: DDP's
+        # broadcast_buffers semantics = rank 0's buffers everywhere at those points
+        S.buffers["b.running_mean"].add_(10.0 * (rank + 1))
+        sync.broadcast_buffers(0)
+        out[rank] = dict(flat=S.flat.clone(), grad=S.grad.clone(), buf=buf_after_start,
+                         buf_eval=S.buffers["b.running_mean"].clone(), scale=sync.grad_scale, ranges=sync.ranges)
     finally:
         dist.destroy_process_group()
 
@@ -85,7 +90,22 @@ def test_gradsync_world2_gloo():
     assert torch.equal(r0["grad"], expect) and torch.equal(r1["grad"], expect)
     assert torch.equal(r0["flat"], r1["flat"])  # rank 0's weights everywhere
     assert float(r1["buf"][0]) == 1.0  # BatchNorm buffers too
+    assert float(r0["buf_eval"][0]) == 11.0 and float(r1["buf_eval"][0]) == 11.0  # rank 0's statistics at evaluation time
     assert r0["scale"] == 0.5
+
+
+def test_host_budget_divides_the_cores_between_ranks():
+    """a rank's intra-op threads and DataLoader workers are its SHARE of the host, not all of it."""
+    from fastspeech2_lightning_amd.parallel import apply_host_budget, host_budget
+    cores = len(os.sched_getaffinity(0))
+    one, eight = host_budget(1), host_budget(8)
+    assert one["threads"] == cores and eight["threads"] == max(1, cores // 8)
+    assert eight["workers"] == max(0, cores // 8 - 2) and host_budget(10 ** 6)["threads"] == 1
+    before = torch.get_num_threads()
+    try:
+        assert apply_host_budget(4)["threads"] == torch.get_num_threads() == max(1, cores // 4)
+    finally:
+        torch.set_num_threads(before)
 
 
 def test_weak_scaling_batches_share_the_structure_and_differ_in_content():

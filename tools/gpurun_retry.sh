@@ -1,11 +1,12 @@
 #!/bin/bash
-# usage: tools/gpurun_retry.sh TIMEOUT_S 'command'  -- re-submits only while gpurun answers "no box free" (exit 3: nothing ran, nothing charged)
-T=$1; shift
+# gpurun with retries ONLY for exit code 3 (no box / slot free: nothing ran, nothing charged).  Any other exit code -- the
+# command's own result, a refusal, a timeout -- is returned at once: a GPU command is never re-run by this script.
+# usage: tools/gpurun_retry.sh <timeout seconds> '<command>'
+t="$1"; shift
 for i in $(seq 1 12); do
-  /usr/local/graft/bin/gpurun --timeout "$T" -- "$@"
+  /usr/local/graft/bin/gpurun --timeout "$t" -- "$@"
   rc=$?
-  if [ $rc -ne 3 ]; then exit $rc; fi
-  echo "[retry] no box free (attempt $i); sleeping 150 s"
-  sleep 150
+  [ "$rc" -ne 3 ] && exit "$rc"
+  sleep 120
 done
 exit 3
