@@ -245,11 +245,14 @@ class Rig:
         from fastspeech2_lightning_amd import plan as PL
         if not PL.ENABLED:
             return 0
-        while n < max_steps:
+        # every rank must run the SAME number of steps (each holds the bucket all-reduces): with more than one rank the
+        # count is fixed -- eager with the shared tile table, recorded, replayed -- instead of "until this rank replays"
+        fixed = 3 if self.sync is not None else None
+        while n < (fixed or max_steps):
             before = plans.replayed
             self.step()
             n += 1
-            if plans.replayed > before:
+            if fixed is None and plans.replayed > before:
                 break
         torch.cuda.synchronize()
         return n

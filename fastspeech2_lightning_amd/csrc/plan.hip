@@ -69,22 +69,22 @@ extern "C" int fs2hip_memset(void* dst, int byte, long long nbytes, void* stream
   return (int)hipMemsetAsync(dst, byte, (size_t)nbytes, (hipStream_t)stream);
 }
 
-extern "C" int fs2hip_plan_replay(const Fs2PlanCmd* cmds, int first, int last, void* main_stream, void* side_stream,
+extern "C" int fs2hip_plan_replay(const Fs2PlanCmd* cmds, int first, int last, void* const* streams, int n_streams,
                                   void* const* events, int n_events, int* failed_at) {
-  if (!cmds || first < 0 || last < first) return FS2HIP_EINVAL;
-  void* const streams[2] = {main_stream, side_stream};
+  if (!cmds || first < 0 || last < first || !streams || n_streams < 1) return FS2HIP_EINVAL;
+  const unsigned long long ns = (unsigned long long)n_streams;
   for (int i = first; i < last; ++i) {
     const Fs2PlanCmd& c = cmds[i];
     int rc;
     if (c.op == FS2_PLAN_SYNC) {
       const unsigned long long e = c.a[0], rs = c.a[1], ws = c.a[2];
-      if (!events || e >= (unsigned long long)n_events || rs > 1 || ws > 1) {
+      if (!events || e >= (unsigned long long)n_events || rs >= ns || ws >= ns) {
         rc = FS2HIP_EINVAL;
       } else {
         rc = (int)hipEventRecord((hipEvent_t)events[e], (hipStream_t)streams[rs]);
         if (rc == 0 && rs != ws) rc = (int)hipStreamWaitEvent((hipStream_t)streams[ws], (hipEvent_t)events[e], 0);
       }
-    } else if ((unsigned)c.stream > 1u) {
+    } else if ((unsigned)c.stream >= (unsigned)n_streams) {
       rc = FS2HIP_EINVAL;
     } else {
       rc = fs2_plan_dispatch(c.op, c.a, streams[c.stream]);

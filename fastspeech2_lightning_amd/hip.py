@@ -140,7 +140,7 @@ SIGNATURES = {
     "fs2hip_plan_op_id": None,      # (const char*)
     "fs2hip_plan_events_create": None,   # (void**, int)
     "fs2hip_plan_events_destroy": None,  # (void* const*, int)
-    "fs2hip_plan_replay": None,     # (const Fs2PlanCmd*, int, int, void*, void*, void* const*, int, int*)
+    "fs2hip_plan_replay": None,     # (const Fs2PlanCmd*, int, int, void* const*, int, void* const*, int, int*)
 }
 EXPORTS = list(SIGNATURES)
 
@@ -166,8 +166,8 @@ def lib():
         L.fs2hip_plan_op_id.argtypes = [C.c_char_p]
         L.fs2hip_plan_events_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
         L.fs2hip_plan_events_destroy.argtypes = [C.POINTER(C.c_void_p), C.c_int]
-        L.fs2hip_plan_replay.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p),
-                                         C.c_int, C.POINTER(C.c_int)]
+        L.fs2hip_plan_replay.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_int,
+                                         C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int)]
         _lib = L
     # while a launch plan is being recorded (plan.Recorder), every entry-point call also lands in the plan
     return _lib if _REC is None else _REC.lib

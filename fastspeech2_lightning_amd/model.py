@@ -41,6 +41,15 @@ import os as _os
 FP32_TRANSPOSED = _os.environ.get("FS2_FP32_TRANSPOSED", "1") != "0"
 
 
+#: FS2_PRED_LANES=1 (measurement aid, off by default): the three variance predictors -- independent chains of ~25 small
+#: launches each, a training step feeds them targets (fs2/variance_adaptor.py:309-352) -- each get a side stream of their
+#: own instead of sharing lane 0 with the weight-gradient GEMMs.  Measured round 5 (same box, alternating, launch plans
+#: on): bf16-mixed batch 64 11.13-11.20 ms with lanes against 10.99-11.00 without, fp32 18.53-18.55 against 18.58-18.67:
+#: three more chains of small kernels take CU slots from the main chain as often as they fill idle ones.
+PRED_LANES = ({"energy": 1, "pitch": 2, "duration": 3} if _os.environ.get("FS2_PRED_LANES", "0") != "0"
+              else {"energy": 0, "pitch": 0, "duration": 0})
+
+
 class VarianceAdaptor:
     """reference ``fs2/variance_adaptor.py:84-412`` (order of operations ``:309-397``)."""
 
@@ -68,7 +77,7 @@ class VarianceAdaptor:
         if inference:
             pred, pctx = predictor.fwd(x, lens)
         else:  # training: the prediction feeds only the loss (the embedding uses the target) -> side stream
-            with self.env.side(x, lens):
+            with self.env.side(x, lens, lane=PRED_LANES[name]):
                 pred, pctx = predictor.fwd(x, lens)
         if inference:
             out, idx = H.bucket_embed_add(pred, S.b(pre + f"{name}_bins"), S.p(pre + f"{name}_embedding.weight"), x, control)
@@ -112,7 +121,8 @@ class VarianceAdaptor:
         if cfg.pitch.level.value == "phone":
             pitch_p, x, c["pitch"] = self._variance("pitch", x, pitch_t, src_lens, control.pitch, inference)
         if dur_aligned is not None or teacher_forcing or not inference:
-            with self.env.side(x, src_lens):  # durations come from the batch / the aligner: prediction feeds the loss only
+            # durations come from the batch / the aligner: prediction feeds the loss only
+            with self.env.side(x, src_lens, lane=PRED_LANES["duration"]):
                 logd, c["duration"] = self.duration_predictor.fwd(x, src_lens)
         else:
             logd, c["duration"] = self.duration_predictor.fwd(x, src_lens)
@@ -151,7 +161,7 @@ class VarianceAdaptor:
             if name not in c or dpred.get(name) is None:
                 continue
             ctx = c[name][0] if name != "duration" else c[name]
-            with env.side(dpred[name]):
+            with env.side(dpred[name], lane=PRED_LANES[name]):
                 out[name] = getattr(self, f"{name}_predictor").bwd(dpred[name], ctx)
         if "align" in c:  # the aligner's backward only meets the main chain at the text embedding's gradient
             with env.side(dpred.get("attn_ctc"), dpred.get("attn_bin")):
@@ -675,6 +685,10 @@ class FastSpeech2(_Base):
         if not sync:
             return
         if env.side_enabled:
+            # the pending second-stage sums include the predictors' (their backward chains run on lanes of their own):
+            # the main stream waits for THOSE lanes -- short chains enqueued at the start of the backward pass -- and
+            # never for lane 0, where the weight-gradient GEMMs run
+            env.join(only=[l for l in set(PRED_LANES.values()) if l != 0])
             with env.side():
                 env._side_held.extend(H.flush_grad_reductions())
                 H.plan_callback(lambda: sync.bucket_ready(bucket))
@@ -752,7 +766,7 @@ class FastSpeech2(_Base):
         sync = self.grad_sync
         weights = (t.pitch_loss_weight, t.energy_loss_weight, t.duration_loss_weight, t.mel_loss_weight,
                    t.postnet_loss_weight, t.attn_ctc_loss_weight, t.attn_bin_loss_weight)
-        return (tuple(geo), self.precision, bool(self.env.side_enabled), id(sync) if sync else 0, bin_w, weights,
+        return (tuple(geo), self.precision, bool(self.env.side_enabled), tuple(PRED_LANES.values()), id(sync) if sync else 0, bin_w, weights,
                 getattr(self.postnet, "dropout_p", None), M.BF16_CHAIN, FP32_TRANSPOSED, self.env.seed, H.plan_flags())
 
     def _planned_step(self, batch):
@@ -764,7 +778,7 @@ class FastSpeech2(_Base):
         if plan is not None:
             with torch.cuda.device(self.device_):
                 plan.feed(self.prepare_batch(batch))
-                losses, output = plan.replay(getattr(self.env, "_side_stream", None))
+                losses, output = plan.replay(self.env.side_streams())
             self._loss_slots, self._hard_idx = plan.extra["loss_slots"], plan.extra["hard_idx"]
             if plan.extra["bad"] is not None:
                 self._pending_bad.append((plan.extra["bad"], list(batch.get("basename") or [])))
@@ -957,9 +971,11 @@ class FastSpeech2(_Base):
             S._pviews, S._gviews, S._bviews, S._tviews, S._tviews32, S.flat_bf16 = {}, {}, {}, {}, {}, None
             self.step_state = self.step_state.to(device, copy=True)
             self.env.step_state = self.step_state
-            if getattr(self.env, "_side_stream", None) is not None:
+            if getattr(self.env, "_lanes", None):
                 self.env.join()
-                self.env._side_stream = None
+                self.env._lanes, self.env._side_stream = None, None
+            self.plans.clear()   # recorded launch plans hold the old device's addresses and streams
+            H._SCRATCH.clear()   # (scratch keyed by a destroyed side stream's handle would dangle)
             self.bad_count = self.bad_count.to(device, copy=True)
             if self.variance_adaptor is not None:
                 self.variance_adaptor.bad_count = self.bad_count

@@ -68,43 +68,58 @@ class Env:
     # kept alive until the join, so the caching allocator cannot hand their memory to the main stream early.
     side_enabled = os.environ.get("FS2_SIDE_STREAM", "1") != "0"  # FS2_SIDE_STREAM=0: everything on one stream
 
-    def side(self, *tensors):
-        """Context manager: run the enclosed launches on the side stream, after everything enqueued so far."""
-        return _SideSection(self, tensors)
+    def side(self, *tensors, lane: int = 0):
+        """Context manager: run the enclosed launches on a side stream, after everything enqueued so far.  ``lane``
+        picks one of several side streams: independent chains (the three variance predictors) each get their own and
+        run beside one another as well as beside the main chain."""
+        return _SideSection(self, tensors, lane)
 
-    def join(self):
-        st = getattr(self, "_side_stream", None)
-        if st is None or not getattr(self, "_side_dirty", False):
+    def side_streams(self) -> dict:
+        """{raw handle: torch.cuda.Stream} of the side streams created so far."""
+        return {st.cuda_stream: st for st in getattr(self, "_lanes", {}).values()}
+
+    def join(self, only=None):
+        """The current stream waits for the side streams that have run anything since their last join (``only``: just
+        these lanes -- the tensors held for the side streams are then kept)."""
+        lanes = getattr(self, "_lanes", None)
+        if not lanes or not getattr(self, "_side_dirty", None):
             return
-        ev = torch.cuda.Event()
-        ev.record(st)
-        torch.cuda.current_stream().wait_event(ev)
-        if H._REC is not None:
-            H._REC.sync(st.cuda_stream, H._stream())
-        self._side_dirty = False
-        self._side_held = []
+        for lane in sorted(self._side_dirty if only is None else self._side_dirty & set(only)):
+            st = lanes[lane]
+            ev = torch.cuda.Event()
+            ev.record(st)
+            torch.cuda.current_stream().wait_event(ev)
+            if H._REC is not None:
+                H._REC.sync(st.cuda_stream, H._stream())
+            self._side_dirty.discard(lane)
+        if not self._side_dirty:
+            self._side_held = []
 
 
 class _SideSection:
-    def __init__(self, env: Env, tensors):
-        self.env, self.tensors = env, tensors
+    def __init__(self, env: Env, tensors, lane=0):
+        self.env, self.tensors, self.lane = env, tensors, lane
         self.ctx = None
 
     def __enter__(self):
         env = self.env
         if not env.side_enabled:
             return self
-        if getattr(env, "_side_stream", None) is None:
-            env._side_stream = torch.cuda.Stream()
-            env._side_held = []
+        if getattr(env, "_lanes", None) is None:
+            env._lanes, env._side_held, env._side_dirty = {}, [], set()
+        st = env._lanes.get(self.lane)
+        if st is None:
+            st = env._lanes[self.lane] = torch.cuda.Stream()
+            if self.lane == 0:
+                env._side_stream = st
         ev = torch.cuda.Event()
         ev.record()
-        env._side_stream.wait_event(ev)
+        st.wait_event(ev)
         if H._REC is not None:
-            H._REC.sync(H._stream(), env._side_stream.cuda_stream)
+            H._REC.sync(H._stream(), st.cuda_stream)
         env._side_held.extend(self.tensors)
-        env._side_dirty = True
-        self.ctx = torch.cuda.stream(env._side_stream)
+        env._side_dirty.add(self.lane)
+        self.ctx = torch.cuda.stream(st)
         self.ctx.__enter__()
         return self
 

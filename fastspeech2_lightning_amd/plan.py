@@ -36,6 +36,7 @@ from . import hip as H
 
 SLOTS = 20
 SYNC = -1
+MAX_STREAMS = 8
 
 ENABLED = os.environ.get("FS2_PLAN", "1") != "0"
 #: a geometry is recorded the n-th time it is seen (the steps before run eagerly: tuner, scratch buffers, tables)
@@ -102,8 +103,7 @@ class Recorder:
     """Collects one step.  Use through ``record(...)`` below."""
 
     def __init__(self, main_stream: int):
-        self.main = int(main_stream)
-        self.side = None           # raw handle of the side stream, learnt from the first call / sync that names it
+        self.streams = [int(main_stream or 0)]   # raw handles: [0] the main stream, then side streams as they appear
         self.cmds = []             # (op, stream index, [slot values])
         self.keep = []             # host copies of struct arguments (addresses are in the slots)
         self.n_events = 0
@@ -114,13 +114,17 @@ class Recorder:
     # -- streams ---------------------------------------------------------------------------------------------------
     def stream_index(self, handle) -> int:
         handle = int(handle or 0)
-        if handle == self.main:
-            return 0
-        if self.side is None:
-            self.side = handle
-        if handle != self.side:
-            raise PlanError("launch plan: a launch went to a third stream (a plan knows the step's main and side stream)")
-        return 1
+        try:
+            return self.streams.index(handle)
+        except ValueError:
+            if len(self.streams) >= MAX_STREAMS:
+                raise PlanError(f"launch plan: the step used more than {MAX_STREAMS} streams")
+            self.streams.append(handle)
+            return len(self.streams) - 1
+
+    @property
+    def side(self):  # (the first side stream's handle, or None)
+        return self.streams[1] if len(self.streams) > 1 else None
 
     # -- entry-point calls -----------------------------------------------------------------------------------------
     def add(self, op, sig, args, name):
@@ -128,23 +132,20 @@ class Recorder:
         if len(vals) > SLOTS:
             raise PlanError(f"launch plan: {name} has {len(vals)} arguments, a command holds {SLOTS}")
         slots = []
-        if sig is None:  # (struct pointer[, count]): fs2hip_gemm, the *_multi job arrays
-            obj = vals[0]
-            obj = getattr(obj, "_obj", obj)          # C.byref(x) -> x
-            copy = type(obj)()
-            C.memmove(C.byref(copy), C.byref(obj), C.sizeof(obj))
-            self.keep.append(copy)
-            slots.append(C.addressof(copy))
-            for v in vals[1:]:
+        codes = sig if sig is not None else "p" + "q" * (len(vals) - 1)  # (struct pointer[, count]): fs2hip_gemm, *_multi
+        for c, v in zip(codes, vals):
+            obj = getattr(v, "_obj", v)                  # C.byref(x) -> x
+            if isinstance(obj, (C.Structure, C.Array)):  # a HOST struct / job array: the plan keeps its own copy
+                copy = type(obj)()
+                C.memmove(C.byref(copy), C.byref(obj), C.sizeof(obj))
+                self.keep.append(copy)
+                slots.append(C.addressof(copy))
+            elif c == "p":
+                slots.append(0 if v is None else int(v) & _M64)
+            elif c == "f":
+                slots.append(_float_bits(v))
+            else:  # i, q, Q
                 slots.append(int(v) & _M64)
-        else:
-            for c, v in zip(sig, vals):
-                if c == "p":
-                    slots.append(0 if v is None else int(v) & _M64)
-                elif c == "f":
-                    slots.append(_float_bits(v))
-                else:  # i, q, Q
-                    slots.append(int(v) & _M64)
         self.cmds.append((op, self.stream_index(stream), slots))
 
     # -- what modules.Env / parallel report ------------------------------------------------------------------------
@@ -212,7 +213,7 @@ class StepPlan:
         self.inputs = inputs          # key -> the device tensor the recorded step read
         self.result = result
         self.host_ops = rec.host_ops
-        self.side_handle = rec.side
+        self.stream_handles = list(rec.streams)   # [0] is replaced by the current stream of each replay
         self.n_events = rec.n_events
         self.events = (C.c_void_p * max(rec.n_events, 1))()
         if rec.n_events:
@@ -244,21 +245,22 @@ class StepPlan:
                 raise PlanError(f"launch plan: batch[{k!r}] does not have the recorded geometry")
             dst.copy_(src, non_blocking=True)
 
-    def replay(self, side_stream=None):
-        main = H._stream()
-        side = self.side_handle
-        if side is not None and side_stream is not None:
-            side = side_stream.cuda_stream
+    def replay(self, side_streams=None):
+        """``side_streams``: {raw handle: torch.cuda.Stream} of the model's side streams (host callbacks recorded under a
+        side stream run under ``torch.cuda.stream`` of it)."""
+        tab = (C.c_void_p * len(self.stream_handles))(*self.stream_handles)
+        tab[0] = H._stream()
         L = H.real_lib()
         for first, end, fn, st in self.segments:
             if end > first:
-                rc = L.fs2hip_plan_replay(self.cmds, first, end, main, side, self.events, self.n_events,
+                rc = L.fs2hip_plan_replay(self.cmds, first, end, tab, len(self.stream_handles), self.events, self.n_events,
                                           C.byref(self._failed))
                 if rc != 0:
                     raise RuntimeError(f"fs2hip: launch plan command {self._failed.value} failed with code {rc}")
             if fn is not None:
-                if st == 1 and side_stream is not None:
-                    with torch.cuda.stream(side_stream):
+                side = (side_streams or {}).get(self.stream_handles[st]) if st else None
+                if side is not None:
+                    with torch.cuda.stream(side):
                         fn()
                 else:
                     fn()

@@ -525,13 +525,14 @@ int fs2hip_memset(void* dst, int byte, long long nbytes, void* stream);
  *          tools/gen_plan_thunks.py -> csrc/plan_thunks.inc); a[i] = its i-th argument, the stream excluded:
  *          pointers and integers as they are (int sign-extended), a float as its bit pattern in the low 32 bits;
  *          struct arguments (Fs2GemmArgs, job arrays) point to HOST copies the plan's owner keeps alive.
- * FS2_PLAN_SYNC: record events[a[0]] on stream a[1], make stream a[2] wait for it (stream indices: 0 main, 1 side).
+ * FS2_PLAN_SYNC: record events[a[0]] on stream a[1], make stream a[2] wait for it (stream indices into the replay call's
+ *          stream table: 0 = the main stream, 1.. = the step's side streams).
  * ------------------------------------------------------------------------------------ */
 #define FS2_PLAN_SLOTS 20
 #define FS2_PLAN_SYNC (-1)
 typedef struct {
   int op;      /* entry-point id or FS2_PLAN_SYNC */
-  int stream;  /* 0: main stream, 1: side stream */
+  int stream;  /* index into the stream table of fs2hip_plan_replay: 0 main, 1.. side streams */
   unsigned long long a[FS2_PLAN_SLOTS];
 } Fs2PlanCmd;
 
@@ -542,7 +543,7 @@ int fs2hip_plan_op_id(const char* name);
 int fs2hip_plan_events_create(void** out, int n);
 int fs2hip_plan_events_destroy(void* const* events, int n);
 /* enqueues cmds[first .. last); on failure returns the failing command's code and writes its index to *failed_at */
-int fs2hip_plan_replay(const Fs2PlanCmd* cmds, int first, int last, void* main_stream, void* side_stream,
+int fs2hip_plan_replay(const Fs2PlanCmd* cmds, int first, int last, void* const* streams, int n_streams,
                        void* const* events, int n_events, int* failed_at);
 
 #ifdef __cplusplus

@@ -30,10 +30,12 @@ def compare_step(model, oracle, batch, tag):
     B, Ts, Tm = batch["text"].shape[0], batch["text"].shape[1], batch["mel"].shape[1]
     seen = DM.inject(model, oracle, B, Ts, Tm)
     oracle.zero_grad()
-    ref = oracle(batch)
-    ref_losses = oracle.loss(ref, batch, 0)
-    ref_losses["total"].backward()
-    total = model.training_step(batch)
+    with DM.ReluCapture(model, oracle) as relu:
+        ref = oracle(batch)
+        ref_losses = oracle.loss(ref, batch, 0)
+        ref_losses["total"].backward()
+        total = model.training_step(batch)
+    flips = relu.flips()
     out = model.last_output
     for k in ("output", "postnet_output", "duration_prediction", "pitch_prediction", "energy_prediction"):
         a, b = out[k].cpu(), ref[k].detach()
@@ -61,10 +63,19 @@ def compare_step(model, oracle, batch, tag):
         else:
             worst = max(worst, (k, r), key=lambda kr: kr[1])
     assert worst[1] < 2e-3, (tag, worst)
-    # (per tensor 1e-1 on this SMALL model: a single flipped ReLU is a larger share of a 64-row predictor tensor's gradient
-    #  than of the full-size one's, where tests/test_fullsize_gpu.py holds 5e-2; seen: 5.8e-2 on one pitch-predictor weight
-    #  once the attention backward took the forward pass's scores.  The group's relative L2 stays at 5e-3.)
-    assert relu_worst[1] < 1e-1 and (num / max(den, 1e-30)) ** 0.5 < 5e-3, (tag, relu_worst, (num / max(den, 1e-30)) ** 0.5)
+    # the ReLU-downstream bound is no longer a number tuned to an observation.  The sign patterns of
+    # every predictor ReLU are compared on both sides (DM.ReluCapture).  No flipped element: these tensors meet the same
+    # 2e-3 as everything else (profiles/r05_relu_flip_diag.txt: 9e-6 measured).  A flip is a NAMED element -- predictor,
+    # layer, utterance, token, channel, the oracle's pre-activation (which must then be within rounding of zero) -- and
+    # only then, for at most 3 of them, single tensors may differ by up to 1e-1 of their maximum (one flipped path is a
+    # visible share of a 64-row predictor gradient) while the group stays within 5e-3 relative L2.
+    group = (num / max(den, 1e-30)) ** 0.5
+    if not flips:
+        assert relu_worst[1] < 2e-3 and group < 2e-3, (tag, relu_worst, group)
+    else:
+        scale = max(float(p.abs().max()) for p in relu.pre.values())
+        assert len(flips) <= 3 and all(abs(f[4]) < 1e-5 * scale for f in flips), (tag, "ReLU flips", flips)
+        assert relu_worst[1] < 1e-1 and group < 5e-3, (tag, relu_worst, group, "with flipped ReLUs", flips)
     return seen, float(total)
 
 
@@ -84,6 +95,7 @@ def test_train_step_with_dropout_on_matches_oracle_with_the_same_masks(p_conf, p
     oracle.load_state_dict(sd)
     model.load_state_dict(sd)
     model.train(); oracle.train()
+    model.plan_enabled = False  # (DM.ReluCapture reads the ReLU outputs back inside the step: not a recordable step)
     model.postnet.dropout_p = oracle.postnet.dropout_p = p_post
     opt = model.configure_optimizers()[0][0]
     model.configure_gradient_clipping(opt, 1.0, "norm")  # Trainer(gradient_clip_val=1.0), fs2/cli/train.py:38

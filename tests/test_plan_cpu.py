@@ -51,7 +51,7 @@ def test_recorder_packs_pointers_integers_floats_and_struct_copies():
     rec.add(0, None, (C.byref(a), 0x55), "fs2hip_gemm")
     a.Mc = 99
     op, st, slots = rec.cmds[-1]
-    assert st == 1 and rec.side == 0x55
+    assert st == 1 and rec.side == 0x55 and rec.streams == [0, 0x55]
     kept = C.cast(slots[0], C.POINTER(hip.GemmArgs)).contents
     assert (kept.Mc, kept.Nc, kept.alpha) == (11, 22, 0.5)
     jobs = (hip.ReduceJob * 3)()
@@ -59,16 +59,19 @@ def test_recorder_packs_pointers_integers_floats_and_struct_copies():
     rec.add(1, None, (jobs, 3, 0), "fs2hip_reduce_rows_multi")
     op, st, slots = rec.cmds[-1]
     assert slots[1] == 3 and C.cast(slots[0], C.POINTER(hip.ReduceJob))[2].rows == 5
-    # forks / joins number their events, a third stream is refused
+    # forks / joins number their events; further streams get the next indices, up to the table's size
     rec.sync(0, 0x55)
     rec.sync(0x55, 0)
     assert [c[2] for c in rec.cmds[-2:]] == [[0, 0, 1], [1, 1, 0]] and rec.n_events == 2
+    rec.add(3, "pp", (1, 0x66), "y")
+    assert rec.cmds[-1][1] == 2 and rec.streams == [0, 0x55, 0x66]
     try:
-        rec.add(3, "pp", (1, 0x66), "y")
+        for h in range(0x100, 0x100 + plan.MAX_STREAMS):
+            rec.stream_index(h)
     except plan.PlanError:
         pass
     else:
-        raise AssertionError("a third stream must be refused")
+        raise AssertionError("more streams than the table holds must be refused")
 
 
 def test_plan_command_layout_matches_the_header():
