@@ -221,8 +221,17 @@ class Rig:
         self.frames = int(self.batch["mel_lens"].sum())
         self.padded = int(self.batch["mel"].shape[0] * self.batch["mel"].shape[1])
         self.wait_events = None  # N > 1: (before, after) HIP events around every GradSync.wait() of the timed steps
+        self.main_stream = None
+        if os.environ.get("FS2_BENCH_MAIN_PRIORITY") == "high":
+            self.main_stream = torch.cuda.Stream(device=f"cuda:{local}", priority=torch.cuda.Stream.priority_range()[1])
 
     def step(self):
+        if self.main_stream is not None:  # FS2_BENCH_MAIN_PRIORITY=high (measurement aid): the main chain on a high-priority stream
+            with torch.cuda.stream(self.main_stream):
+                return self._step()
+        return self._step()
+
+    def _step(self):
         with torch.no_grad():  # the native loop: the optimizer reads the flat gradient buffer, no autograd node
             self.model.training_step(self.dev_batch)
         if self.sync:

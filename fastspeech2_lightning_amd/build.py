@@ -42,7 +42,16 @@ def needs_build() -> bool:
     return any(d.stat().st_mtime > t for d in deps)
 
 
+def refresh_generated() -> None:
+    """csrc/plan_thunks.inc is generated from include/fs2hip.h (tools/gen_plan_thunks.py): rewritten here when the header
+    has moved on, so that a changed prototype cannot meet a stale unpacking line (the compiler would refuse it anyway)."""
+    gen = PKG.parent / "tools" / "gen_plan_thunks.py"
+    if gen.exists() and subprocess.run([sys.executable, str(gen), "--check"]).returncode != 0:
+        subprocess.run([sys.executable, str(gen)], check=True, stdout=subprocess.DEVNULL)
+
+
 def build(force: bool = False, verbose: bool = False) -> Path:
+    refresh_generated()
     if not force and not needs_build():
         return LIB
     objs = []

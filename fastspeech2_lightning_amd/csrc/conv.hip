@@ -23,7 +23,7 @@ __device__ __forceinline__ float dw_ld(const void* p, long long i) {
 // x: [B*T][ldx]; value at column c, gate (GLU) at column C + c.  XB: x and y are bf16 tensors (precision "bf16-mixed"
 // with bf16 activation storage: what autocast hands a convolution); the statistics are those of the ROUNDED outputs,
 // which is what BatchNorm then normalises.
-template <int K, bool GLU, bool STATS, bool XB = false>
+template <int K, bool GLU, bool STATS, bool XB = false, bool YB = XB>
 __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const void* __restrict__ x, int ldx,
                                                           const float* __restrict__ w, const float* __restrict__ bias,
                                                           void* __restrict__ y, float* __restrict__ partial, int B,
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const void* __restrict_
       float acc = bs;
 #pragma unroll
       for (int k = 0; k < K; ++k) acc = fmaf(wk[k], a[o + k], acc);
-      if constexpr (XB) {
+      if constexpr (YB) {
         const unsigned short r = dw_bf16(acc);
         ((unsigned short*)y)[((long long)b * T + t) * C + c] = r;
         acc = __builtin_bit_cast(float, (unsigned)r << 16);
@@ -431,7 +431,10 @@ extern "C" int fs2hip_dwconv_blocks(int B, int T) { return B * ((T + 4 * RUN - 1
 extern "C" int fs2hip_dwconv_part_rows(void) { return 4 * RUN; }
 
 #define DW_FWD(KK)                                                                                              \
-  if (io_bf16) {                                                                                                \
+  if (io_bf16 == 2) { /* fp32 in, bf16 out: the variance predictors' plain depthwise layer feeding a bf16-storage GEMM */ \
+    if (glu || stats) return FS2HIP_EINVAL;                                                                     \
+    dwconv_fwd_kernel<KK, false, false, false, true><<<grid, dim3(256), 0, s>>>(x, ldx, w, bias, y, partial, B, T, C); \
+  } else if (io_bf16) {                                                                                         \
     if (!glu) return FS2HIP_EINVAL; /* bf16 tensors: the Conformer convolution module's GLU form only */         \
     if (stats) dwconv_fwd_kernel<KK, true, true, true><<<grid, dim3(256), 0, s>>>(x, ldx, w, bias, y, partial, B, T, C); \
     else dwconv_fwd_kernel<KK, true, false, true><<<grid, dim3(256), 0, s>>>(x, ldx, w, bias, y, partial, B, T, C);      \
@@ -447,7 +450,7 @@ extern "C" int fs2hip_dwconv_fwd(const float* x, int ldx, const float* w, const 
   return fs2hip_dwconv_fwd_b(x, ldx, w, bias, y, partial, B, T, C, K, glu, stats, 0, stream);
 }
 
-// io_bf16: x and y are bf16 tensors (GLU form only)
+// io_bf16 = 1: x and y are bf16 tensors (GLU form only); 2: x fp32, y bf16 (plain form, no statistics)
 extern "C" int fs2hip_dwconv_fwd_b(const void* x, int ldx, const float* w, const float* bias, void* y, float* partial,
                                    int B, int T, int C, int K, int glu, int stats, int io_bf16, void* stream) {
   if (B <= 0 || T <= 0 || C <= 0 || ldx < (glu ? 2 * C : C)) return FS2HIP_EINVAL;
@@ -456,6 +459,8 @@ extern "C" int fs2hip_dwconv_fwd_b(const void* x, int ldx, const float* w, const
   hipStream_t s = (hipStream_t)stream;
   const char* tile_env = getenv("FS2_DWCONV_TILE");  // "0": the per-thread-window kernels everywhere (measurement aid, tests)
   const bool tiles_off = tile_env && atoi(tile_env) == 0;
+  if (io_bf16 != 0 && io_bf16 != 1 && io_bf16 != 2) return FS2HIP_EINVAL;
+  if (io_bf16 == 2 && (glu || stats)) return FS2HIP_EINVAL;
   if (glu && !tiles_off && (C % 64) == 0 && (ldx % 8) == 0 && ((uintptr_t)x % 16) == 0) {
 #define DW_FWD_T(KK)                                                                                              \
   if (io_bf16 && stats) dwconv_glu_fwd_tile_kernel<KK, true, true><<<grid, dim3(256), 0, s>>>(x, ldx, w, bias, y, partial, B, T, C);        \

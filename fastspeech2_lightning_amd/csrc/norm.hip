@@ -87,11 +87,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // PRED: the backward of such a predictor layer in one pass -- dy is first multiplied by the layer's dropout mask
 // (`drop_in`), and dx by relu'(pre-activation) = (x > 0), x being the ReLU's output that the LayerNorm normalised
 // (what were an axpby launch in front of this kernel and a dact_mul launch behind it)
-template <int NCH, bool DZ, bool DYB = false, bool ZB = false, bool PRED = false>
+// XOB (with PRED): dx is written as bf16 -- the operand of the predictor layer's bf16-storage weight- and data-gradient GEMMs
+template <int NCH, bool DZ, bool DYB = false, bool ZB = false, bool PRED = false, bool XOB = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, const float* __restrict__ x,
                                                       const float* __restrict__ gamma, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, const float* __restrict__ dx_add,
-                                                      float* __restrict__ dx, float* __restrict__ partial, int M, int C,
+                                                      void* __restrict__ dx, float* __restrict__ partial, int M, int C,
                                                       void* __restrict__ dz, float dz_scale, Fs2Drop drop_in) {
   constexpr int NP = DZ ? 3 : 2;
   __shared__ float red[4][NP][LN_MAX_CH * 256];
@@ -160,7 +161,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
           if (!(pos[j] & 4u)) o.z = 0.f;
           if (!(pos[j] & 8u)) o.w = 0.f;
         }
-        reinterpret_cast<float4*>(dx + (long long)row * C)[i] = o;
+        if constexpr (XOB) reinterpret_cast<uint2*>((unsigned short*)dx + (long long)row * C)[i] = ln_pack_bf16(o);
+        else reinterpret_cast<float4*>((float*)dx + (long long)row * C)[i] = o;
         if constexpr (DZ) {
           const unsigned long long e = ((unsigned long long)row * C) + 4ull * i;  // element index in the [M, C] tensor
           float4 z;
@@ -233,7 +235,7 @@ extern "C" int fs2hip_layernorm_fwd_drop(const float* x, const float* gamma, con
 }
 
 extern "C" int fs2hip_layernorm_bwd_pred(const float* dy, const float* x, const float* gamma, const float* mean,
-                                         const float* rstd, float* dx, float* partial, int M, int C, float drop_p,
+                                         const float* rstd, void* dx, int dx_bf16, float* partial, int M, int C, float drop_p,
                                          unsigned long long drop_seed, const unsigned long long* drop_step, void* stream) {
   if (M <= 0 || C <= 0 || (C % 4) || C > LN_MAX_CH * 256 || !partial || (long long)M * C >= 0x7fffffffLL) return FS2HIP_EINVAL;
   if (((uintptr_t)x % 16) || ((uintptr_t)dy % 16) || ((uintptr_t)dx % 16) || ((uintptr_t)gamma % 16)) return FS2HIP_EINVAL;
@@ -241,11 +243,21 @@ extern "C" int fs2hip_layernorm_bwd_pred(const float* dy, const float* x, const 
   hipStream_t s = (hipStream_t)stream;
   const Fs2Drop drop = fs2_make_drop(drop_p, drop_seed, drop_step);  // (p = 0: every factor is 1)
   const int nch = (C / 4 + 63) / 64;
-  switch (nch) {
-    case 1: ln_bwd_kernel<1, false, false, false, true><<<dim3(nblk), dim3(256), 0, s>>>(dy, x, gamma, mean, rstd, nullptr, dx, partial, M, C, nullptr, 0.f, drop); break;
-    case 2: ln_bwd_kernel<2, false, false, false, true><<<dim3(nblk), dim3(256), 0, s>>>(dy, x, gamma, mean, rstd, nullptr, dx, partial, M, C, nullptr, 0.f, drop); break;
-    default: ln_bwd_kernel<4, false, false, false, true><<<dim3(nblk), dim3(256), 0, s>>>(dy, x, gamma, mean, rstd, nullptr, dx, partial, M, C, nullptr, 0.f, drop); break;
+#define LN_PRED(N_, XOB_) ln_bwd_kernel<N_, false, false, false, true, XOB_><<<dim3(nblk), dim3(256), 0, s>>>(dy, x, gamma, mean, rstd, nullptr, dx, partial, M, C, nullptr, 0.f, drop)
+  if (dx_bf16) {
+    switch (nch) {
+      case 1: LN_PRED(1, true); break;
+      case 2: LN_PRED(2, true); break;
+      default: LN_PRED(4, true); break;
+    }
+  } else {
+    switch (nch) {
+      case 1: LN_PRED(1, false); break;
+      case 2: LN_PRED(2, false); break;
+      default: LN_PRED(4, false); break;
+    }
   }
+#undef LN_PRED
   FS2_LAUNCH_CHECK();
   return 0;  // partial is [nblk][2][C]: dgamma | dbeta partial sums, finished by fs2hip_reduce_rows_multi
 }

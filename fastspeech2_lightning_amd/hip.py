@@ -64,7 +64,7 @@ SIGNATURES = {
     "fs2hip_layernorm_bwd_dz": "ppppppppffQppiip",
     "fs2hip_layernorm_fwd_b": "ppppppiifp",
     "fs2hip_layernorm_fwd_drop": "ppppppiiffQpp",
-    "fs2hip_layernorm_bwd_pred": "pppppppiifQpp",
+    "fs2hip_layernorm_bwd_pred": "ppppppipiifQpp",
     "fs2hip_layernorm_bwd_x": "ppppppppffQppiiip",
     "fs2hip_dwconv_bwd_b": "ppippipppiiiiip",
     "fs2hip_attention_fwd": "ppppiiiifQpip",
@@ -742,7 +742,7 @@ def pick_splitk(Mc: int, Nc: int, R: int, taps: int = 1) -> int:
     return s
 
 
-def linear_bwd_weight(dy, x, out, *, taps=1, T=0, n_valid=None, bias_grad=None):
+def _linear_bwd_weight(dy, x, out, *, taps=1, T=0, n_valid=None, bias_grad=None):
     """dw[N, K] = dy[M, N]^T @ x[M, K]  (or dw[taps, N, Kper] for the k-tap conv).
     Written into ``out`` (a view of the flat gradient buffer).  ``n_valid``: only the first
     n_valid columns of dy produce output rows (dy's row length may be padded to a multiple of 4).
@@ -791,6 +791,54 @@ def linear_bwd_weight(dy, x, out, *, taps=1, T=0, n_valid=None, bias_grad=None):
     else:
         _gemm(_algorithmic=n_valid is None, **kw)
     return out
+
+
+#: weight-gradient GEMMs held back for a later window of the backward pass (``hold_weight_gradients``): a list while on
+_HELD_WGRADS = None
+
+
+def linear_bwd_weight(dy, x, out, *, taps=1, T=0, n_valid=None, bias_grad=None):
+    """dW = dy^T x (see ``_linear_bwd_weight``).  While ``hold_weight_gradients(True)`` is in force the launch is only
+    noted -- with its operands, which stay alive -- and enqueued by ``release_weight_gradients``."""
+    if _HELD_WGRADS is not None:
+        _HELD_WGRADS.append((dy, x, out, dict(taps=taps, T=T, n_valid=n_valid, bias_grad=bias_grad)))
+        return out
+    return _linear_bwd_weight(dy, x, out, taps=taps, T=T, n_valid=n_valid, bias_grad=bias_grad)
+
+
+def hold_weight_gradients(on: bool):
+    """A weight gradient depends only on tensors that exist once its layer's data gradient has run, and nothing reads it
+    before the optimizer: WHEN it runs is free.  Holding the decoder's and PostNet's weight-gradient GEMMs back until
+    the encoder's backward pass puts their large, matrix-pipe-bound workgroups beside the encoder's small kernels (which
+    leave most of the chip idle) instead of beside the decoder's own large GEMMs (where two matrix-bound kernels only
+    slow each other down).  Returns what was still held (a caller that switches holding off must release first)."""
+    global _HELD_WGRADS
+    left = _HELD_WGRADS or []
+    _HELD_WGRADS = [] if on else None
+    return left
+
+
+def held_weight_gradients() -> int:
+    return len(_HELD_WGRADS) if _HELD_WGRADS is not None else 0
+
+
+def release_weight_gradients(n=None):
+    """Enqueues the oldest ``n`` held weight-gradient GEMMs (all of them when None) on the current stream; holding stays on
+    for later calls.  Returns the operand tensors (a caller on a side stream keeps them until the join)."""
+    global _HELD_WGRADS
+    if not _HELD_WGRADS:
+        return []
+    jobs = _HELD_WGRADS[:n] if n is not None else list(_HELD_WGRADS)
+    del _HELD_WGRADS[:len(jobs)]
+    held, _HELD_WGRADS = _HELD_WGRADS, None   # (the launches below must run, not be noted again)
+    used = []
+    try:
+        for dy, x, out, kw in jobs:
+            _linear_bwd_weight(dy, x, out, **kw)
+            used += [dy, x]
+    finally:
+        _HELD_WGRADS = held
+    return used
 
 
 def colsum(x, out):
@@ -931,18 +979,21 @@ def layernorm_fwd_drop(x, gamma, beta, drop: Drop, eps=1e-5):
     return y, mean, rstd
 
 
-def layernorm_bwd_pred(dy, x, gamma, mean, rstd, dgamma, dbeta, drop: Drop):
+def layernorm_bwd_pred(dy, x, gamma, mean, rstd, dgamma, dbeta, drop: Drop, out_dtype=torch.float32):
     """relu'(x) * LayerNormBackward(dropmask * dy): the backward of a predictor layer's Dropout, LayerNorm and ReLU in one
-    launch (x = the ReLU output).  dgamma / dbeta arrive at the next ``flush_grad_reductions()``."""
+    launch (x = the ReLU output).  dgamma / dbeta arrive at the next ``flush_grad_reductions()``.  ``out_dtype`` bf16: the
+    result is the bf16 operand of the layer's weight- and data-gradient GEMMs (bf16 operand storage)."""
     for n, t in (("dy", dy), ("x", x), ("gamma", gamma), ("mean", mean), ("rstd", rstd), ("dgamma", dgamma), ("dbeta", dbeta)):
         _chk(t, name=n)
     M, Cc = _rows(x), x.shape[-1]
     _req(dy.shape == x.shape and mean.numel() == M and rstd.numel() == M and dgamma.numel() == Cc and dbeta.numel() == Cc,
          "layernorm_bwd_pred: shape mismatch")
-    dx = torch.empty_like(x)
+    _req(out_dtype in (torch.float32, torch.bfloat16), "layernorm_bwd_pred: result is fp32 or bf16")
+    dx = torch.empty(x.shape, device=x.device, dtype=out_dtype)
     nblk = lib().fs2hip_layernorm_bwd_blocks(M)
     part = torch.empty(nblk * 2 * Cc, device=x.device, dtype=torch.float32)
-    _ok(lib().fs2hip_layernorm_bwd_pred(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(part), M, Cc, drop.p,
+    _ok(lib().fs2hip_layernorm_bwd_pred(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx),
+                                        int(out_dtype == torch.bfloat16), _p(part), M, Cc, drop.p,
                                         drop.seed, drop.step_ptr, _stream()), "layernorm_bwd_pred")
     _defer_reduction(part, nblk, 2 * Cc, 2 * Cc, dgamma, Cc, dbeta)
     return dx
@@ -1137,23 +1188,26 @@ class StatParts:
         self.partial, self.nparts, self.part_rows, self.group_rows, self.count = partial, nparts, part_rows, group_rows, count
 
 
-def dwconv_fwd(x, w, bias, B, T, *, glu=False, stats=False):
+def dwconv_fwd(x, w, bias, B, T, *, glu=False, stats=False, out_dtype=None):
     """x [B*T, C or 2C] -> y [B, T, C]; w [K, C].  Returns (y, StatParts or None).  A bf16 ``x`` (GLU form; bf16
-    activation storage) gives a bf16 ``y`` whose statistics are those of the rounded values."""
+    activation storage) gives a bf16 ``y`` whose statistics are those of the rounded values.  ``out_dtype`` bf16 with an
+    fp32 ``x`` (plain form, no statistics): the result is written as bf16 only -- a bf16-storage GEMM's operand."""
     xb = x.dtype == torch.bfloat16
     _chk(x, x.dtype if xb else torch.float32, "x"); _chk(w, name="w")
     _req(glu or not xb, "dwconv_fwd: bf16 tensors are taken in the GLU form only")
+    yb_only = out_dtype == torch.bfloat16 and not xb
+    _req(not yb_only or not (glu or stats), "dwconv_fwd: fp32 -> bf16 is the plain form without statistics")
     K, Cc = w.shape
     ldx = x.shape[-1]
     _req(_rows(x) == B * T and ldx == (2 * Cc if glu else Cc), "dwconv_fwd: shape mismatch")
     if bias is not None:
         _chk(bias, name="bias")
         _req(bias.numel() == Cc, "dwconv_fwd: bias size")
-    y = torch.empty(B, T, Cc, device=x.device, dtype=x.dtype)
+    y = torch.empty(B, T, Cc, device=x.device, dtype=torch.bfloat16 if yb_only else x.dtype)
     nparts = lib().fs2hip_dwconv_blocks(B, T)
     partial = torch.empty(nparts, 2, Cc, device=x.device, dtype=torch.float32) if stats else None
     _ok(lib().fs2hip_dwconv_fwd_b(_p(x), ldx, _p(w), _p(bias), _p(y), _p(partial), B, T, Cc, K, int(glu), int(stats),
-                                  int(xb), _stream()), "dwconv_fwd")
+                                  2 if yb_only else int(xb), _stream()), "dwconv_fwd")
     return y, (StatParts(partial, nparts, lib().fs2hip_dwconv_part_rows(), T, B * T) if stats else None)
 
 

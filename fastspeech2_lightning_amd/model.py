@@ -39,6 +39,10 @@ LOSS_KEYS = ("pitch", "energy", "duration", "spec", "postnet", "attn_ctc", "attn
 #: per step), so that those GEMMs run in the forward orientation on the streaming kernel.  FS2_FP32_TRANSPOSED=0: off.
 import os as _os
 FP32_TRANSPOSED = _os.environ.get("FS2_FP32_TRANSPOSED", "1") != "0"
+#: FS2_HOLD_WGRADS=1: the PostNet's, mel head's and decoder's weight-gradient GEMMs are held back and released, a few per
+#: encoder sub-module, during the encoder's backward pass (single GPU only: under data parallelism a bucket's weight
+#: gradients must be enqueued before its hand-off).  See ``hip.hold_weight_gradients``.
+HOLD_WGRADS = _os.environ.get("FS2_HOLD_WGRADS", "0") != "0"
 
 
 #: FS2_PRED_LANES=1 (measurement aid, off by default): the three variance predictors -- independent chains of ~25 small
@@ -631,6 +635,7 @@ class FastSpeech2(_Base):
                 raise
             finally:
                 H.defer_slab_reductions(prev)
+                H.hold_weight_gradients(False)
 
     def _backward(self):
         if self._ctx is None or self._loss_grads is None:
@@ -640,6 +645,9 @@ class FastSpeech2(_Base):
         sync = self.grad_sync
         with self._prec("adaptor"):
             self.variance_adaptor.bwd_predictors_early(g, c["va"])
+        hold = HOLD_WGRADS and not sync
+        if hold:
+            H.hold_weight_gradients(True)
         d_out = g["spec"]
         if m.use_postnet:
             d_post = g["postnet"]
@@ -664,8 +672,27 @@ class FastSpeech2(_Base):
         if m.multilingual:
             self._rowvec_embedding_bwd("language_embedding.weight", c["batch"]["language_id"], d)
         self._bucket_done(self._bucket_va)                                # variance adaptor, GST, speaker / language
+        if hold:
+            # from here on weight gradients run as they come (the encoder's own), and the held ones are released in
+            # equal shares behind each of the encoder's layers
+            n_held = H.held_weight_gradients()
+            share = -(-n_held // max(len(self.encoder.layers), 1))
+            pending = list(H.hold_weight_gradients(False))
+
+            def release_share(_bucket=None):
+                if not pending:
+                    return
+                jobs = pending[:share]
+                del pending[:share]
+                with self.env.side(*[t for j in jobs for t in j[:2]]):
+                    for dy_, x_, out_, kw_ in jobs:
+                        H._linear_bwd_weight(dy_, x_, out_, **kw_)
+            release_share()
         with self._prec("encoder"):
-            d = self.encoder.bwd(d, c["enc"], layer_done=self._bucket_done)
+            d = self.encoder.bwd(d, c["enc"], layer_done=(release_share if hold else self._bucket_done))
+        if hold:
+            while pending:
+                release_share()
         if d_text is not None:  # the aligner's keys are the raw text embedding (fs2/variance_adaptor.py:254)
             d = H.axpby(d, d_text)
         if self.use_pfs:
@@ -767,7 +794,7 @@ class FastSpeech2(_Base):
         weights = (t.pitch_loss_weight, t.energy_loss_weight, t.duration_loss_weight, t.mel_loss_weight,
                    t.postnet_loss_weight, t.attn_ctc_loss_weight, t.attn_bin_loss_weight)
         return (tuple(geo), self.precision, bool(self.env.side_enabled), tuple(PRED_LANES.values()), id(sync) if sync else 0, bin_w, weights,
-                getattr(self.postnet, "dropout_p", None), M.BF16_CHAIN, FP32_TRANSPOSED, self.env.seed, H.plan_flags())
+                getattr(self.postnet, "dropout_p", None), M.BF16_CHAIN, M.PRED_STORED, FP32_TRANSPOSED, HOLD_WGRADS, self.env.seed, H.plan_flags())
 
     def _planned_step(self, batch):
         sig = self._plan_signature(batch)

@@ -263,6 +263,9 @@ class FeedForward:
 #: FS2_BF16_CHAIN=0 (measurement aid): under bf16 operand storage the convolution module's value|gate / depthwise result
 #: and the PostNet's inner convolution results stay fp32 tensors (the state before they became bf16)
 BF16_CHAIN = os.environ.get("FS2_BF16_CHAIN", "1") != "0"
+#: FS2_PRED_STORED=0 (measurement aid): the variance predictors' pointwise GEMMs round fp32 operands in registers as in
+#: rounds 1-4 instead of reading bf16 operands from memory
+PRED_STORED = os.environ.get("FS2_PRED_STORED", "1") != "0"
 
 
 class SelfAttention:
@@ -526,12 +529,21 @@ class VariancePredictor:
         S.add(self.wl, (1, self.c), "id", P.init_linear_weight)
         S.add(self.bl, (1,), "id", P.init_bias_for(self.c))
 
+    def _stored(self, L) -> bool:
+        """bf16 operand storage for this layer's pointwise GEMM (round 5): the depthwise convolution writes its result as
+        the bf16 operand, the fused LayerNorm backward the bf16 gradient -- the values the register-rounding GEMMs of
+        rounds 1-4 multiplied, without the fp32 tiles."""
+        return self.env.stored and self.depthwise and PRED_STORED and self.c % 8 == 0 and L["cin"] % 8 == 0
+
     def fwd(self, x, lens):
         S, env = self.S, self.env
         B, T, _ = x.shape
         saved = []
         for L in self.layers:
-            if self.depthwise:
+            if self._stored(L):
+                c, _ = H.dwconv_fwd(x, S.p(L["wd"]), S.p(L["bd"]), B, T, out_dtype=torch.bfloat16)
+                r = H.linear_fwd(c, S.pb(L["wp"]), S.p(L["bp"]), epi=H.EPI_ACT, act="relu")
+            elif self.depthwise:
                 c, _ = H.dwconv_fwd(x, S.p(L["wd"]), S.p(L["bd"]), B, T)
                 r = H.linear_fwd(c, S.p(L["wp"]), S.p(L["bp"]), epi=H.EPI_ACT, act="relu")
             else:
@@ -552,6 +564,13 @@ class VariancePredictor:
         d = H.rowdot_bwd(dpred, xl, S.p(self.wl), lens, S.g(self.wl), S.g(self.bl), B, T)
         for L, (x, c, r, ln_saved) in zip(reversed(self.layers), reversed(saved)):
             ln = L["ln"]
+            if c is not None and c.dtype == torch.bfloat16:  # bf16 operand storage (``_stored``)
+                d = H.layernorm_bwd_pred(d, r, S.p(ln.w), ln_saved[1], ln_saved[2], S.g(ln.w), S.g(ln.b),
+                                         env.drop(self.p, L["site"]), out_dtype=torch.bfloat16)
+                H.linear_bwd_weight(d, c, S.g(L["wp"]), bias_grad=S.g(L["bp"]))
+                dc = H.linear_bwd_data(d, S.pb(L["wp"]))
+                d = H.dwconv_bwd(dc, x, S.p(L["wd"]), S.g(L["wd"]), S.g(L["bd"]), B, T)
+                continue
             d = H.layernorm_bwd_pred(d, r, S.p(ln.w), ln_saved[1], ln_saved[2], S.g(ln.w), S.g(ln.b),
                                      env.drop(self.p, L["site"]))
             if self.depthwise:

@@ -190,8 +190,9 @@ int fs2hip_layernorm_bwd_dz(const float* dy, const float* x, const float* gamma,
 int fs2hip_layernorm_fwd_drop(const float* x, const float* gamma, const float* beta, float* y, float* mean,
                               float* rstd, int M, int C, float eps, float drop_p, unsigned long long drop_seed,
                               const unsigned long long* drop_step, void* stream);
+/* dx_bf16 != 0: dx is written as bf16 (bf16 operand storage: the layer's weight- and data-gradient GEMMs read it) */
 int fs2hip_layernorm_bwd_pred(const float* dy, const float* x, const float* gamma, const float* mean,
-                              const float* rstd, float* dx, float* partial, int M, int C, float drop_p,
+                              const float* rstd, void* dx, int dx_bf16, float* partial, int M, int C, float drop_p,
                               unsigned long long drop_seed, const unsigned long long* drop_step, void* stream);
 /* bf16 on either side of a LayerNorm ("bf16-mixed" with bf16 activation storage: the normalised activations and the
  * gradients between GEMMs exist only as the bf16 operands those GEMMs read).
@@ -294,7 +295,9 @@ int fs2hip_dwconv_bwd(const float* dy, const float* x, int ldx, const float* w, 
                       float* dw, float* dbias, int B, int T, int C, int K, int glu, void* stream);
 /* bf16 tensors (precision "bf16-mixed" with bf16 activation storage; what torch.autocast hands the convolution
  * module of torchaudio's ConformerLayer, call sites fs2/model.py:193, :241), GLU form only:
- *   fwd_b, io_bf16 != 0: x and y are bf16 (the BatchNorm statistics are those of the rounded y);
+ *   fwd_b, io_bf16 = 1: x and y are bf16 (the BatchNorm statistics are those of the rounded y);
+ *          io_bf16 = 2: x fp32, y bf16, plain (non-GLU) form without statistics -- the variance predictors' depthwise
+ *          layer (fs2/blocks.py:4-19) feeding its pointwise GEMM's bf16 operand;
  *   bwd_b, dx_bf16 bit 0: dx is written as bf16 (layout and leading dimension of x); bit 1: dy and x are bf16. */
 int fs2hip_dwconv_fwd_b(const void* x, int ldx, const float* w, const float* bias, void* y, float* partial,
                         int B, int T, int C, int K, int glu, int stats, int io_bf16, void* stream);

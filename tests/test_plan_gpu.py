@@ -165,3 +165,20 @@ def test_plans_follow_the_switches_in_their_signature(monkeypatch):
         planned.training_step(bs[0])
     assert planned.plans.replayed == 2
     torch.cuda.synchronize()
+
+
+def test_held_weight_gradients_change_nothing_but_the_schedule(monkeypatch):
+    """``FS2_HOLD_WGRADS=1`` moves the PostNet's / decoder's weight-gradient GEMMs into the encoder's backward window
+    (``hip.hold_weight_gradients``): the same launches with the same operands at another time -- every gradient, loss and
+    weight must come out bit for bit as without it, eagerly and from a recorded plan."""
+    from fastspeech2_lightning_amd import model as MM
+    ref, opt_r, config = build(plan=False)
+    bs = batches(config, 5)
+    want = run(ref, opt_r, bs)
+    monkeypatch.setattr(MM, "HOLD_WGRADS", True)
+    held, opt_h, _ = build(plan=True)
+    got = run(held, opt_h, bs)
+    assert held.plans.replayed == 3 and H._HELD_WGRADS is None
+    for i, (w, g) in enumerate(zip(want, got)):
+        assert torch.equal(w, g), i
+    assert_same_state(ref, held)
