@@ -88,7 +88,8 @@ def cpu_baseline(config, batch, sample_B=32, iters=3):
         else:
             sub[k] = v
     sub["max_src_len"], sub["max_mel_len"] = Ts, Tm
-    model = O.FastSpeech2Oracle(config, Stats(**DEFAULT_STATS), n_symbols=64)
+    n_spk = 16 if config.model.multispeaker else 0  # (the --gst configuration: 16 speakers, Rig.__init__)
+    model = O.FastSpeech2Oracle(config, Stats(**DEFAULT_STATS), n_symbols=64, n_speakers=n_spk)
     model.train()
     o = config.training.optimizer
     opt = torch.optim.AdamW(model.parameters(), o.learning_rate, betas=tuple(o.betas), eps=o.eps,

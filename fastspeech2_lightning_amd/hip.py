@@ -737,6 +737,12 @@ def pick_splitk(Mc: int, Nc: int, R: int, taps: int = 1) -> int:
         # of a chunk (same dY rows, X rows shifted by one) then share that XCD's L2 instead of every (tap, split) slice
         # fetching its own copy (PostNet 512x512x5: 481 -> 286 MB fetched, 118 -> 130 TFLOP/s)
         s = max(s, int(os.environ.get("FS2_CONV_DW_SPLITK", 8)))
+    if taps == 1 and Mc * Nc <= 64 * 64 and R >= (1 << 17):
+        # a tiny output over a very long reduction -- the GST reference encoder's first convolution (fs2/gst/model.py:
+        # 103-139): 9 x 32 weights over B x H x W = 1.65 M rows -- is ONE tile: 16 slices are 16 workgroups on 256 CUs, each
+        # walking 100 k rows (2.2 ms, the single longest launch of the configs[4] step).  Its slabs are a few KB, so the
+        # 16-slice rule above (slab traffic) does not apply: the slice count follows the reduction, ~4096 rows a slice.
+        s = max(s, min(512, R // 4096))
     while s > 1 and R // s < 256:
         s //= 2
     return s

@@ -6,7 +6,7 @@
 TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out
-FS2_BENCH_GEMM_BREAKDOWN=1 python3 bench.py "$@" > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err || exit 1
+FS2_BENCH_GEMM_BREAKDOWN=1 python3 bench.py "$@" > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err || { tail -5 $O/${TAG}_bench.err; exit 1; }
 # per-shape GEMM table of the roofline pass (HIP-event intervals, one stream): the first table is the headline configuration's,
 # a second one (default command only) the bf16_mixed_b64 leg's
 grep -E "gemm Mc|roofline pass|ms/step" $O/${TAG}_bench.err | sed -E 's/^\[bench[^]]*\] //' > $O/${TAG}_gemm_shapes.txt
