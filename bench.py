@@ -377,11 +377,32 @@ def committed_traffic(sig):
     return None, reason
 
 
+def committed_gemm_trace(sig):
+    """GEMM-family kernel time per step from the committed one-stream kernel trace of this configuration
+    (profiles/*_gemm_trace.json, tools/gemm_trace_sum.py), while it was measured on the tree's kernel sources."""
+    want, tree = (sig if isinstance(sig, dict) else config_signature(sig)), kernel_source_hash()
+    for tfile in sorted((REPO / "profiles").glob("r*_gemm_trace.json"), reverse=True):
+        t = json.loads(tfile.read_text())
+        if t.get("config") == want and t.get("kernel_source_hash") == tree:
+            return t, f"profiles/{tfile.name}"
+    return None, None
+
+
 def roofline_of(sig, precision, prof, ov):
     """``sig``: the configuration (argparse namespace or config_signature dict) whose committed counter profile supplies
     ``traffic``; None: no such profile exists for this leg."""
     g = gemm_numbers(prof, ov)
     tf, gbs = g.pop("_tflops"), g.pop("_gbs")
+    # which clock: the committed kernel trace of this configuration on these kernel sources when there is one (the
+    # profiler's own kernel durations), else the live HIP-event intervals minus the event pair's measured device cost
+    trace, trace_file = committed_gemm_trace(sig) if sig is not None else (None, None)
+    g["time_source"] = "hip events around every GEMM launch, event-pair overhead subtracted"
+    g["achieved_from_events_tflops"] = round(tf, 2)
+    if trace is not None:
+        scale = g["gemm_ms_per_step"] / trace["gemm_ms_per_step"]
+        tf, gbs = tf * scale, gbs * scale
+        g["time_source"] = f"{trace_file} (rocprofv3 --kernel-trace, one stream: {trace['gemm_ms_per_step']:.3f} ms of GEMM kernels per step)"
+        g["gemm_ms_per_step_trace"] = round(trace["gemm_ms_per_step"], 3)
     if precision == "bf16-mixed":
         # both fractions (SURVEY.md 8d): operand + result bytes against HBM, flops against the dense bf16 MFMA peak.
         # The ridge is ~310 flop/B; the family's intensity decides which one bounds it.

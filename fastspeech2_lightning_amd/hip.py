@@ -437,15 +437,31 @@ def _tile_key(a):
             tq, flags, _current_device())
 
 
+#: layout version of a tile signature (``_tile_key``): 2 = the convolution length enters as (q(T), T >= 32, T >= 64)
+TILE_KEY_FORMAT = 2
+
+
 def tile_table() -> dict:
-    """The tuned tiles as {repr(signature): tile} (JSON-serialisable): persist it with ``save_tile_cache`` or
-    broadcast it so that every rank of a data-parallel job sums in the same order."""
-    return {repr(k): int(v) for k, v in _TILE_CACHE.items()}
+    """The tuned tiles as {repr(signature): tile} (JSON-serialisable) plus ``"__format__"``: persist it with
+    ``save_tile_cache`` or broadcast it so that every rank of a data-parallel job sums in the same order."""
+    t = {repr(k): int(v) for k, v in _TILE_CACHE.items()}
+    t["__format__"] = TILE_KEY_FORMAT
+    return t
 
 
 def load_tile_table(table: dict) -> None:
+    """Takes a table of ``tile_table()``.  A table written with another signature layout would load and never match a
+    launch -- silently, every GEMM then running untuned: it is refused with a warning instead."""
     import ast
+    import warnings
+    fmt = table.get("__format__")
+    if fmt != TILE_KEY_FORMAT:
+        warnings.warn(f"fs2hip: tile table in signature format {fmt!r}, this build uses {TILE_KEY_FORMAT}: ignored "
+                      "(re-tune, or delete the file FS2_GEMM_TILE_CACHE names)")
+        return
     for k, v in table.items():
+        if k == "__format__":
+            continue
         _TILE_CACHE[ast.literal_eval(k) if isinstance(k, str) else tuple(k)] = int(v)
     TILE_GEN[0] += 1
 
@@ -522,12 +538,26 @@ def _tune_tile(a) -> int:
     return best
 
 
+#: (tile, exact geometry) pairs the library has refused: a cached tile is right for its bucket of quantised shapes, and an
+#: exact shape of the bucket that it does not admit must not pay a failing call on every launch
+_TILE_REFUSED = set()
+
+
+def _refusal_key(a):
+    return (a.tile, a.Mc, a.Nc, a.R, a.T, a.taps, a.lda, a.ldb, a.ldc, a.epi, a.io_bf16, a.operand_bf16, a.splitk,
+            bool(a.colsum), (a.C or 0) % 16)
+
+
 def _launch_gemm(a):
+    if a.tile != 0 and _TILE_REFUSED and _refusal_key(a) in _TILE_REFUSED:
+        a.tile = 0
     rc = lib().fs2hip_gemm(C.byref(a), _stream())
     if rc == -22 and a.tile != 0:
         # a cached / replayed tile that this exact geometry does not admit (the key quantises long extents): the
-        # library chooses for THIS launch; the entry stays -- it is right for the other shapes of its bucket, and
-        # dropping it made two alternating shapes re-run the tuner every step (a refusal costs no launch)
+        # library chooses for THIS launch and for every later launch of this exact geometry (noted in _TILE_REFUSED); the
+        # cache entry stays -- it is right for the other shapes of its bucket, and dropping it made two alternating
+        # shapes re-run the tuner every step
+        _TILE_REFUSED.add(_refusal_key(a))
         a.tile = 0
         rc = lib().fs2hip_gemm(C.byref(a), _stream())
     _ok(rc, "gemm")
@@ -1104,8 +1134,20 @@ def reserve_scratch(name, floats):
     key = (name, _current_device(), _stream())
     t = _SCRATCH.get(key)
     if t is None or t.numel() < floats:
+        # (a buffer first allocated while a hipGraph is captured would live in the graph's pool and then be used outside
+        # it: size the scratch with one eager step before capturing -- ADVICE r4)
+        _req(not torch.cuda.is_current_stream_capturing(),
+             f"scratch buffer {name!r} must be sized by an eager step before a hipGraph capture")
         t = _SCRATCH[key] = torch.empty(int(floats), device="cuda", dtype=torch.float32)
     return t
+
+
+def release_scratch():
+    """Drops every grow-only scratch / workspace buffer of this process (the dS scratch of the attention backward is
+    B*H*T*T floats: 0.9 GB at the configs[4] shape).  They are re-made on demand; ``FastSpeech2.move_to`` calls this, a
+    caller that switches to much smaller batches may."""
+    _SCRATCH.clear()
+    _WS.clear()
 
 
 def attention_bwd(qkv, lens, o, dout, lse, B, T, H, drop: Drop = NO_DROP, scores=None):

@@ -526,7 +526,9 @@ class FastSpeech2(_Base):
     def _forward(self, batch, control=None, inference=False):
         H.set_precision(self.precision)
         if self.env.stored:
-            self.store.refresh_bf16()  # the weights as bf16, once per step: every GEMM orientation reads this mirror
+            # the weights as bf16, once per step: every GEMM orientation reads this mirror (the transposed ones only
+            # serve data gradients: a training forward)
+            self.store.refresh_bf16(transposed=self.training and not inference)
         elif H.GEMM_BF16 == 0 and self.training and not inference and FP32_TRANSPOSED:
             self.store.refresh_transposed_fp32()  # W^T of the K = 256 data-gradient weights (streaming fp32 kernel)
         control = control or InferenceControl()
@@ -996,13 +998,14 @@ class FastSpeech2(_Base):
             S.bn_counters = counters
             S.device = device
             S._pviews, S._gviews, S._bviews, S._tviews, S._tviews32, S.flat_bf16 = {}, {}, {}, {}, {}, None
+            S.weights_changed()
             self.step_state = self.step_state.to(device, copy=True)
             self.env.step_state = self.step_state
             if getattr(self.env, "_lanes", None):
                 self.env.join()
                 self.env._lanes, self.env._side_stream = None, None
             self.plans.clear()   # recorded launch plans hold the old device's addresses and streams
-            H._SCRATCH.clear()   # (scratch keyed by a destroyed side stream's handle would dangle)
+            H.release_scratch()  # (scratch keyed by a destroyed side stream's handle would dangle)
             self.bad_count = self.bad_count.to(device, copy=True)
             if self.variance_adaptor is not None:
                 self.variance_adaptor.bad_count = self.bad_count

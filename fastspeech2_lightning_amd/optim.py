@@ -71,6 +71,7 @@ class FusedAdamWNoam(torch.optim.Optimizer):
             H.grad_clip_coef(g, float(self.max_grad_norm or 0.0), self.grad_scale, self.step_state)
             H.adamw_step(S.flat, g, S.adam_m, S.adam_v, self.step_state, self.betas[0], self.betas[1], self.eps,
                          self.weight_decay)
+        S.weights_changed()  # (the transposed weight mirrors are stale until the next training forward refreshes them)
         self.steps_since_delivery += 1
         return loss
 

@@ -170,12 +170,23 @@ class ParamStore:
 
     # ---- bf16 mirror of the weights ("bf16-mixed" with operand storage): ONE cast pass over the flat buffer per step;
     # the GEMMs read weights from it in every orientation, so no per-layer casts and no transposed copies exist ----
-    def refresh_bf16(self):
+    #: bumped by everything that rewrites the weights (the optimizer step, ``load_state_dict``, ``move_to``): the transposed
+    #: mirrors carry the generation they were made from, and ``pt`` / ``pbt`` hand out None for a stale one -- the caller
+    #: (``hip.linear_bwd_data(wt=...)``) then reads the weight itself in the other orientation, which is always right
+    weights_gen = 0
+    _gen_t16 = _gen_t32 = -1
+
+    def weights_changed(self):
+        self.weights_gen += 1
+
+    def refresh_bf16(self, transposed: bool = True):
+        """``transposed=False`` (evaluation / inference forwards, which never run a data gradient): the cast alone."""
         from . import hip as H
         if self.flat_bf16 is None:
             self.flat_bf16 = torch.empty(self.total, device=self.flat.device, dtype=torch.bfloat16)
         H.cast_bf16(self.flat, out=self.flat_bf16)
-        if self._transposed:
+        if self._transposed and transposed:
+            self._gen_t16 = self.weights_gen
             # transposed bf16 mirrors (one launch for all of them): the weights whose data-gradient GEMM runs in the
             # forward orientation on the weights-stationary kernel (reduction = the model width)
             if not self._tviews:
@@ -198,10 +209,12 @@ class ParamStore:
                 self._tviews32[name] = torch.empty(k, n, device=self.flat.device, dtype=torch.float32)
         if self._tviews32:
             H.transpose_cast_bf16_multi([(self.p(name), v) for name, v in self._tviews32.items()])
+            self._gen_t32 = self.weights_gen
 
     def pt(self, name):
-        """The transposed fp32 mirror of ``name`` (None when it was not declared or not refreshed yet)."""
-        return self._tviews32.get(name)
+        """The transposed fp32 mirror of ``name`` (None when it was not declared, not refreshed yet, or made from
+        weights that have changed since)."""
+        return self._tviews32.get(name) if self._gen_t32 == self.weights_gen else None
 
     def want_transposed(self, name, bf16_only=False):
         """Declares that ``pbt(name)`` -- the weight [N, K] as bf16 [K, N] -- is wanted (kept by ``refresh_bf16``);
@@ -214,8 +227,9 @@ class ParamStore:
                 self._transposed_bf16_only.add(name)
 
     def pbt(self, name):
-        """The transposed bf16 mirror of ``name`` (None when it was not declared or not refreshed yet)."""
-        return self._tviews.get(name)
+        """The transposed bf16 mirror of ``name`` (None when it was not declared, not refreshed yet, or made from
+        weights that have changed since)."""
+        return self._tviews.get(name) if self._gen_t16 == self.weights_gen else None
 
     def pb(self, name):
         v = self._bviews.get(name)
@@ -290,6 +304,7 @@ class ParamStore:
         unexpected = [k for k in sd if k not in self.entries and k not in self.buffers]
         if strict and (missing or unexpected):
             raise RuntimeError(f"state dict mismatch: missing {missing[:8]} unexpected {unexpected[:8]}")
+        self.weights_changed()
         with torch.no_grad():
             for k, v in sd.items():
                 if k in self.entries:

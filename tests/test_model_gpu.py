@@ -413,3 +413,38 @@ def test_unsupported_head_dimension_is_refused_at_construction():
                                text=dict(symbols=dict(letters=[f"s{i}" for i in range(40)])))
     with pytest.raises(ValueError, match="head dimension"):
         FastSpeech2(config, Stats(**C.STATS))
+
+
+@pytest.mark.parametrize("precision", ["32-true", "bf16-mixed"])
+def test_transposed_weight_mirrors_carry_the_weights_generation(precision):
+    """``ParamStore.pt`` / ``pbt`` (W^T mirrors for the forward-orientation data gradients) must not outlive the
+    weights they were made from: after an optimizer step or ``load_state_dict`` they read as None -- ``linear_bwd_data``
+    then takes the weight itself -- until the next TRAINING forward refreshes them; evaluation forwards skip them."""
+    from fastspeech2_lightning_amd.model import FastSpeech2
+    from tests.test_dropout_gpu import default_width_config
+    config = default_width_config(0.0, 0.0, 1)
+    model = FastSpeech2(config, Stats(**C.STATS), seed=3, precision=precision)
+    S = model.store
+    name = model.decoder.layers[0].attn.wo
+    get = S.pt if precision == "32-true" else S.pbt
+    batch = O.synthetic_batch(B=2, ts_lo=8, ts_hi=12, n_symbols=41, n_mels=80, seed=4, dur_hi=4)
+    model.train()
+    opt = model.configure_optimizers()[0][0]
+    assert get(name) is None                                    # never refreshed
+    with torch.no_grad():
+        model.training_step(batch)
+    mirror = get(name)
+    assert mirror is not None and torch.equal(mirror.float(), S.p(name).t().to(mirror.dtype).float())
+    opt.step()
+    assert get(name) is None                                    # the weights moved: the mirror is stale
+    model.eval()
+    with torch.no_grad():
+        model(batch)                                            # an evaluation forward does not pay for the transposes
+    assert get(name) is None
+    model.train()
+    with torch.no_grad():
+        model.training_step(batch)
+    mirror = get(name)
+    assert mirror is not None and torch.equal(mirror.float(), S.p(name).t().to(mirror.dtype).float())
+    model.load_state_dict(model.state_dict())
+    assert get(name) is None

@@ -255,3 +255,27 @@ def test_gather_from_ranks_fails_in_seconds_when_a_rank_dies():
     assert sorted(gather_from_ranks(ok, q2, 2, timeout=120)) == [0, 1]
     for p in ok:
         p.join(30)
+
+
+def test_tile_table_of_another_signature_format_is_refused_with_a_warning():
+    """a tile table saved with an older signature layout would load and never match a launch."""
+    import warnings
+    from fastspeech2_lightning_amd import hip as H
+    saved = dict(H._TILE_CACHE)
+    try:
+        H._TILE_CACHE.clear()
+        H._TILE_CACHE[(20736, 1024, 256, 1, 1, 1, 0, 1, 1, 0, 0, 17, 0)] = 7
+        t = H.tile_table()
+        assert t["__format__"] == H.TILE_KEY_FORMAT
+        H._TILE_CACHE.clear()
+        H.load_tile_table(t)
+        assert len(H._TILE_CACHE) == 1
+        old = {k: v for k, v in t.items() if k != "__format__"}
+        H._TILE_CACHE.clear()
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            H.load_tile_table(old)
+        assert not H._TILE_CACHE and any("signature format" in str(x.message) for x in w)
+    finally:
+        H._TILE_CACHE.clear()
+        H._TILE_CACHE.update(saved)

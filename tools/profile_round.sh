@@ -16,6 +16,7 @@ rm -rf $O/${TAG}_kt
 FS2_SIDE_STREAM=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_kt -- python3 bench.py $COMMON "$@" > $O/${TAG}_kt.log 2>&1 || exit 1
 cp $O/${TAG}_kt/*/*_kernel_stats.csv $O/${TAG}_one_stream_kernel_stats.csv
 python3 tools/step_breakdown.py $O/${TAG}_kt/*/*_kernel_trace.csv 5 > $O/${TAG}_one_stream_step_breakdown.txt
+python3 tools/gemm_trace_sum.py $O/${TAG}_kt/*/*_kernel_trace.csv 5 "$@" > $O/${TAG}_gemm_trace.json
 head -12 $O/${TAG}_one_stream_step_breakdown.txt
 NGEMM=$(python3 -c "import json;print(json.load(open('$O/${TAG}_bench.json'))['roofline']['launches_per_step'])")
 PM="--steps 2 --warmup 2 --no-cpu-baseline --no-roofline --no-extra-legs"
