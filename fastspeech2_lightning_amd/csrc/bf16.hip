@@ -18,6 +18,36 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
   }
 }
 
+// out[(b, t)][tap * C + c] = bf16(x[(b, t + dir * (tap - (taps - 1) / 2))][c]), zero outside the utterance's [0, T): the
+// rows of a k-tap 'same' convolution over time laid side by side, so that a convolution whose channel count is not whole
+// 64-deep K-tiles per tap (the PostNet's 80 mel bins, fs2/layers.py:143-212) is ONE plain GEMM with K = taps * C on the
+// bf16-storage core instead of a per-piece-decoded launch on the fp32-operand tiles.  dir = +1: forward (pairs with the
+// weight as [taps * Cin][Cout]); dir = -1: the data gradient (pairs with the weight as stored, [taps * Cout][Cin] read
+// reduction-major).  Eight elements (one 16-byte store) per thread; C % 8 == 0 keeps a piece inside one tap.
+template <bool XB>
+__global__ __launch_bounds__(256) void im2col_taps_kernel(const void* __restrict__ x, __bf16* __restrict__ out, int T,
+                                                           int C, int taps, int dir, long long n8) {
+  const int c8 = C / 8, w8 = taps * c8, pad = (taps - 1) / 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / w8;
+    const int j = (int)(i - row * w8), tap = j / c8, c = (j - tap * c8) * 8;
+    const int t = (int)(row % T), ts = t + dir * (tap - pad);
+    bf16x8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (ts >= 0 && ts < T) {
+      const long long src = (row + (ts - t)) * C + c;
+      if (XB) {
+        v = *reinterpret_cast<const bf16x8_t*>((const __bf16*)x + src);
+      } else {
+        const f32x4 a = *reinterpret_cast<const f32x4*>((const float*)x + src);
+        const f32x4 b = *reinterpret_cast<const f32x4*>((const float*)x + src + 4);
+        const f32x8_t f = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        v = __builtin_convertvector(f, bf16x8_t);
+      }
+    }
+    reinterpret_cast<bf16x8_t*>(out)[i] = v;
+  }
+}
+
 // dst[c][r] = bf16(src[r][c]) for a [rows][cols] matrix: 64 x 64 tiles through LDS (padded against bank conflicts),
 // reads and writes both contiguous.  dst rows are ld_dst elements apart; the pad columns rows..ld_dst-1 are zeroed.
 __global__ __launch_bounds__(256) void transpose_cast_bf16_kernel(const float* __restrict__ src, int rows, int cols,
@@ -89,6 +119,20 @@ extern "C" int fs2hip_cast_bf16(const float* src, void* dst, long long n, void* 
   long long blocks = (n8 + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   cast_bf16_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(src, (__bf16*)dst, n8);
+  FS2_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fs2hip_im2col_taps(const void* x, int x_bf16, void* out_bf16, int B, int T, int C, int taps, int dir,
+                                  void* stream) {
+  if (B <= 0 || T <= 0 || C <= 0 || (C % 8) || taps < 1 || !(taps & 1) || (dir != 1 && dir != -1)) return FS2HIP_EINVAL;
+  if (((uintptr_t)x % 16) || ((uintptr_t)out_bf16 % 16)) return FS2HIP_EINVAL;
+  const long long n8 = (long long)B * T * taps * (C / 8);
+  long long blocks = (n8 + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipStream_t s = (hipStream_t)stream;
+  if (x_bf16) im2col_taps_kernel<true><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(x, (__bf16*)out_bf16, T, C, taps, dir, n8);
+  else im2col_taps_kernel<false><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(x, (__bf16*)out_bf16, T, C, taps, dir, n8);
   FS2_LAUNCH_CHECK();
   return 0;
 }

@@ -17,6 +17,17 @@
 // the top of interval i and has long landed when it is needed, so the epilogue is the tiled kernels' own
 // (gemm_epilogue_impl: same arithmetic, same dropout element index, compiler-managed loads) and the only hand-counted
 // wait is the one that lets the previous tile's stores stay in flight across the barrier.
+//
+// Round 5: the two wavefronts of a SIMD run HALF AN INTERVAL APART.  Rounds 4's kernel ran all eight in lockstep: MFMAs,
+// then epilogue, then the barrier -- so both wavefronts of a SIMD left the matrix pipe idle together for the length of
+// an epilogue (address arithmetic, 16-32 stores, their issue stalls): 103.6 us where the MFMA count says 76
+// (profiles/r05_clock_probe.txt: the clock is NOT the difference).  One wavefront's single dependent accumulation chain
+// fills the fp32 matrix pipe by itself (tools/probes/chain_probe.hip: 0.988 of peak with one chain, one wavefront per
+// SIMD), so nothing is lost while a SIMD's other wavefront is elsewhere: wavefronts 0-3 run tile i's MFMAs and then its
+// epilogue as before; wavefronts 4-7 carry tile i - 1's accumulator across the barrier, run ITS epilogue first -- beside
+// the MFMAs of their SIMD's early wavefront -- and then tile i's MFMAs, beside the early wavefront's epilogue.  Same
+// barrier per tile, same stage discipline (at barrier i every wavefront has finished READING tile i - 1), same
+// arithmetic in the same order: still bit-identical to the tiled kernels.
 #include "gemm2_core.h"
 
 namespace {
@@ -73,12 +84,16 @@ __global__ __launch_bounds__(W32_THREADS) void gemmws32_kernel(GemmP p, int n_sl
   f32x16 acc[1][1];
   constexpr int STORES = TWO ? 32 : 16;
   float* C = a.C;
+  const bool late = wave >= 4;  // (wave-uniform) the SIMD's second wavefront: epilogues run one interval later
   dma(0);
   for (int i = 0; i < cnt; ++i) {
-    // tile i has landed for everybody (the stores of the previous epilogue, younger than its DMA, may stay in flight);
-    // everybody has left the MFMAs of tile i - 1, whose stage the next DMA overwrites
-    if (i == 0) wait_vmcnt_barrier<0>(); else wait_vmcnt_barrier<STORES>();
+    // tile i has landed for everybody (the stores of the previous epilogue, younger than its DMA, may stay in flight --
+    // a late wavefront has no epilogue behind DMA(1) yet); everybody has left the MFMAs of tile i - 1, whose stage the
+    // next DMA overwrites
+    if (i == 0 || (late && i == 1)) wait_vmcnt_barrier<0>(); else wait_vmcnt_barrier<STORES>();
     dma(i + 1);
+    if (late && i > 0)
+      gemm_epilogue_impl<64, 64, EPI>(p, acc, C, a.ldc, (stream + (i - 1) * n_streams) * 32, ns0, 0, wave, lane);
     const unsigned sb = (i & 1) * (W32_TILE_FLOATS * 4);
     f32x16 acc2;
 #pragma unroll
@@ -109,8 +124,10 @@ __global__ __launch_bounds__(W32_THREADS) void gemmws32_kernel(GemmP p, int n_sl
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[0][0][r] += acc2[r];
     }
-    gemm_epilogue_impl<64, 64, EPI>(p, acc, C, a.ldc, (stream + i * n_streams) * 32, ns0, 0, wave, lane);
+    if (!late) gemm_epilogue_impl<64, 64, EPI>(p, acc, C, a.ldc, (stream + i * n_streams) * 32, ns0, 0, wave, lane);
   }
+  if (late && cnt > 0)
+    gemm_epilogue_impl<64, 64, EPI>(p, acc, C, a.ldc, (stream + (cnt - 1) * n_streams) * 32, ns0, 0, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 

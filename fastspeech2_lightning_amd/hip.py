@@ -108,6 +108,7 @@ SIGNATURES = {
     "fs2hip_adamw_step": "ppppqpffffp",
     "fs2hip_axpby": "pppqfffQpp",
     "fs2hip_cast_bf16": "ppqp",
+    "fs2hip_im2col_taps": "pipiiiiip",
     "fs2hip_transpose_cast_bf16": "piiipiip",
     "fs2hip_transpose_cast_bf16_multi": None,  # (const Fs2TransposeJob*, int, void*): set below
     "fs2hip_add_rowvec": "pppiiip",
@@ -717,6 +718,37 @@ def cast_bf16(x, out=None):
     _chk(out, torch.bfloat16, "out")
     _req(out.numel() == x.numel(), "cast_bf16: output size")
     _ok(lib().fs2hip_cast_bf16(_p(x), _p(out), x.numel(), _stream()), "cast_bf16")
+    return out
+
+
+def im2col_taps(x, B, T, taps, direction=1):
+    """[B*T, C] (fp32 or bf16) -> bf16 [B*T, taps * C]: row (b, t) holds x[b, t + direction * (tap - (taps - 1) // 2)] for
+    every tap, zeros outside the utterance -- a k-tap 'same' convolution becomes one plain GEMM (``matmul_kn``)."""
+    xb = x.dtype == torch.bfloat16
+    _chk(x, x.dtype if xb else torch.float32, "x")
+    Cc = x.shape[-1]
+    _req(_rows(x) == B * T and Cc % 8 == 0 and taps % 2 == 1 and direction in (1, -1), "im2col_taps: shape mismatch")
+    out = torch.empty(B * T, taps * Cc, device=x.device, dtype=torch.bfloat16)
+    _ok(lib().fs2hip_im2col_taps(_p(x), int(xb), _p(out), B, T, Cc, taps, direction, _stream()), "im2col_taps")
+    return out
+
+
+def matmul_kn(a, b_kn, bias=None, out_dtype=torch.float32):
+    """out[M, N] = a[M, K] @ b_kn[K, N] (+ bias): bf16 operands, ``b_kn`` reduction-major as stored (the bf16 core's
+    transposing reads; K and N multiples of 8, a reduction tail that is not a whole K-tile reads zeros)."""
+    _chk(a, torch.bfloat16, "a"); _chk(b_kn, torch.bfloat16, "b_kn")
+    M, K = _rows(a), a.shape[-1]
+    _req(b_kn.dim() == 2 and b_kn.shape[0] == K and K % 8 == 0 and b_kn.shape[1] % 8 == 0, "matmul_kn: a is [M, K], b_kn [K, N]")
+    N = b_kn.shape[1]
+    out = torch.empty(*a.shape[:-1], N, device=a.device, dtype=out_dtype)
+    kw = dict(A=_p(a), B=_p(b_kn), C=_p(out), Mc=M, Nc=N, R=K, lda=K, ldb=N, ldc=N, a_kcontig=1, b_kcontig=0, taps=1, T=0,
+              tap_mul=1, tap_add=0, shift_operand=0, epi=EPI_STORE, operand_bf16=4,
+              io_bf16=1 if out_dtype == torch.bfloat16 else 0)
+    if bias is not None:
+        _chk(bias, name="bias")
+        _req(bias.numel() == N, "matmul_kn: bias size")
+        kw["bias"] = _p(bias)
+    _gemm(**kw)
     return out
 
 

@@ -796,7 +796,7 @@ class FastSpeech2(_Base):
         weights = (t.pitch_loss_weight, t.energy_loss_weight, t.duration_loss_weight, t.mel_loss_weight,
                    t.postnet_loss_weight, t.attn_ctc_loss_weight, t.attn_bin_loss_weight)
         return (tuple(geo), self.precision, bool(self.env.side_enabled), tuple(PRED_LANES.values()), id(sync) if sync else 0, bin_w, weights,
-                getattr(self.postnet, "dropout_p", None), M.BF16_CHAIN, M.PRED_STORED, FP32_TRANSPOSED, HOLD_WGRADS, self.env.seed, H.plan_flags())
+                getattr(self.postnet, "dropout_p", None), M.BF16_CHAIN, M.PRED_STORED, M.POSTNET_IM2COL, FP32_TRANSPOSED, HOLD_WGRADS, self.env.seed, H.plan_flags())
 
     def _planned_step(self, batch):
         sig = self._plan_signature(batch)

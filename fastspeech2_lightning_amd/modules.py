@@ -266,6 +266,9 @@ BF16_CHAIN = os.environ.get("FS2_BF16_CHAIN", "1") != "0"
 #: FS2_PRED_STORED=0 (measurement aid): the variance predictors' pointwise GEMMs round fp32 operands in registers as in
 #: rounds 1-4 instead of reading bf16 operands from memory
 PRED_STORED = os.environ.get("FS2_PRED_STORED", "1") != "0"
+#: FS2_POSTNET_IM2COL=0 (measurement aid): the PostNet's two 80-mel-bin convolutions (first layer forward, last layer data
+#: gradient) on the fp32-operand tiles with per-piece tap decoding, as in rounds 1-4
+POSTNET_IM2COL = os.environ.get("FS2_POSTNET_IM2COL", "1") != "0"
 
 
 class SelfAttention:
@@ -814,6 +817,16 @@ class PostNet:
                 # convolution's result meets the loss gradient in fp32 and stays fp32.
                 raw_dt = torch.bfloat16 if i + 1 < self.n and BF16_CHAIN else torch.float32
                 raw = H.linear_fwd(x.view(B * T, -1), S.pb(w), S.p(b), taps=self.k, T=T, out_dtype=raw_dt).view(B, T, -1)
+            elif stored and POSTNET_IM2COL and x.shape[-1] % 8 == 0 and x.shape[-1] % 64 != 0:
+                # round 5: the first layer's 80 mel bins are not whole K-tiles per tap, which kept this convolution on
+                # the fp32-operand tiles (105 us at 168 TFLOP/s in the bf16 step).  Its input rows laid side by side per
+                # tap (one 16-byte-per-thread gather, bf16) make it ONE plain K = 5 x 80 GEMM on the bf16-storage core
+                # against the weight transposed per tap: the same products, rounded as before (bf16 operands), summed
+                # over (tap, channel) in the same order.
+                raw_dt = torch.bfloat16 if i + 1 < self.n and BF16_CHAIN else torch.float32
+                xc = H.im2col_taps(x.view(B * T, -1), B, T, self.k)
+                wt = H.transpose_cast_bf16(S.p(w)).view(self.k * x.shape[-1], -1)   # [taps][Cout][Cin] -> [taps * Cin][Cout]
+                raw = H.matmul_kn(xc, wt, S.p(b), out_dtype=raw_dt).view(B, T, -1)
             else:
                 raw = H.linear_fwd(x, S.p(w), S.p(b), taps=self.k, T=T)
             stats = bn.stats(H.colstats(raw) if env.training else None, env.training)
@@ -847,7 +860,12 @@ class PostNet:
                     dy = H.linear_bwd_data(draw, S.p(w), taps=self.k, T=T)
                 continue
             dgrad_b = need and cout % 64 == 0 and x.shape[-1] % 8 == 0
-            if need and not dgrad_b:
+            # (round 5) the last layer's data gradient reduces over taps x 80 output channels: the same side-by-side rows,
+            # taken backwards in time, against the weight as it is stored
+            dgrad_im2col = need and not dgrad_b and POSTNET_IM2COL and cout % 8 == 0 and x.shape[-1] % 8 == 0
+            if dgrad_im2col:
+                draw, draw_b = None, H.bn_act_bwd(dy, raw, stats, gg, gb, act, drop, training=env.training, bf16_only=True)
+            elif need and not dgrad_b:
                 draw, draw_b = H.bn_act_bwd(dy, raw, stats, gg, gb, act, drop, training=env.training, bf16_copy=True)
             else:
                 draw, draw_b = None, H.bn_act_bwd(dy, raw, stats, gg, gb, act, drop, training=env.training, bf16_only=True)
@@ -859,6 +877,10 @@ class PostNet:
                 # layer's convolution result: both bf16 or both fp32)
                 dy_dt = torch.bfloat16 if i > 0 and saved[i - 1][1].dtype == torch.bfloat16 else torch.float32
                 dy = H.linear_bwd_data(draw_b.view(B * T, -1), S.pb(w), taps=self.k, T=T, out_dtype=dy_dt).view(B, T, -1)
+            elif dgrad_im2col:
+                dy_dt = torch.bfloat16 if i > 0 and saved[i - 1][1].dtype == torch.bfloat16 else torch.float32
+                dyc = H.im2col_taps(draw_b.view(B * T, -1), B, T, self.k, direction=-1)
+                dy = H.matmul_kn(dyc, S.pb(w).view(self.k * cout, -1), out_dtype=dy_dt).view(B, T, -1)
             elif need:
                 dy = H.linear_bwd_data(draw, S.p(w), taps=self.k, T=T)
         return dy

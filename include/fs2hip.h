@@ -409,6 +409,12 @@ int fs2hip_adamw_step(float* p, const float* g, float* m, float* v, long long n,
  * matrix with rows ld_src apart, dst rows ld_dst >= rows elements apart (pad columns zeroed), for `batch` matrices
  * stored back to back (the taps of a convolution weight). */
 int fs2hip_cast_bf16(const float* src, void* dst, long long n, void* stream);
+/* out[(b, t)][tap * C + c] = bf16(x[(b, t + dir * (tap - (taps - 1) / 2))][c]), zero outside [0, T): a k-tap 'same'
+ * convolution's input rows side by side (x fp32 or bf16, C % 8 == 0, taps odd).  The PostNet's 80-mel-bin convolutions
+ * (fs2/layers.py:143-212: first layer forward, last layer data gradient) then run as ONE plain K = taps * C GEMM on the
+ * bf16-storage core; dir = +1 pairs with the weight as [taps * Cin][Cout], dir = -1 (data gradient) with the weight as
+ * stored. */
+int fs2hip_im2col_taps(const void* x, int x_bf16, void* out_bf16, int B, int T, int C, int taps, int dir, void* stream);
 int fs2hip_transpose_cast_bf16(const float* src, int rows, int cols, int ld_src, void* dst, int ld_dst, int batch,
                                void* stream);
 /* The same for up to FS2_TRANSPOSE_MAX_JOBS matrices in one launch: dst[c][r] = bf16(src[r][c]), src fp32 [rows][cols]

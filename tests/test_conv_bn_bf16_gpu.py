@@ -104,3 +104,39 @@ def test_tiled_glu_depthwise_kernels_give_the_same_bits(H, B, T, C, K, bf):
             os.environ["FS2_DWCONV_TILE"] = prev
     for name, a, b in zip(("y", "stats", "dx", "dw", "db"), ref, got):
         assert torch.equal(a, b), name
+
+
+@pytest.mark.parametrize("B,T,Cin,Cout", [(3, 70, 80, 512), (2, 5, 16, 24), (1, 1, 8, 8)])
+def test_im2col_taps_gemm_is_the_k_tap_convolution(B, T, Cin, Cout):
+    """Round 5: the PostNet's 80-mel-bin convolutions as ONE plain GEMM over side-by-side input rows
+    (``hip.im2col_taps`` + ``hip.matmul_kn``): forward (dir = +1, weight transposed per tap) and data gradient (dir = -1,
+    weight as stored) against ``F.conv1d`` / its transposed form on the SAME bf16-rounded operands, fp32 and bf16 inputs,
+    utterance boundaries zero-padded (T = 1: only the centre tap sees data)."""
+    import torch.nn.functional as F
+    from fastspeech2_lightning_amd import hip as H
+    g = torch.Generator().manual_seed(5)
+    k = 5
+    x = torch.randn(B, T, Cin, generator=g)
+    w = torch.randn(Cout, Cin, k, generator=g) / (Cin * k) ** 0.5          # reference layout
+    bias = torch.randn(Cout, generator=g)
+    xb, wb = x.bfloat16().float(), w.bfloat16().float()
+    want = F.conv1d(xb.transpose(1, 2), wb, bias, padding=2).transpose(1, 2)
+    w_native = w.permute(2, 0, 1).contiguous().cuda()                        # [tap][Cout][Cin], the store's "convk" layout
+    for src in (x.cuda(), x.cuda().bfloat16()):
+        cols = H.im2col_taps(src.view(B * T, Cin), B, T, k)
+        assert cols.dtype == torch.bfloat16 and cols.shape == (B * T, k * Cin)
+        # column block `tap` of row (b, t) is x[b, t + tap - 2] (zeros outside the utterance)
+        pad = F.pad(xb, (0, 0, 2, 2))
+        for tap in range(k):
+            assert torch.equal(cols[:, tap * Cin:(tap + 1) * Cin].float().cpu().view(B, T, Cin), pad[:, tap:tap + T])
+        wt = H.transpose_cast_bf16(w_native).view(k * Cin, Cout)
+        got = H.matmul_kn(cols, wt, bias.cuda()).view(B, T, Cout).cpu()
+        assert float((got - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max())) * (k * Cin) ** 0.5
+    # data gradient: dx[t] = sum_tap W[tap]^T dy[t - (tap - 2)]
+    dy = torch.randn(B, T, Cout, generator=g)
+    dyb = dy.bfloat16().float()
+    want_dx = F.conv_transpose1d(dyb.transpose(1, 2), wb, padding=2).transpose(1, 2)
+    dcols = H.im2col_taps(dy.cuda().bfloat16().view(B * T, Cout), B, T, k, direction=-1)
+    # the stored layout of a Cin -> Cout conv weight [tap][Cout][Cin] is, flattened, the [taps * Cout][Cin] operand
+    got_dx = H.matmul_kn(dcols, w_native.bfloat16().view(k * Cout, Cin)).view(B, T, Cin).cpu()
+    assert float((got_dx - want_dx).abs().max()) < 2e-5 * max(1.0, float(want_dx.abs().max())) * (k * Cout) ** 0.5
