@@ -182,3 +182,36 @@ def test_held_weight_gradients_change_nothing_but_the_schedule(monkeypatch):
     for i, (w, g) in enumerate(zip(want, got)):
         assert torch.equal(w, g), i
     assert_same_state(ref, held)
+
+
+def test_replays_survive_validation_checkpoint_reload_and_a_grad_enabled_loop():
+    """What a real training loop does between two steps of one geometry: a validation pass (evaluation forward, its own
+    allocations), a checkpoint save + ``load_state_dict`` (weights rewritten in place), Lightning's grad-enabled call with
+    ``loss.backward()`` -- the replayed steps must still equal an eager model's bit for bit."""
+    eager, opt_e, config = build(plan=False)
+    planned, opt_p, _ = build(plan=True)
+    bs = batches(config, 6)
+    val = batches(config, 1, seed=31)[0]
+    rows = {id(eager): [], id(planned): []}
+    for model, opt in ((eager, opt_e), (planned, opt_p)):
+        for i, b in enumerate(bs):
+            if i % 2 == 0:   # the native loop
+                with torch.no_grad():
+                    model.training_step(b)
+            else:            # Lightning's automatic optimization: closure -> zero_grad -> backward -> step
+                loss = model.training_step(b)
+                opt.zero_grad()
+                loss.backward()
+            rows[id(model)].append(model._loss_slots.clone())
+            opt.step()
+            if i == 2:
+                v = model.validation_step(val)
+                assert torch.isfinite(v["total"])
+            if i == 3:
+                sd = {k: t.clone() for k, t in model.state_dict().items()}
+                model.load_state_dict(sd)
+    torch.cuda.synchronize()
+    assert planned.plans.replayed == 4
+    for i, (w, g) in enumerate(zip(rows[id(eager)], rows[id(planned)])):
+        assert torch.equal(w, g), i
+    assert_same_state(eager, planned)
