@@ -36,6 +36,44 @@ __global__ __launch_bounds__(256) void conv2d_s2_fwd_kernel(const float* __restr
   y[idx] = acc;
 }
 
+// The reference encoder's FIRST layer (fs2/gst/model.py:103-139: Conv2d(1, 32, 3, stride 2) over the mel "image"): one
+// input channel, so a thread of the generic kernel above loaded 9 + 9 scalars for ONE output and the launch -- 53 M
+// threads for the configs[4] batch -- took 419 us to write 211 MB (round 5 profile; the style encoder's forward pass is
+// what the main stream waits for at its join).  Here a thread makes four neighbouring output channels of a pixel: the
+// nine taps once, nine 16-byte weight loads, one 16-byte store; the same fmaf sequence per output (taps outside the
+// image skipped, in the same order), so the results are the generic kernel's bit for bit.
+__global__ __launch_bounds__(256) void conv2d_s2_fwd_c1_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                float* __restrict__ y, int B, int H, int W, int Ho, int Wo,
+                                                                int Cout) {
+  const int c4n = Cout >> 2;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)B * Ho * Wo * c4n;
+  if (idx >= total) return;
+  const int c4 = (int)(idx % c4n);
+  long long row = idx / c4n;
+  const int wo = (int)(row % Wo);
+  row /= Wo;
+  const int ho = (int)(row % Ho), b = (int)(row / Ho);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const int hi = 2 * ho + kh - 1;
+    if (hi < 0 || hi >= H) continue;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int wi = 2 * wo + kw - 1;
+      if (wi < 0 || wi >= W) continue;
+      const float xv = x[((long long)b * H + hi) * W + wi];
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (kh * 3 + kw) * Cout + 4 * c4);
+      acc[0] = fmaf(xv, wv[0], acc[0]);
+      acc[1] = fmaf(xv, wv[1], acc[1]);
+      acc[2] = fmaf(xv, wv[2], acc[2]);
+      acc[3] = fmaf(xv, wv[3], acc[3]);
+    }
+  }
+  *reinterpret_cast<f32x4*>(y + idx * 4) = acc;
+}
+
 // dx[b,hi,wi,ci] = sum over (kh,kw) with hi = 2ho+kh-1, wi = 2wo+kw-1 of sum_co dy[b,ho,wo,co] * w[kh][kw][ci][co]
 __global__ __launch_bounds__(256) void conv2d_s2_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                                   float* __restrict__ dx, int B, int H, int W, int Cin,
@@ -271,6 +309,11 @@ extern "C" int fs2hip_conv2d_s2_fwd(const float* x, const float* w, float* y, in
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return FS2HIP_EINVAL;
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   const long long total = (long long)B * Ho * Wo * Cout;
+  if (Cin == 1 && (Cout % 4) == 0 && !((uintptr_t)w % 16) && !((uintptr_t)y % 16) && total / 4 < 0x7fffffffLL * 256) {
+    conv2d_s2_fwd_c1_kernel<<<dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, S_>>>(x, w, y, B, H, W, Ho, Wo, Cout);
+    FS2_LAUNCH_CHECK();
+    return 0;
+  }
   conv2d_s2_fwd_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, S_>>>(x, w, y, B, H, W, Cin, Ho, Wo, Cout);
   FS2_LAUNCH_CHECK();
   return 0;

@@ -43,6 +43,11 @@ FP32_TRANSPOSED = _os.environ.get("FS2_FP32_TRANSPOSED", "1") != "0"
 #: encoder sub-module, during the encoder's backward pass (single GPU only: under data parallelism a bucket's weight
 #: gradients must be enqueued before its hand-off).  See ``hip.hold_weight_gradients``.
 HOLD_WGRADS = _os.environ.get("FS2_HOLD_WGRADS", "0") != "0"
+#: FS2_EARLY_FLUSH (single GPU): the second-stage sums pending when the encoder's backward pass starts -- every split-K
+#: slab set and bias / LayerNorm partial of the PostNet, the decoder and the variance adaptor, ~80 % of the 1.2 GB the
+#: final flush reads -- are finished on the side stream beside the encoder's small kernels instead of on the main stream
+#: after the last backward kernel, where nothing can hide them (0.2 ms).  Data parallel runs flush per bucket anyway.
+EARLY_FLUSH = _os.environ.get("FS2_EARLY_FLUSH", "1") != "0"
 
 
 #: FS2_PRED_LANES=1 (measurement aid, off by default): the three variance predictors -- independent chains of ~25 small
@@ -674,6 +679,9 @@ class FastSpeech2(_Base):
         if m.multilingual:
             self._rowvec_embedding_bwd("language_embedding.weight", c["batch"]["language_id"], d)
         self._bucket_done(self._bucket_va)                                # variance adaptor, GST, speaker / language
+        if EARLY_FLUSH and not sync and self.env.side_enabled and not hold:
+            with self.env.side():   # (after everything enqueued so far on both streams: lane 0 is in order)
+                self.env._side_held.extend(H.flush_grad_reductions())
         if hold:
             # from here on weight gradients run as they come (the encoder's own), and the held ones are released in
             # equal shares behind each of the encoder's layers
@@ -796,7 +804,7 @@ class FastSpeech2(_Base):
         weights = (t.pitch_loss_weight, t.energy_loss_weight, t.duration_loss_weight, t.mel_loss_weight,
                    t.postnet_loss_weight, t.attn_ctc_loss_weight, t.attn_bin_loss_weight)
         return (tuple(geo), self.precision, bool(self.env.side_enabled), tuple(PRED_LANES.values()), id(sync) if sync else 0, bin_w, weights,
-                getattr(self.postnet, "dropout_p", None), M.BF16_CHAIN, M.PRED_STORED, M.POSTNET_IM2COL, FP32_TRANSPOSED, HOLD_WGRADS, self.env.seed, H.plan_flags())
+                getattr(self.postnet, "dropout_p", None), M.BF16_CHAIN, M.PRED_STORED, M.POSTNET_IM2COL, FP32_TRANSPOSED, HOLD_WGRADS, EARLY_FLUSH, self.env.seed, H.plan_flags())
 
     def _planned_step(self, batch):
         sig = self._plan_signature(batch)

@@ -339,7 +339,7 @@ def test_duration_round_dense_sweep_around_every_tie(H, control):
     assert int((ref32 != ref64).sum()) <= 8, int((ref32 != ref64).sum())
 
 
-@pytest.mark.parametrize("B,Hh,Ww,Cin,Cout", [(2, 37, 80, 1, 32), (3, 19, 40, 32, 32), (2, 10, 5, 64, 128), (1, 3, 2, 128, 128),
+@pytest.mark.parametrize("B,Hh,Ww,Cin,Cout", [(2, 37, 80, 1, 32), (1, 5, 7, 1, 8), (3, 19, 40, 32, 32), (2, 10, 5, 64, 128), (1, 3, 2, 128, 128),
                                                (2, 8, 6, 6, 10)])
 def test_conv2d_stride2_fwd_bwd(H, B, Hh, Ww, Cin, Cout):
     """GST reference-encoder convolution (3x3, stride 2, pad 1, no bias, channels-last): the gather + MFMA GEMM route
