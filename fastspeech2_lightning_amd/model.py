@@ -816,7 +816,11 @@ class FastSpeech2(_Base):
             with torch.cuda.device(self.device_):
                 plan.feed(self.prepare_batch(batch))
                 losses, output = plan.replay(self.env.side_streams())
-            self._loss_slots, self._hard_idx = plan.extra["loss_slots"], plan.extra["hard_idx"]
+            # the loss terms are handed out as a COPY of the recorded slot vector (one 32-byte ATen copy): Lightning keeps
+            # logged tensors and reads them later, and the next replay rewrites the recorded vector in place
+            slots = plan.extra["loss_slots"].clone()
+            losses = OrderedDict((k, slots[i]) for k, i in plan.extra["loss_index"])
+            self._loss_slots, self._hard_idx = slots, plan.extra["hard_idx"]
             if plan.extra["bad"] is not None:
                 self._pending_bad.append((plan.extra["bad"], list(batch.get("basename") or [])))
             plans.replayed += 1
@@ -830,10 +834,14 @@ class FastSpeech2(_Base):
             n_bad = len(self._pending_bad)
             plan, (losses, output) = PL.record(lambda: self._run_step(pb), inputs, self.device_)
         bad = self._pending_bad[-1][0] if len(self._pending_bad) > n_bad else None
-        plan.extra = dict(loss_slots=self._loss_slots, hard_idx=self._hard_idx, bad=bad)
+        index = [(k, len(LOSS_KEYS) if k == "total" else LOSS_KEYS.index(k)) for k in losses]
+        plan.extra = dict(loss_slots=self._loss_slots, loss_index=index, hard_idx=self._hard_idx, bad=bad)
         plans.store(sig, plan)
         plans.recorded += 1
-        return losses, output
+        # (the recorded step's own loss terms are handed out as a copy too: replays rewrite the recorded vector)
+        slots = self._loss_slots.clone()
+        self._loss_slots = slots
+        return OrderedDict((k, slots[i]) for k, i in index), output
 
     def losses_to_host(self, losses=None) -> dict:
         """Every term of the last ``loss()`` as Python floats with ONE device-to-host copy (the slot vector)."""

@@ -215,3 +215,23 @@ def test_replays_survive_validation_checkpoint_reload_and_a_grad_enabled_loop():
     for i, (w, g) in enumerate(zip(rows[id(eager)], rows[id(planned)])):
         assert torch.equal(w, g), i
     assert_same_state(eager, planned)
+
+
+def test_logged_loss_tensors_of_a_replayed_step_keep_their_values():
+    """Lightning keeps the tensors ``log_dict`` received and reads them later: a replayed step hands out a copy of the
+    recorded slot vector, so step n's logged losses are not rewritten by step n + 1 (the big outputs are, by design)."""
+    planned, opt, config = build(plan=True)
+    bs = batches(config, 5)
+    kept = []
+    with torch.no_grad():
+        for b in bs:
+            total = planned.training_step(b)
+            kept.append((total, float(total), dict(planned.last_losses), {k: float(v) for k, v in planned.last_losses.items()}))
+            opt.step()
+    torch.cuda.synchronize()
+    assert planned.plans.replayed == 3
+    for total, value, losses, values in kept:
+        assert float(total) == value
+        for k, v in losses.items():
+            assert float(v) == values[k], k
+    assert len({v for _, v, _, _ in kept}) == len(kept)   # (the steps really differ: fresh contents, optimizer steps)
