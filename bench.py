@@ -30,6 +30,10 @@ import sys
 import time
 from pathlib import Path
 
+# before the HIP runtime initialises (fastspeech2_lightning_amd/hip.py explains): with the default 4 hardware queues the
+# step's side stream shares a queue with the main stream once RCCL has made its own streams
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import torch
 
 REPO = Path(__file__).resolve().parent

@@ -26,6 +26,8 @@ import time
 from pathlib import Path
 from typing import Optional
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the HIP runtime initialises: see fastspeech2_lightning_amd/hip.py
+
 import torch
 
 MONITOR = "validation/total_loss"  # fs2/cli/train.py:37

@@ -13,6 +13,13 @@ import os
 from pathlib import Path
 from typing import Optional
 
+# ROCclr maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  Once RCCL has created its streams the
+# step's side stream lands on the SAME hardware queue as the main stream and the two-stream step runs as one queue:
+# 20.9 ms against 18.7 ms per fp32 step with one RCCL rank (round 5, `FS2_BENCH_FORCE_SYNC=1`; every rank of a
+# data-parallel job would pay it).  Eight queues keep them apart.  Read when the HIP runtime initialises, so it is set
+# here -- and at the top of bench.py / cli.py, whose first GPU call precedes this import -- unless the user chose a value.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import torch
 
 _LIB_PATH = Path(__file__).resolve().parent / "_fs2hip.so"

@@ -107,10 +107,39 @@ def _rccl_single(port, q):
     sync = GradSync(model.store, force=True)  # one rank, but every bucket goes through RCCL from the side stream
     sync.broadcast_parameters(0)
     model.grad_sync = sync
-    model.training_step(batch)
-    sync.wait()
-    torch.cuda.synchronize()
-    q.put(float((model.store.grad - want).abs().max() / want.abs().max()))
+    # four steps: eager, RECORDED into a launch plan (the RCCL all-reduces are issued from the recording, inside the
+    # plan's memory pool and under its dispatch guard), then replayed twice with the hand-offs as host callbacks
+    worst = 0.0
+    for _ in range(4):
+        model.training_step(batch)
+        sync.wait()
+        torch.cuda.synchronize()
+        worst = max(worst, float((model.store.grad - want).abs().max() / want.abs().max()))
+    assert model.plans.recorded == 1 and model.plans.replayed == 2, (model.plans.recorded, model.plans.replayed)
+    # With RCCL's streams alive the step's side stream must still have a HARDWARE queue of its own: two spin kernels, one per
+    # stream, run side by side (with ROCclr's default of 4 hardware queues they shared one and took twice as long; the
+    # binding sets GPU_MAX_HW_QUEUES=8 before the runtime starts: fastspeech2_lightning_amd/hip.py)
+    side = model.env._lanes[0]
+    spin = int(3e-3 * 2.0e9)
+
+    def timed(both):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        torch.cuda._sleep(spin)
+        if both:
+            side.wait_event(e0)
+            with torch.cuda.stream(side):
+                torch.cuda._sleep(spin)
+            ev = torch.cuda.Event()
+            ev.record(side)
+            torch.cuda.current_stream().wait_event(ev)
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1)
+    timed(True)
+    ratio = min(timed(True) for _ in range(3)) / min(timed(False) for _ in range(3))
+    q.put((worst, ratio))
     dist.destroy_process_group()
 
 
@@ -127,10 +156,11 @@ def test_rccl_call_path_with_one_rank():
     p = ctx.Process(target=_rccl_single, args=(port, q))
     p.start()
     from fastspeech2_lightning_amd.cli import gather_from_ranks
-    err = gather_from_ranks([p], q, 1, timeout=300)[0]
+    err, overlap_ratio = gather_from_ranks([p], q, 1, timeout=300)[0]
     p.join(120)
     assert p.exitcode == 0
     assert err < 1e-6, err
+    assert overlap_ratio < 1.5, f"main and side stream share a hardware queue beside RCCL (two spins took {overlap_ratio:.2f} x one)"
 
 
 def test_bench_gpus_2_starts_its_own_ranks_and_reports_the_whole_job():
