@@ -31,8 +31,13 @@ import time
 from pathlib import Path
 
 # before the HIP runtime initialises (fastspeech2_lightning_amd/hip.py explains): with the default 4 hardware queues the
-# step's side stream shares a queue with the main stream once RCCL has made its own streams
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# step's side stream shares a queue with the main stream once RCCL has made its own streams.  Not for the gloo rehearsal
+# (FS2_BENCH_BACKEND=gloo: several ranks on ONE GPU, a test-only set-up): two processes with eight queues each on one
+# device turn gloo's host-synchronised exchange from seconds per step into minutes (round 5, tests/test_ddp_gpu.py).
+if os.environ.get("FS2_BENCH_BACKEND", "nccl") == "nccl":
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+else:  # (set, not defaulted: a parent process that imported the package has exported its 8)
+    os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("FS2_BENCH_HW_QUEUES", "4")
 
 import torch
 
