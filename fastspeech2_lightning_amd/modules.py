@@ -96,6 +96,64 @@ class Env:
             self._side_held = []
 
 
+#: side streams, ONE per (device, lane) for the whole process: every model's Env shares them (steps of different models are
+#: ordered on them exactly as on the shared main stream).  A stream per model was how the fourth model of a process -- the
+#: configs[4] leg of the default bench line -- came to run 50 % slower in some runs (round 4's driver: 30.2 ms against
+#: 23.1; round 5: 30.7 against 20.1): ROCclr maps HIP streams onto a few hardware queues, torch hands out pooled streams
+#: round-robin, and a side stream that lands on the MAIN stream's hardware queue turns the two-stream step into one queue
+#: with cross-stream waits in it.
+_SIDE_STREAMS = {}
+
+
+def _overlaps(main, side) -> bool:
+    """True when a spin kernel on ``side`` runs beside one on ``main`` (two hardware queues), False when the two take
+    twice as long as one (the streams share a hardware queue)."""
+    spin = int(1.0e-3 * 2.0e9)
+
+    def timed(both):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(main)
+        with torch.cuda.stream(main):
+            torch.cuda._sleep(spin)
+        if both:
+            side.wait_event(e0)
+            with torch.cuda.stream(side):
+                torch.cuda._sleep(spin)
+            ev = torch.cuda.Event()
+            ev.record(side)
+            main.wait_event(ev)
+        e1.record(main)
+        e1.synchronize()
+        return e0.elapsed_time(e1)
+    timed(True)
+    one = min(timed(False) for _ in range(2))
+    two = min(timed(True) for _ in range(2))
+    return two < 1.5 * one
+
+
+def shared_side_stream(lane: int = 0):
+    """The process-wide side stream of ``lane`` on the current device: created once, and CHECKED to run beside the
+    current (main) stream -- up to eight fresh streams are tried until one's spin kernel overlaps the main stream's
+    (a few milliseconds, once per process and lane)."""
+    dev = torch.cuda.current_device()
+    st = _SIDE_STREAMS.get((dev, lane))
+    if st is None:
+        main = torch.cuda.current_stream()
+        tried = []
+        for _ in range(8):
+            st = torch.cuda.Stream()
+            tried.append(st)  # (kept alive while probing: a released pooled stream would be handed out again)
+            if st.cuda_stream != main.cuda_stream and all(st.cuda_stream != o.cuda_stream for o in _SIDE_STREAMS.values()) \
+                    and _overlaps(main, st):
+                break
+        else:
+            import warnings
+            warnings.warn("fs2hip: no side stream with a hardware queue of its own was found (GPU_MAX_HW_QUEUES?): the "
+                          "two-stream step will run as one queue")
+        _SIDE_STREAMS[(dev, lane)] = st
+    return st
+
+
 class _SideSection:
     def __init__(self, env: Env, tensors, lane=0):
         self.env, self.tensors, self.lane = env, tensors, lane
@@ -109,7 +167,7 @@ class _SideSection:
             env._lanes, env._side_held, env._side_dirty = {}, [], set()
         st = env._lanes.get(self.lane)
         if st is None:
-            st = env._lanes[self.lane] = torch.cuda.Stream()
+            st = env._lanes[self.lane] = shared_side_stream(self.lane)
             if self.lane == 0:
                 env._side_stream = st
         ev = torch.cuda.Event()
