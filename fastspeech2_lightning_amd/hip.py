@@ -203,9 +203,15 @@ def plan_flags() -> tuple:
 def plan_callback(fn):
     """Host-side work that belongs at THIS point of the step's launch sequence (a gradient bucket's hand-off to the
     all-reduce): runs now, and at the same point -- under the same current stream -- of every replay of a recorded plan."""
-    fn()
     if _REC is not None:
+        # (a callback is HOST work the replayer repeats itself: whatever ATen it runs -- a collective, a pinned-memory
+        # copy -- is not what the recording guard is looking for)
+        from torch.utils._python_dispatch import _disable_current_modes
+        with _disable_current_modes():
+            fn()
         _REC.callback(fn, _stream())
+    else:
+        fn()
 
 
 def plan_host_op(fn):

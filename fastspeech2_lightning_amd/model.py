@@ -65,6 +65,7 @@ class VarianceAdaptor:
     def __init__(self, S: P.ParamStore, env: M.Env, config: FastSpeech2Config, stats: Stats):
         self.S, self.env, self.config = S, env, config
         self.bad_count = None  # set by the model: persistent device word counting duration / mel_lens mismatches
+        self.bad_probe = None  # set by the model: called right behind the kernel that bumps bad_count (training steps)
         vp, d = config.model.variance_predictors, config.model.encoder.input_dim
         pre = "variance_adaptor."
         # declaration order = execution order: energy, pitch, duration
@@ -121,6 +122,8 @@ class VarianceAdaptor:
             # fs2/variance_adaptor.py:289-305: the aligner's durations must add up to mel_lens; the per-utterance
             # flags stay on the device (FastSpeech2.check_bad_data reads them, no sync in a training step)
             cum_a, _, c["bad"] = H.duration_cumsum(dur_aligned, Tm_, expect=mel_lens, bad_count=self.bad_count)
+            if self.bad_probe is not None:
+                H.plan_callback(self.bad_probe)  # (host side of the in-step check: FastSpeech2._bad_probe)
             if energy_t is not None and cfg.energy.level.value == "phone":
                 energy_t = H.avg_variance(energy_t, cum_a)
             if pitch_t is not None and cfg.pitch.level.value == "phone":
@@ -402,6 +405,9 @@ class FastSpeech2(_Base):
         self._val_acc = {}
         if self.variance_adaptor is not None:
             self.variance_adaptor.bad_count = self.bad_count
+            self.variance_adaptor.bad_probe = self._bad_probe
+        self._bad_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._bad_event, self._bad_probed = None, False
         self._reorder_state_dict_keys()
         self.loss = FastSpeech2Loss(self)
         self._tables = {}
@@ -768,6 +774,7 @@ class FastSpeech2(_Base):
             losses, output = self._planned_step(batch)
         finally:
             self._in_step = False
+        self._raise_if_bad_in_step()  # (models that learn the alignment: BadDataError in the offending step)
         self.last_losses, self.last_output = losses, output
         # fs2/model.py:387-389 -- the reference reads every term back with ``.item()`` (6-8 host syncs per step); here
         # the values stay 0-dim device tensors (views of ONE slot vector): Lightning keeps logged tensors on the device
@@ -850,6 +857,28 @@ class FastSpeech2(_Base):
         out = {k: host[LOSS_KEYS.index(k)] for k in losses if k != "total"}
         out["total"] = host[len(LOSS_KEYS)]
         return out
+
+    def _bad_probe(self):
+        """Host side of the reference's IN-STEP ``BadDataError`` (fs2/variance_adaptor.py:289-305 raises inside the
+        step's forward): right behind the kernel that compares the aligner's durations with ``mel_lens``, the device
+        counter is copied into pinned host memory and an event is recorded.  ``training_step`` waits for THAT event -- the
+        GPU reaches it early in the step -- not for the step, and raises before the optimizer can apply a step computed
+        from corrupt data.  A launch-plan callback: replays repeat it at the same place."""
+        if not self._in_step:
+            return
+        if self._bad_event is None:
+            self._bad_event = torch.cuda.Event()
+        self._bad_host.copy_(self.bad_count, non_blocking=True)
+        self._bad_event.record()
+        self._bad_probed = True
+
+    def _raise_if_bad_in_step(self):
+        if not self._bad_probed:
+            return
+        self._bad_probed = False
+        self._bad_event.synchronize()
+        if int(self._bad_host) != self._bad_seen:
+            self.check_bad_data()
 
     def check_bad_data(self):
         """fs2/variance_adaptor.py:289-305: raises ``BadDataError`` naming the utterances whose aligner durations did not
