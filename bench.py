@@ -176,8 +176,10 @@ def build_parser():
                     help="replay the step from a hipGraph (single stream: the side stream for weight-gradient work is "
                          "switched off, graph branches run slower than two eager streams)")
     ap.add_argument("--no-graph", action="store_true", help="(default, kept for old command lines) launch eagerly")
-    ap.add_argument("--refine", action="store_true",
-                    help="second tuner stage: try the next-best GEMM tiles inside the step (+6 s of warm-up; measured gain 0.4 %%)")
+    ap.add_argument("--refine", action="store_true", help="(default since round 5; kept for old command lines)")
+    ap.add_argument("--no-refine", action="store_true",
+                    help="skip the second tuner stage (the next-best GEMM tiles of the 16 heaviest shapes tried inside the "
+                         "replayed step: +8-13 s of warm-up per model, measured -1.0 %% fp32 / -1.9 %% bf16-mixed per step)")
     ap.add_argument("--gst", action="store_true",
                     help="BASELINE.json configs[4] shape in fp32: multi-speaker (16) + GST style encoder, mel up to ~1200 frames")
     ap.add_argument("--precision", default="32-true", choices=["32-true", "32-split", "bf16-mixed"],
@@ -275,6 +277,33 @@ class Rig:
                 break
         torch.cuda.synchronize()
         return n
+
+    def refine(self, log=None, world=1, top=16, candidates=2):
+        """Second tuner stage (``hip.refine_tiles_in_step``): the runner-up tiles of the heaviest GEMM shapes tried inside
+        the replayed step.  With several ranks every decision is taken on the maximum over ranks of the timed step."""
+        from fastspeech2_lightning_amd import hip as H
+        from fastspeech2_lightning_amd import plan as PL
+        if not (H.GEMM_TUNE and PL.ENABLED):
+            return 0.0, 0
+        model = self.model
+
+        def eager_step():
+            model.plan_enabled = False
+            try:
+                self.step()
+            finally:
+                model.plan_enabled = True
+        agree = None
+        if world > 1:
+            import torch.distributed as dist
+
+            def agree(ms):
+                t = torch.tensor([ms], device=model.device_, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                return float(t)
+        return H.refine_tiles_in_step(self.step, rounds=8, log=log, settle=self.settle, count_step=eager_step, agree=agree,
+                                      top=int(os.environ.get("FS2_REFINE_TOP", top)),
+                                      candidates=int(os.environ.get("FS2_REFINE_CANDIDATES", candidates)))
 
     def plan_info(self):
         plans = self.model.plans
@@ -457,13 +486,15 @@ def roofline_of(sig, precision, prof, ov):
     return r
 
 
-def extra_leg(name, precision, batch_size, learn_alignment, steps, local, want_roofline, gst=False):
+def extra_leg(name, precision, batch_size, learn_alignment, steps, local, want_roofline, gst=False, refine=True):
     """One of the secondary configurations: own model, own batch, warm-up (tile tuning), >= 20 timed steps."""
     rig = Rig(precision, batch_size, learn_alignment=learn_alignment, gst=gst, local=local)
     for _ in range(3):
         rig.step()
     torch.cuda.synchronize()
     rig.settle()
+    if refine:
+        rig.refine()
     dt = rig.timed(steps) / steps
     out = {"precision": precision, "batch_per_gpu": batch_size, "learn_alignment": learn_alignment, "gst_multispeaker": gst,
            "steps": steps,
@@ -556,8 +587,10 @@ def main():
 
     use_graph = args.graph and not args.no_graph and world == 1
     model.env.side_enabled = model.env.side_enabled and not use_graph  # (FS2_SIDE_STREAM=0 keeps it off)
-    if args.refine and not use_graph:
-        t_ref, n_ref = H.refine_tiles_in_step(step, log=log)
+    # (with several ranks only on request: every rank must take the same trials and decisions -- rig.refine agrees on the
+    # maximum over ranks and share_tile_table ships rank 0's candidate lists -- but that path has never met real RCCL ranks)
+    if (args.refine or world == 1) and not args.no_refine and not use_graph:
+        t_ref, n_ref = rig.refine(log, world, top=32, candidates=3)  # (the headline: ~45 s; the legs take 16 x 2)
         log(f"in-step tile refinement: {n_ref} signatures changed, {t_ref:.2f} ms/step")
     graph = None
     if use_graph:
@@ -639,11 +672,12 @@ def main():
     if default_cfg and world == 1 and not args.no_extra_legs and graph is None:
         del rig, model, step, run
         torch.cuda.empty_cache()
-        bf16_b64 = extra_leg("bf16_mixed_b64", "bf16-mixed", 64, False, n_leg, local, not args.no_roofline)
-        align = extra_leg("learn_alignment", "32-true", 32, True, n_leg, local, False)
+        rf = not args.no_refine
+        bf16_b64 = extra_leg("bf16_mixed_b64", "bf16-mixed", 64, False, n_leg, local, not args.no_roofline, refine=rf)
+        align = extra_leg("learn_alignment", "32-true", 32, True, n_leg, local, False, refine=rf)
         # BASELINE.json configs[4] at its per-GPU share: GST reference encoder + 16 speakers, mel up to ~1 250 frames,
         # bf16-mixed, batch 64 (fs2/gst/model.py:87-100, fs2/model.py:196-213)
-        gst_leg = extra_leg("gst_bf16_b64", "bf16-mixed", 64, False, n_leg, local, not args.no_roofline, gst=True)
+        gst_leg = extra_leg("gst_bf16_b64", "bf16-mixed", 64, False, n_leg, local, not args.no_roofline, gst=True, refine=rf)
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         cpu = cpu_baseline(cpu_cfg, cpu_batch)
         log("cpu baseline done")

@@ -388,12 +388,20 @@ _TILE_CALLS = {}
 
 
 def refine_tiles_in_step(step, rounds: int = 5, candidates: int = 2, top: int = 16, min_gain: float = 0.004,
-                         log=None):
+                         log=None, settle=None, count_step=None, agree=None):
     """Second tuning stage, run once after warm-up: the per-shape tuner times a GEMM alone, back to back, with its
     operands warm in the Infinity Cache; inside the step the same launch sees cold outputs and a second stream.  For
     the ``top`` signatures by time the next-best isolated tiles are therefore tried IN the step (``step()`` = one whole
-    training step, timed over ``rounds`` steps) and kept when the step gets faster by more than ``min_gain``."""
+    training step, timed over ``rounds`` steps) and kept when the step gets faster by more than ``min_gain``.
+    With launch plans a changed tile re-keys the plan: ``settle()`` (runs steps until one replays) is called after every
+    change, so that what is timed is the replayed step -- whose timing is repeatable to a few hundredths of a millisecond
+    -- and ``count_step()`` is an EAGER step (the per-signature launch counts come from the binding).  Data parallel:
+    every rank must try the same tiles in the same order and take the same decisions (each trial runs collectives):
+    ``agree(ms)`` returns the value all ranks decide on (the maximum over ranks), and the candidate lists must be rank 0's
+    (``parallel.share_tile_table`` ships them with the tile table)."""
     def timed():
+        if settle is not None:
+            settle()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -401,11 +409,12 @@ def refine_tiles_in_step(step, rounds: int = 5, candidates: int = 2, top: int = 
             step()
         e1.record()
         e1.synchronize()
-        return e0.elapsed_time(e1) / rounds
+        t = e0.elapsed_time(e1) / rounds
+        return agree(t) if agree is not None else t
 
     for v in _TILE_CALLS.values():
         v[0] = 0
-    step()  # counts launches per signature
+    (count_step or step)()  # counts launches per signature
     base = min(timed(), timed())
     order = sorted((k for k in _TILE_TIMINGS if _TILE_CALLS.get(k, [0])[0] > 0),
                    key=lambda k: -_TILE_TIMINGS[k][0][0] * _TILE_CALLS[k][0])[:top]
@@ -422,6 +431,8 @@ def refine_tiles_in_step(step, rounds: int = 5, candidates: int = 2, top: int = 
                 base, keep, changed = t, tile, changed + 1
         _TILE_CACHE[key] = keep
         TILE_GEN[0] += 1
+    if settle is not None:
+        settle()
     return base, changed
 
 
@@ -461,6 +472,22 @@ def tile_table() -> dict:
     t = {repr(k): int(v) for k, v in _TILE_CACHE.items()}
     t["__format__"] = TILE_KEY_FORMAT
     return t
+
+
+def tile_timings() -> dict:
+    """The tuner's isolated timings per signature ({repr(signature): [[ms, tile], ...]}): what ``refine_tiles_in_step``
+    draws its candidates from -- shipped to every rank with the tile table so that all ranks try the same tiles."""
+    return {repr(k): [[float(ms), int(t)] for ms, t in v] for k, v in _TILE_TIMINGS.items()}
+
+
+def load_tile_timings(table: dict) -> None:
+    import ast
+    _TILE_TIMINGS.clear()
+    _TILE_CALLS.clear()
+    for k, v in table.items():
+        key = ast.literal_eval(k) if isinstance(k, str) else tuple(k)
+        _TILE_TIMINGS[key] = [(float(ms), int(t)) for ms, t in v]
+        _TILE_CALLS[key] = [0]
 
 
 def load_tile_table(table: dict) -> None:
