@@ -494,7 +494,8 @@ def extra_leg(name, precision, batch_size, learn_alignment, steps, local, want_r
     torch.cuda.synchronize()
     rig.settle()
     if refine:
-        rig.refine()
+        t_ref, n_ref = rig.refine(log)
+        log(f"{name}: in-step tile refinement: {n_ref} signatures changed, {t_ref:.2f} ms/step")
     dt = rig.timed(steps) / steps
     out = {"precision": precision, "batch_per_gpu": batch_size, "learn_alignment": learn_alignment, "gst_multispeaker": gst,
            "steps": steps,
@@ -592,6 +593,8 @@ def main():
     if (args.refine or world == 1) and not args.no_refine and not use_graph:
         t_ref, n_ref = rig.refine(log, world, top=32, candidates=3)  # (the headline: ~45 s; the legs take 16 x 2)
         log(f"in-step tile refinement: {n_ref} signatures changed, {t_ref:.2f} ms/step")
+        if os.environ.get("FS2_BENCH_SAVE_TILES"):  # the refined table, for FS2_GEMM_TILE_CACHE of a training run
+            H.save_tile_cache(os.environ["FS2_BENCH_SAVE_TILES"])
     graph = None
     if use_graph:
         graph = torch.cuda.CUDAGraph()
