@@ -388,7 +388,7 @@ _TILE_CALLS = {}
 
 
 def refine_tiles_in_step(step, rounds: int = 5, candidates: int = 2, top: int = 16, min_gain: float = 0.004,
-                         log=None, settle=None, count_step=None, agree=None):
+                         log=None, settle=None, count_step=None, agree=None, timer=None):
     """Second tuning stage, run once after warm-up: the per-shape tuner times a GEMM alone, back to back, with its
     operands warm in the Infinity Cache; inside the step the same launch sees cold outputs and a second stream.  For
     the ``top`` signatures by time the next-best isolated tiles are therefore tried IN the step (``step()`` = one whole
@@ -398,18 +398,22 @@ def refine_tiles_in_step(step, rounds: int = 5, candidates: int = 2, top: int = 
     -- and ``count_step()`` is an EAGER step (the per-signature launch counts come from the binding).  Data parallel:
     every rank must try the same tiles in the same order and take the same decisions (each trial runs collectives):
     ``agree(ms)`` returns the value all ranks decide on (the maximum over ranks), and the candidate lists must be rank 0's
-    (``parallel.share_tile_table`` ships them with the tile table)."""
-    def timed():
-        if settle is not None:
-            settle()
+    (``parallel.share_tile_table`` ships them with the tile table).  ``timer(step, rounds) -> ms per step`` replaces the
+    HIP-event clock (tests)."""
+    def event_timer(fn, n):
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(rounds):
-            step()
+        for _ in range(n):
+            fn()
         e1.record()
         e1.synchronize()
-        t = e0.elapsed_time(e1) / rounds
+        return e0.elapsed_time(e1) / n
+
+    def timed():
+        if settle is not None:
+            settle()
+        t = (timer or event_timer)(step, rounds)
         return agree(t) if agree is not None else t
 
     for v in _TILE_CALLS.values():

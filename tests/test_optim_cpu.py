@@ -76,3 +76,51 @@ def test_state_dicts_have_torch_shapes_and_round_trip():
     opt.param.grad = torch.zeros_like(opt.param)
     opt.zero_grad()
     assert opt.param.grad is None
+
+
+def test_in_step_tile_refinement_keeps_only_measured_gains():
+    """``hip.refine_tiles_in_step`` (the tuner's second stage, on by default in bench.py): the runner-up tiles of the
+    heaviest signatures are tried one at a time, a change is kept only when the (agreed) step time improves by more than
+    ``min_gain``, everything else is restored, every change bumps the tile generation (launch plans re-record) and
+    ``settle`` runs before each timing.  A fake clock stands in for the GPU."""
+    from fastspeech2_lightning_amd import hip as H
+    saved = dict(H._TILE_CACHE), dict(H._TILE_TIMINGS), dict(H._TILE_CALLS), H.TILE_GEN[0]
+    try:
+        H._TILE_CACHE.clear(); H._TILE_TIMINGS.clear(); H._TILE_CALLS.clear()
+        a, b, c = ("A",), ("B",), ("C",)
+        H._TILE_CACHE.update({a: 13, b: 7, c: 7})
+        H._TILE_TIMINGS.update({a: [(4.0, 13), (4.2, 7), (5.0, 8)], b: [(2.0, 7), (2.1, 5)], c: [(0.1, 7), (0.2, 8)]})
+        H._TILE_CALLS.update({a: [0], b: [0], c: [0]})
+        # the step's true time as a function of the table: signature a is faster IN the step on its runner-up tile 7,
+        # b's runner-up is slower, c is never launched in the step
+        def true_ms():
+            return 18.0 + {13: 0.5, 7: 0.2, 8: 0.6}[H._TILE_CACHE[a]] + {7: 0.0, 5: 0.3}[H._TILE_CACHE[b]]
+        calls = {"settle": 0, "count": 0, "agree": 0}
+
+        def count_step():
+            calls["count"] += 1
+            H._TILE_CALLS[a][0] += 3
+            H._TILE_CALLS[b][0] += 8
+
+        def settle():
+            calls["settle"] += 1
+
+        def agree(ms):
+            calls["agree"] += 1
+            return ms + 0.01  # (the maximum over ranks)
+        logs = []
+        gen0 = H.TILE_GEN[0]
+        base, changed = H.refine_tiles_in_step(lambda: None, rounds=4, candidates=2, top=8, min_gain=0.004, log=logs.append,
+                                               settle=settle, count_step=count_step, agree=agree,
+                                               timer=lambda fn, n: true_ms())
+        assert changed == 1 and H._TILE_CACHE == {a: 7, b: 7, c: 7}
+        assert abs(base - 18.21) < 1e-9 and len(logs) == 1 and "13 -> 7" in logs[0]
+        # timings: the baseline, a's two runner-ups, b's one (c is not launched in the step): each twice; settle before each
+        # and once more at the end
+        assert calls["count"] == 1 and calls["agree"] == 8 and calls["settle"] == 9
+        assert H.TILE_GEN[0] > gen0
+    finally:
+        H._TILE_CACHE.clear(); H._TILE_CACHE.update(saved[0])
+        H._TILE_TIMINGS.clear(); H._TILE_TIMINGS.update(saved[1])
+        H._TILE_CALLS.clear(); H._TILE_CALLS.update(saved[2])
+        H.TILE_GEN[0] = saved[3]
