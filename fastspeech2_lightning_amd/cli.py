@@ -116,6 +116,11 @@ def build_parser() -> argparse.ArgumentParser:
     tr.add_argument("--ckpt-every", type=int, default=None, help="write last.ckpt every N optimizer steps (default: once per epoch)")
     tr.add_argument("--log-every", type=int, default=50)
     tr.add_argument("--seed", type=int, default=1234)
+    tr.add_argument("--tune-tiles", action="store_true",
+                    help="before training: the GEMM tile tuner's in-step stage on the first training batch (the runner-up "
+                         "tiles of the heaviest shapes tried inside the replayed step; ~30-60 s; -1...2 %% per step).  "
+                         "Weights, optimizer state and BatchNorm buffers are restored afterwards; one rank only.  Save the "
+                         "table with FS2_GEMM_TILE_CACHE=<file> to reuse it")
     tr.add_argument("--dry-run", action="store_true", help="resolve config, filelists, look-up tables and the run directory, print the plan, touch no GPU")
     bm = sub.add_parser("benchmark", help="Time the forward pass on one batch of the training filelist (reference fs2/cli/benchmark.py)")
     bm.add_argument("config_file", type=Path)
@@ -312,7 +317,57 @@ class Trainer:
             self.best = m
             self.save("best.ckpt")
 
+    def tune_tiles(self):
+        """``--tune-tiles``: ``hip.refine_tiles_in_step`` on the first training batch.  The trial steps are real steps, so
+        everything they touch -- weights, gradient, Adam moments, the device step record (learning-rate schedule, dropout
+        masks), BatchNorm running statistics and counters -- is snapshotted first and put back afterwards: training
+        starts from exactly the state it would have started from, with a better tile table."""
+        if self.world > 1:
+            self.log({"tune_tiles": "skipped: one rank only"})
+            return
+        H, model, S = self.H, self.model, self.model.store
+        loader = self.loader(self.train_set, True, self.epoch, 0, 0)
+        batch = model.prepare_batch(next(iter(loader)))
+        snap = [t.clone() for t in (S.flat, S.grad, S.adam_m, S.adam_v, model.step_state, S.bn_counters)]
+        bufs = {k: v.clone() for k, v in S.buffers.items()}
+
+        def step():
+            with torch.no_grad():
+                model.training_step(batch)
+            self.opt.step()
+
+        def settle():
+            for _ in range(6):
+                before = model.plans.replayed
+                step()
+                if model.plans.replayed > before:
+                    break
+            torch.cuda.synchronize()
+
+        def eager_step():
+            model.plan_enabled = False
+            try:
+                step()
+            finally:
+                model.plan_enabled = True
+        t0 = time.perf_counter()
+        for _ in range(2):
+            step()  # (first-stage tuning of this geometry's shapes)
+        ms, changed = H.refine_tiles_in_step(step, rounds=8, top=32, candidates=3, settle=settle, count_step=eager_step)
+        with torch.no_grad():
+            for dst, src in zip((S.flat, S.grad, S.adam_m, S.adam_v, model.step_state, S.bn_counters), snap):
+                dst.copy_(src)
+            for k, v in bufs.items():
+                S.buffers[k].copy_(v)
+        S.weights_changed()
+        model.plans.clear()  # (their recorded loss / output tensors belong to the tuning steps)
+        if os.environ.get("FS2_GEMM_TILE_CACHE"):
+            H.save_tile_cache(os.environ["FS2_GEMM_TILE_CACHE"])
+        self.log({"tune_tiles": {"changed": changed, "ms_per_step": round(ms, 3), "seconds": round(time.perf_counter() - t0, 1)}})
+
     def fit(self):
+        if getattr(self.args, "tune_tiles", False):
+            self.tune_tiles()
         p, cfg = self.p, self.model.config
         max_steps, max_epochs = p["max_steps"], p["max_epochs"]
         done = lambda: 0 <= max_steps <= self.global_step  # noqa: E731  (Lightning: max_steps = -1 means no limit)

@@ -69,3 +69,23 @@ def test_fs2l_benchmark_times_the_forward_pass(tmp_path, capsys, kind):
     assert f"Average forward pass for {kind} duration after 5 repetitions:" in out and "Standard Deviation" in out
     ms = float(out.split("repetitions:")[1].split("ms")[0])
     assert 0.0 < ms < 1000.0
+
+
+@pytest.mark.tuned_tiles
+def test_tune_tiles_runs_trial_steps_and_hands_back_the_starting_state(tmp_path):
+    """``fs2l train --tune-tiles``: the tuner's in-step stage takes dozens of REAL steps on the first batch before training;
+    weights, Adam moments, the Noam / dropout step record and the BatchNorm buffers must come back, so the run's own steps
+    equal those of a run without the flag (to summation-order rounding: the tile table may differ)."""
+    cfg = make_project(tmp_path, n_train=10, n_val=3, write_features=True)
+    plain, _ = run(cfg, tmp_path / "a", "--max-steps", "4")
+    tuned, _ = run(cfg, tmp_path / "b", "--max-steps", "4", "--tune-tiles")
+    recs = [json.loads(l) for l in (tmp_path / "b" / "metrics.jsonl").read_text().splitlines()]
+    tune = [r["tune_tiles"] for r in recs if "tune_tiles" in r]
+    assert len(tune) == 1 and tune[0]["ms_per_step"] > 0 and tune[0]["changed"] >= 0
+    assert sorted(tuned) == [1, 2, 3, 4]
+    for step in range(1, 5):
+        a, b = plain[step], tuned[step]
+        assert abs(a["training/total_loss"] - b["training/total_loss"]) < 2e-5 * a["training/total_loss"], (step, a, b)
+        assert a["lr"] == b["lr"]
+    ck = torch.load(tmp_path / "b" / "checkpoints" / "last.ckpt", map_location="cpu", weights_only=False)
+    assert ck["global_step"] == 4 and ck["lr_schedulers"][0]["last_epoch"] == 4
