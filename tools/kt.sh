@@ -5,7 +5,7 @@ TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out
 rm -rf $O/${TAG}_kt
-FS2_SIDE_STREAM=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_kt -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-extra-legs "$@" > $O/${TAG}_kt.log 2>&1 || { tail -5 $O/${TAG}_kt.log; exit 1; }
+FS2_SIDE_STREAM=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_kt -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-extra-legs --no-refine "$@" > $O/${TAG}_kt.log 2>&1 || { tail -5 $O/${TAG}_kt.log; exit 1; }
 cp $O/${TAG}_kt/*/*_kernel_stats.csv $O/${TAG}_one_stream_kernel_stats.csv
 python3 tools/step_breakdown.py $O/${TAG}_kt/*/*_kernel_trace.csv 5 > $O/${TAG}_one_stream_step_breakdown.txt
 rm -rf $O/${TAG}_kt
