@@ -542,6 +542,90 @@ __global__ __launch_bounds__(256) void dist_bwd_k_kernel(const float* __restrict
   }
 }
 
+// ---- round 5: the two kernels above walk their reduction with one dependent global load per step (a wavefront per row,
+// the same dl address in every lane): 0.18 + 0.37 ms of the learned-alignment step at the benchmark shape for 0.85 GFLOP.
+// The tiled forms keep the other operand of an utterance in LDS and fetch dl coalesced, same arithmetic per term
+// (dl * (q - k), summed in ascending order of the reduction index), so the results are the simple kernels' bit for bit.
+
+// dq: a workgroup = 64 query rows of one utterance; k[b] ([T2][C], <= 64 KB) in LDS; a wavefront takes a row at a time,
+// lanes along the channels (two channel slots per lane: C <= 128), dl[row][j0 .. j0 + 63] fetched as one coalesced load and
+// handed round by readlane.
+__global__ __launch_bounds__(256) void dist_bwd_q_tile_kernel(const float* __restrict__ dl, const float* __restrict__ q,
+                                                               const float* __restrict__ k, float* __restrict__ dq, int T1,
+                                                               int T2, int C) {
+  extern __shared__ float ks[];  // [T2][C]
+  const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* kb = k + (long long)b * T2 * C;
+  for (int i = threadIdx.x; i < T2 * C; i += 256) ks[i] = kb[i];
+  __syncthreads();
+  const int c0 = lane, c1 = lane + 64;
+  for (int r = wave; r < 64; r += 4) {
+    const int t = blockIdx.x * 64 + r;
+    if (t >= T1) break;
+    const long long row = (long long)b * T1 + t;
+    const float q0 = c0 < C ? q[row * C + c0] : 0.f, q1 = c1 < C ? q[row * C + c1] : 0.f;
+    float a0 = 0.f, a1 = 0.f;
+    for (int j0 = 0; j0 < T2; j0 += 64) {
+      const float dv = j0 + lane < T2 ? dl[row * T2 + j0 + lane] : 0.f;
+      const int n = min(64, T2 - j0);
+#pragma unroll 8
+      for (int jj = 0; jj < n; ++jj) {
+        const float d = __shfl(dv, jj);
+        const float* kr = ks + (j0 + jj) * C;
+        if (c0 < C) a0 = fmaf(d, q0 - kr[c0], a0);
+        if (c1 < C) a1 = fmaf(d, q1 - kr[c1], a1);
+      }
+    }
+    if (c0 < C) dq[row * C + c0] = -0.001f * a0;
+    if (c1 < C) dq[row * C + c1] = -0.001f * a1;
+  }
+}
+
+// dk: a workgroup = 64 key positions of one utterance x all channels: lanes along the key positions (dl rows are read
+// coalesced), the four wavefronts take a quarter of the channels each (CPT per thread, in registers); q[b] passes through
+// LDS in tiles of 32 frames (broadcast reads).
+template <int CPT>
+__global__ __launch_bounds__(256) void dist_bwd_k_tile_kernel(const float* __restrict__ dl, const float* __restrict__ q,
+                                                               const float* __restrict__ k, float* __restrict__ dk, int T1,
+                                                               int T2, int C) {
+  constexpr int TT = 32;
+  __shared__ float qs[TT][4 * CPT];
+  const int b = blockIdx.y, lane = threadIdx.x & 63, cg = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + lane;
+  const bool jok = j < T2;
+  float kv[CPT], acc[CPT];
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = cg * CPT + i;
+    kv[i] = (jok && c < C) ? k[((long long)b * T2 + j) * C + c] : 0.f;
+    acc[i] = 0.f;
+  }
+  for (int t0 = 0; t0 < T1; t0 += TT) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < TT * 4 * CPT; i += 256) {
+      const int tt = i / (4 * CPT), c = i - tt * (4 * CPT);
+      qs[tt][c] = (t0 + tt < T1 && c < C) ? q[((long long)b * T1 + t0 + tt) * C + c] : 0.f;
+    }
+    float dv[TT];
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) dv[tt] = (jok && t0 + tt < T1) ? dl[((long long)b * T1 + t0 + tt) * T2 + j] : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      if (t0 + tt >= T1) break;  // (uniform: keeps the summation exactly T1 terms long)
+#pragma unroll
+      for (int i = 0; i < CPT; ++i) acc[i] = fmaf(dv[tt], qs[tt][cg * CPT + i] - kv[i], acc[i]);
+    }
+  }
+  if (jok) {
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int c = cg * CPT + i;
+      if (c < C) dk[((long long)b * T2 + j) * C + c] = 0.001f * acc[i];
+    }
+  }
+}
+
 }  // namespace
 
 #define S_ ((hipStream_t)stream)
@@ -637,14 +721,28 @@ extern "C" int fs2hip_attn_softmax_bwd(const float* logits, const float* soft, c
 extern "C" int fs2hip_attn_dist_bwd(const float* dlogits, const float* q, const float* k, float* dq, float* dk, int B,
                                     int T1, int T2, int C, void* stream) {
   if (B <= 0 || T1 <= 0 || T2 <= 0 || C <= 0) return FS2HIP_EINVAL;
+  const char* tile_env = getenv("FS2_DIST_BWD_TILE");  // "0": the simple one-wavefront-per-row kernels (measurement aid, tests)
+  const bool tiled = !(tile_env && atoi(tile_env) == 0) && C <= 128 && B <= 65535;
   if (dq) {
-    const long long rows = (long long)B * T1;
-    dist_bwd_q_kernel<<<dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, S_>>>(dlogits, q, k, dq, B, T1, T2, C);
+    const size_t smem = (size_t)T2 * C * sizeof(float);
+    if (tiled && smem <= 64 * 1024) {
+      dist_bwd_q_tile_kernel<<<dim3((T1 + 63) / 64, B), dim3(256), smem, S_>>>(dlogits, q, k, dq, T1, T2, C);
+    } else {
+      const long long rows = (long long)B * T1;
+      dist_bwd_q_kernel<<<dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, S_>>>(dlogits, q, k, dq, B, T1, T2, C);
+    }
     FS2_LAUNCH_CHECK();
   }
   if (dk) {
-    const long long rows = (long long)B * T2;
-    dist_bwd_k_kernel<<<dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, S_>>>(dlogits, q, k, dk, B, T1, T2, C);
+    if (tiled) {
+      const dim3 grid((T2 + 63) / 64, B);
+      if (C <= 32) dist_bwd_k_tile_kernel<8><<<grid, dim3(256), 0, S_>>>(dlogits, q, k, dk, T1, T2, C);
+      else if (C <= 80) dist_bwd_k_tile_kernel<20><<<grid, dim3(256), 0, S_>>>(dlogits, q, k, dk, T1, T2, C);
+      else dist_bwd_k_tile_kernel<32><<<grid, dim3(256), 0, S_>>>(dlogits, q, k, dk, T1, T2, C);
+    } else {
+      const long long rows = (long long)B * T2;
+      dist_bwd_k_kernel<<<dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, S_>>>(dlogits, q, k, dk, B, T1, T2, C);
+    }
     FS2_LAUNCH_CHECK();
   }
   return 0;

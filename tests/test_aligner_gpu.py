@@ -123,3 +123,28 @@ def test_ctc_bin_and_backward(H):
     dq, dk = H.attn_dist_bwd(dlogits, q.cuda(), k.cuda())
     close(dq, qr.grad, 2e-4, "dq")
     close(dk, kr.grad, 2e-4, "dk")
+
+
+@pytest.mark.parametrize("B,T1,T2,C", [(2, 648, 128, 80), (3, 131, 70, 80), (2, 65, 1, 20), (1, 33, 65, 128),
+                                       (2, 40, 300, 80), (1, 17, 9, 200)])
+def test_dist_bwd_tiled_kernels(H, B, T1, T2, C, monkeypatch):
+    """The LDS-tiled distance backward (csrc/aligner.hip, dist_bwd_{q,k}_tile_kernel) against autograd of the reference's
+    logits (fs2/model.py aligner: -temperature * squared distance, temperature 0.0005) and, bit for bit, against the
+    one-wavefront-per-row kernels it replaces (same terms in the same order).  Shapes: the benchmark's (648 frames x 128
+    symbols), ragged tails on both axes, one key, a 128-channel and a >64 KB key tile / >128-channel case (which fall back)."""
+    g = torch.Generator().manual_seed(B * 1000 + T1 + T2)
+    q = torch.randn(B, T1, C, generator=g)
+    k = torch.randn(B, T2, C, generator=g)
+    dl = torch.randn(B, T1, T2, generator=g) * 0.1
+    qr, kr = q.clone().requires_grad_(), k.clone().requires_grad_()
+    logits = -0.0005 * ((qr[:, :, None] - kr[:, None]) ** 2).sum(-1)
+    (logits * dl).sum().backward()
+    monkeypatch.delenv("FS2_DIST_BWD_TILE", raising=False)
+    dq, dk = H.attn_dist_bwd(dl.cuda(), q.cuda(), k.cuda())
+    close(dq, qr.grad, 2e-5, "dq")
+    close(dk, kr.grad, 2e-5, "dk")
+    monkeypatch.setenv("FS2_DIST_BWD_TILE", "0")
+    dq0, dk0 = H.attn_dist_bwd(dl.cuda(), q.cuda(), k.cuda())
+    assert torch.equal(dq, dq0) and torch.equal(dk, dk0)
+    only_q, none_k = H.attn_dist_bwd(dl.cuda(), q.cuda(), k.cuda(), want_dk=False)
+    assert none_k is None and torch.equal(only_q, dq0)
