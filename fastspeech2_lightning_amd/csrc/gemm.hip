@@ -10,6 +10,8 @@
 // k-contiguous sources on the way), issued one K-tile ahead of the MFMAs.
 #include <cstdlib>
 
+#include <string.h>
+
 #include "gemm_common.h"
 
 namespace {
@@ -186,8 +188,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 
 extern "C" int fs2hip_version(void) { return 1; }
 
-extern "C" int fs2hip_gemm(const Fs2GemmArgs* args, void* stream) {
-  GemmP p;
+namespace {
+// which launcher takes a prepared GemmP: the bf16-storage core, the direct-to-LDS fp32 cores (tile >= 4), the
+// register-staged core (tiles 1-3)
+enum { ROUTE_B = 1, ROUTE_V2 = 2, ROUTE_V1 = 3 };
+struct GemmRoute {
+  int core, tile, nz;
+};
+
+// fs2hip_gemm's argument checks and derived fields (p.a normalised, Rper, staged, drop, r_chunk of the BK=16 core) and
+// the choice of core and tile; nothing is enqueued
+int gemm_prepare(const Fs2GemmArgs* args, GemmP& p, GemmRoute& route) {
   p.staged = 0;
 #ifdef FS2_PROBES  // phase-ablation builds only (FS2_BUILD_PROBES=1 python -m fastspeech2_lightning_amd.build --force;
   // tools/probe_phases_bf16.sh): wrong results, timing only -- never in the shipped library
@@ -245,9 +256,9 @@ extern "C" int fs2hip_gemm(const Fs2GemmArgs* args, void* stream) {
     const int nzb = (a.shift_operand == 1 ? a.taps : 1) * a.splitk;
     int tb = a.tile;
     if (tb == 0) tb = (long long)((a.Mc + 127) / 128) * ((a.Nc + 127) / 128) * nzb >= 256 ? 20 : 23;
-    if (tb == 33) return nzb == 1 ? fs2_gemmws4_launch(p, (hipStream_t)stream) : FS2HIP_EINVAL;
-    if (tb >= 30) return nzb == 1 ? fs2_gemmws_launch(p, tb, (hipStream_t)stream) : FS2HIP_EINVAL;
-    return fs2_gemmb_launch(p, tb, nzb, (hipStream_t)stream);
+    if (tb >= 30 && nzb != 1) return FS2HIP_EINVAL;
+    route = {ROUTE_B, tb, nzb};
+    return 0;
   }
   // vector-load preconditions: the contiguous dimension of every operand is a multiple of 4
   // floats and rows start 16-byte aligned
@@ -298,7 +309,6 @@ extern "C" int fs2hip_gemm(const Fs2GemmArgs* args, void* stream) {
   int chunk = (a.R + a.splitk - 1) / a.splitk;
   p.r_chunk = ((chunk + BK - 1) / BK) * BK;
   const int nz = (a.shift_operand == 1 ? a.taps : 1) * a.splitk;
-  hipStream_t s = (hipStream_t)stream;
   static const int env_tile = getenv("FS2_GEMM_TILE") ? atoi(getenv("FS2_GEMM_TILE")) : 0;  // tuning aid
   int tile = a.tile ? a.tile : env_tile;
   // core v2 (direct-to-LDS, BK = 32) handles NT / NN / TN; core v1 (register-staged, BK = 16) additionally
@@ -314,12 +324,28 @@ extern "C" int fs2hip_gemm(const Fs2GemmArgs* args, void* stream) {
     tile = v2_ok ? (odd_taps ? (v1_ok && !a.operand_bf16 && !a.colsum ? 3 : 7) : (narrow ? 5 : 4)) : (narrow ? 2 : 1);  // (core v1 is fp32 only)
   }
   if (a.operand_bf16 == 3 && (tile < 4 || tile > 9)) return FS2HIP_EINVAL;  // the one-tile-per-workgroup direct-to-LDS core only
-  if (tile == 32) return fs2_gemmws32_launch(p, s);
   if (tile >= 4) {
-    if (!v2_ok) return FS2HIP_EINVAL;
-    return tile >= 10 ? fs2_gemm2p_launch(p, tile, nz, s) : fs2_gemm2_launch(p, tile, nz, s);
+    if (tile != 32 && !v2_ok) return FS2HIP_EINVAL;
+    route = {ROUTE_V2, tile, nz};
+    return 0;
   }
   if (!v1_ok || a.colsum) return FS2HIP_EINVAL;  // (the register-staged core does not sum columns)
+  route = {ROUTE_V1, tile, nz};
+  return 0;
+}
+
+int gemm_launch(GemmP& p, const GemmRoute& route, hipStream_t s) {
+  const Fs2GemmArgs& a = p.a;
+  const int tile = route.tile, nz = route.nz;
+  if (route.core == ROUTE_B) {
+    if (tile == 33) return fs2_gemmws4_launch(p, s);
+    if (tile >= 30) return fs2_gemmws_launch(p, tile, s);
+    return fs2_gemmb_launch(p, tile, nz, s);
+  }
+  if (route.core == ROUTE_V2) {
+    if (tile == 32) return fs2_gemmws32_launch(p, s);
+    return tile >= 10 ? fs2_gemm2p_launch(p, tile, nz, s) : fs2_gemm2_launch(p, tile, nz, s);
+  }
   if (tile == 3) {
     p.tiles_n = (a.Nc + 63) / 64;
     dim3 grid(((a.Mc + 63) / 64) * p.tiles_n, 1, nz);
@@ -335,4 +361,40 @@ extern "C" int fs2hip_gemm(const Fs2GemmArgs* args, void* stream) {
   }
   FS2_LAUNCH_CHECK();
   return 0;
+}
+}  // namespace
+
+extern "C" int fs2hip_gemm(const Fs2GemmArgs* args, void* stream) {
+  if (!args) return FS2HIP_EINVAL;
+  GemmP p;
+  GemmRoute route;
+  const int rc = gemm_prepare(args, p, route);
+  if (rc != 0) return rc;
+  return gemm_launch(p, route, (hipStream_t)stream);
+}
+
+extern "C" int fs2hip_gemm_grouped(const Fs2GemmArgs* args, int n, void* stream) {
+  if (!args || n < 1 || n > FS2_GEMM_GROUP_MAX) return FS2HIP_EINVAL;
+  if (n == 1) return fs2hip_gemm(args, stream);
+  GemmPG g;
+  memset(&g, 0, sizeof(g));
+  g.n = n;
+  const bool stored = args[0].operand_bf16 == 4;
+  int tile = args[0].tile;
+  if (tile == 0) tile = stored ? 23 : 7;
+  for (int i = 0; i < n; ++i) {
+    Fs2GemmArgs m = args[i];
+    // one kernel instance for all members: plain (tap-free) GEMMs of one orientation and operand type, on a tile the
+    // grouped kernels are built for; no in-kernel split-K finish (the counters are per stream, not per member), no
+    // dropout in the epilogue (not needed by any caller: the instance would have to carry it)
+    if (m.operand_bf16 != args[0].operand_bf16 || (m.operand_bf16 != 0 && m.operand_bf16 != 4)) return FS2HIP_EINVAL;
+    if ((m.a_kcontig != 0) != (args[0].a_kcontig != 0) || (m.b_kcontig != 0) != (args[0].b_kcontig != 0)) return FS2HIP_EINVAL;
+    if (m.taps > 1 || m.counters || m.drop_p > 0.f) return FS2HIP_EINVAL;
+    m.tile = tile;
+    GemmRoute route;
+    const int rc = gemm_prepare(&m, g.m[i], route);
+    if (rc != 0) return rc;
+    if (route.core != (stored ? ROUTE_B : ROUTE_V2) || route.tile != tile || route.nz != g.m[i].a.splitk) return FS2HIP_EINVAL;
+  }
+  return stored ? fs2_gemmb_launch_grouped(g, tile, (hipStream_t)stream) : fs2_gemm2_launch_grouped(g, tile, (hipStream_t)stream);
 }

@@ -20,8 +20,9 @@
 #include "gemm2_core.h"
 namespace {
 
+// ``bid`` of ``nblk``: the workgroup's index inside its launch -- or, in a grouped launch, inside its member's share of it
 template <int BM, int BN, bool AKC, bool BKC, int NST, int TAPS, int BF>
-__global__ __launch_bounds__(256) void gemm2_kernel(GemmP p) {
+__device__ __forceinline__ void gemm2_body(const GemmP& p, const int bid, const int nblk) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int A_TILE = BM * BK2, B_TILE = BN * BK2, STAGE = A_TILE + B_TILE;
   constexpr int L = BM / 32 + BN / 32;  // LDS-DMA instructions per thread per K-tile
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmP p) {
   // gridDim.z a slice's tiles were dealt over all eight XCDs and every XCD fetched the chunk: the 1024x256
   // weight gradient read X eight times, 255 MB for 106 MB of operands.]
   const int ntile = p.tiles_m * p.tiles_n;
-  const int unit = fs2_xcd_remap(blockIdx.x, gridDim.x);
+  const int unit = fs2_xcd_remap(bid, nblk);
   const int z = unit / ntile;
   const int wg = unit - z * ntile;
   const int tile_m = wg / p.tiles_n, tile_n = wg - tile_m * p.tiles_n;
@@ -113,6 +114,18 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmP p) {
   if (do_cs) colsum_store<BM>(a, cs, m0, wm, lane, split);
 }
 
+template <int BM, int BN, bool AKC, bool BKC, int NST, int TAPS, int BF>
+__global__ __launch_bounds__(256) void gemm2_kernel(GemmP p) {
+  gemm2_body<BM, BN, AKC, BKC, NST, TAPS, BF>(p, blockIdx.x, gridDim.x);
+}
+
+// grouped launch (GemmPG, gemm_common.h): the member that owns this workgroup, then the same code on ITS arguments
+template <int BM, int BN, bool AKC, bool BKC, int NST>
+__global__ __launch_bounds__(256) void gemm2g_kernel(GemmPG g) {
+  const int i = fs2_group_member(g, blockIdx.x);
+  gemm2_body<BM, BN, AKC, BKC, NST, TAPS_NONE, 0>(g.m[i], blockIdx.x - g.start[i], g.start[i + 1] - g.start[i]);
+}
+
 // fp32 or bf16-operand instance of one kernel shape
 #define FS2_GO(AKC_, BKC_, TAPS_)                                                          \
   do {                                                                                     \
@@ -169,7 +182,41 @@ int launch_tile(GemmP& p, int nz, hipStream_t s) {
 
 #undef FS2_GO
 
+template <int BM, int BN, int NST>
+int launch_grouped(GemmPG& g, hipStream_t s) {
+  long long total = 0;
+  for (int i = 0; i < g.n; ++i) {
+    GemmP& p = g.m[i];
+    const Fs2GemmArgs& a = p.a;
+    const int chunk = (a.R + a.splitk - 1) / a.splitk;
+    p.r_chunk = ((chunk + BK2 - 1) / BK2) * BK2;
+    p.tiles_m = (a.Mc + BM - 1) / BM;
+    p.tiles_n = (a.Nc + BN - 1) / BN;
+    if (!fs2_gemm2_offsets_fit(a)) return FS2HIP_EINVAL;
+    g.start[i] = (int)total;
+    total += (long long)p.tiles_m * p.tiles_n * a.splitk;
+    if (total > 0x7fffffffLL) return FS2HIP_EINVAL;
+  }
+  for (int i = g.n; i <= FS2_GEMM_GROUP_MAX; ++i) g.start[i] = (int)total;
+  const Fs2GemmArgs& a = g.m[0].a;
+  dim3 grid((unsigned)total), block(256);
+  if (a.a_kcontig && a.b_kcontig) gemm2g_kernel<BM, BN, true, true, NST><<<grid, block, 0, s>>>(g);
+  else if (a.a_kcontig && !a.b_kcontig) gemm2g_kernel<BM, BN, true, false, NST><<<grid, block, 0, s>>>(g);
+  else if (!a.a_kcontig && !a.b_kcontig) gemm2g_kernel<BM, BN, false, false, NST><<<grid, block, 0, s>>>(g);
+  else return FS2HIP_EINVAL;
+  FS2_LAUNCH_CHECK();
+  return 0;
+}
+
 }  // namespace
+
+int fs2_gemm2_launch_grouped(GemmPG& g, int tile, hipStream_t s) {
+  switch (tile) {
+    case 7: return launch_grouped<64, 64, 2>(g, s);
+    case 8: return launch_grouped<128, 64, 2>(g, s);
+    default: return FS2HIP_EINVAL;
+  }
+}
 
 int fs2_gemm2_launch(GemmP& p, int tile, int nz, hipStream_t s) {
   const Fs2GemmArgs& a = p.a;

@@ -4,8 +4,9 @@
 
 namespace {
 
+// ``bid`` of ``nblk``: the workgroup's index inside its launch -- or, in a grouped launch, inside its member's share of it
 template <int BM, int BN, bool AKC, bool BKC, int TAPS, int NST, bool COLSUM>
-__global__ __launch_bounds__(256) void gemmb_kernel(GemmP p) {
+__device__ __forceinline__ void gemmb_body(const GemmP& p, const int bid, const int nblk) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   constexpr int L = BM / 32 + BN / 32;  // LDS-DMA instructions per thread per K-tile
@@ -16,7 +17,7 @@ __global__ __launch_bounds__(256) void gemmb_kernel(GemmP p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int ntile = p.tiles_m * p.tiles_n;
-  const int unit = fs2_xcd_remap(blockIdx.x, gridDim.x);
+  const int unit = fs2_xcd_remap(bid, nblk);
   const int z = unit / ntile;
   const int wg = unit - z * ntile;
   const int tile_m = wg / p.tiles_n, tile_n = wg - tile_m * p.tiles_n;
@@ -100,6 +101,18 @@ __global__ __launch_bounds__(256) void gemmb_kernel(GemmP p) {
   }
 }
 
+template <int BM, int BN, bool AKC, bool BKC, int TAPS, int NST, bool COLSUM>
+__global__ __launch_bounds__(256) void gemmb_kernel(GemmP p) {
+  gemmb_body<BM, BN, AKC, BKC, TAPS, NST, COLSUM>(p, blockIdx.x, gridDim.x);
+}
+
+// grouped launch (GemmPG, gemm_common.h): the member that owns this workgroup, then the same code on ITS arguments
+template <int BM, int BN, bool AKC, bool BKC, int NST, bool COLSUM>
+__global__ __launch_bounds__(256) void gemmbg_kernel(GemmPG g) {
+  const int i = fs2_group_member(g, blockIdx.x);
+  gemmb_body<BM, BN, AKC, BKC, BT_NONE, NST, COLSUM>(g.m[i], blockIdx.x - g.start[i], g.start[i + 1] - g.start[i]);
+}
+
 template <int BM, int BN, int NST>
 int launch_b(GemmP& p, int nz, hipStream_t s) {
   const Fs2GemmArgs& a = p.a;
@@ -136,7 +149,41 @@ int launch_b(GemmP& p, int nz, hipStream_t s) {
   return 0;
 }
 
+template <int BM, int BN, int NST>
+int launch_b_grouped(GemmPG& g, hipStream_t s) {
+  long long total = 0;
+  for (int i = 0; i < g.n; ++i) {
+    GemmP& p = g.m[i];
+    const Fs2GemmArgs& a = p.a;
+    const int chunk = (a.R + a.splitk - 1) / a.splitk;
+    p.r_chunk = ((chunk + BKE - 1) / BKE) * BKE;
+    p.tiles_m = (a.Mc + BM - 1) / BM;
+    p.tiles_n = (a.Nc + BN - 1) / BN;
+    g.start[i] = (int)total;
+    total += (long long)p.tiles_m * p.tiles_n * a.splitk;
+    if (total > 0x7fffffffLL) return FS2HIP_EINVAL;
+  }
+  for (int i = g.n; i <= FS2_GEMM_GROUP_MAX; ++i) g.start[i] = (int)total;
+  const Fs2GemmArgs& a = g.m[0].a;
+  dim3 grid((unsigned)total), block(256);
+  if (a.a_kcontig && a.b_kcontig) gemmbg_kernel<BM, BN, true, true, NST, false><<<grid, block, 0, s>>>(g);
+  else if (a.a_kcontig && !a.b_kcontig) gemmbg_kernel<BM, BN, true, false, NST, false><<<grid, block, 0, s>>>(g);
+  else if (!a.a_kcontig && !a.b_kcontig) gemmbg_kernel<BM, BN, false, false, NST, true><<<grid, block, 0, s>>>(g);
+  else return FS2HIP_EINVAL;
+  FS2_LAUNCH_CHECK();
+  return 0;
+}
+
 }  // namespace
+
+int fs2_gemmb_launch_grouped(GemmPG& g, int tile, hipStream_t s) {
+  switch (tile) {
+    case 22: return launch_b_grouped<128, 64, 2>(g, s);
+    case 23: return launch_b_grouped<64, 64, 3>(g, s);
+    case 26: return launch_b_grouped<64, 64, 2>(g, s);
+    default: return FS2HIP_EINVAL;
+  }
+}
 
 int fs2_gemmbp_launch(GemmP& p, int tile, int nz, hipStream_t s);  // gemm_bf16p.hip
 

@@ -14,6 +14,22 @@ struct GemmP {
   Fs2Drop drop;
 };
 
+// Grouped launch (fs2hip_gemm_grouped): up to FS2_GEMM_GROUP_MAX independent GEMMs of ONE kernel instance (same core, tile,
+// operand orientations, no conv taps) in one grid.  Member i owns the workgroups [start[i], start[i + 1]); inside them
+// the member's own GemmP applies unchanged (shapes, split-K, epilogue and pointers may all differ).  The whole table
+// travels as the kernel argument (2.4 KB): nothing to upload, and a recorded launch plan replays it as it stands.
+struct GemmPG {
+  int n;
+  int start[FS2_GEMM_GROUP_MAX + 1];
+  GemmP m[FS2_GEMM_GROUP_MAX];
+};
+__device__ __forceinline__ int fs2_group_member(const GemmPG& g, int bid) {
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < FS2_GEMM_GROUP_MAX; ++k) i += (k < g.n && bid >= g.start[k]) ? 1 : 0;
+  return i;
+}
+
 // accumulator tile -> global memory with the fused epilogue (bias, activation, residual, dropout, act')
 // C/D layout of v_mfma_f32_32x32x2_f32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5):
 // one store instruction writes two full 128-byte row segments.
@@ -267,6 +283,10 @@ int fs2_gemmws_launch(GemmP& p, int tile, hipStream_t s);
 int fs2_gemmws32_launch(GemmP& p, hipStream_t s);
 // bf16-storage core, K = 1024, tile id 33 (gemm_ws4.hip)
 int fs2_gemmws4_launch(GemmP& p, hipStream_t s);
+// grouped forms (GemmPG): fp32 core tiles 7 / 8, bf16-storage core tiles 22 / 23 / 26; every member prepared by
+// fs2hip_gemm's own checks (p.a, Rper, drop, staged set; tiles_m / tiles_n / r_chunk / start are filled in here)
+int fs2_gemm2_launch_grouped(GemmPG& g, int tile, hipStream_t s);
+int fs2_gemmb_launch_grouped(GemmPG& g, int tile, hipStream_t s);
 // finishes the reduction-split tail tiles of a persistent launch (reduce.hip)
 int fs2_tail_fixup(const float* ws, int S, long long slab, float* C, int ldc, const float* bias, float alpha, int m0,
                    int Mc, int Nc, hipStream_t s);

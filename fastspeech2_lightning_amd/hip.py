@@ -60,6 +60,7 @@ _T = {"p": C.c_void_p, "i": C.c_int, "f": C.c_float, "q": C.c_longlong, "Q": C.c
 SIGNATURES = {
     "fs2hip_version": "",
     "fs2hip_gemm": None,  # (const Fs2GemmArgs*, stream)
+    "fs2hip_gemm_grouped": None,  # (const Fs2GemmArgs*, int, stream)
     "fs2hip_reduce_slabs_multi": "pip",
     "fs2hip_reduce_slabs": "ppqiqp",
     "fs2hip_reduce_rows_multi": None,  # (const Fs2ReduceJob*, int, void*): set below
@@ -168,6 +169,7 @@ def lib():
             if sig is not None:
                 fn.argtypes = [_T[c] for c in sig]
         L.fs2hip_gemm.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
+        L.fs2hip_gemm_grouped.argtypes = [C.POINTER(GemmArgs), C.c_int, C.c_void_p]
         L.fs2hip_reduce_rows_multi.argtypes = [C.POINTER(ReduceJob), C.c_int, C.c_void_p]
         L.fs2hip_reduce_slabs_multi.argtypes = [C.POINTER(SlabJob), C.c_int, C.c_void_p]
         L.fs2hip_transpose_cast_bf16_multi.argtypes = [C.POINTER(TransposeJob), C.c_int, C.c_void_p]
@@ -619,6 +621,9 @@ def _gemm(_algorithmic=True, **kw):
     if not a.operand_bf16:  # (3 / 4 = bf16 operands in memory: set by the caller that passes bf16 tensors)
         a.operand_bf16 = int(GEMM_BF16) if _algorithmic else 0
     a.tile = _tune_tile(a)
+    if _GROUP is not None:  # ``gemm_group()``: launched with the others when the group closes
+        _GROUP.entries.append((a, _algorithmic, _stream()))
+        return
     if GEMM_PROFILE is None or not _algorithmic:  # (the one-hot embedding GEMM's flops are not algorithmic)
         _launch_gemm(a)
         return
@@ -626,15 +631,172 @@ def _gemm(_algorithmic=True, **kw):
     e0.record()
     _launch_gemm(a)
     e1.record()
+    _profile_gemm(a, e0, e1)
+
+
+def _gemm_cost(a):
+    """(algorithmic flops, algorithmic bytes: every operand element read once, every output element written once)"""
     ntap = a.taps if a.shift_operand == 1 else 1
-    # algorithmic bytes: every operand element read once, every output element written once
     ra = a.R // a.taps if (a.taps > 1 and a.shift_operand == 0) else a.R
     esz = 2.0 if a.operand_bf16 >= 3 else 4.0
     osz = 2.0 if (a.io_bf16 & 1) else 4.0
     nbytes = (esz * (a.Mc * ra + a.Nc * a.R) + osz * a.Mc * a.Nc * ntap + 4.0 * (a.Mc * a.Nc if a.resid else 0)
               + (2.0 if (a.io_bf16 & 2) else 4.0) * (a.Mc * a.Nc if a.aux else 0) + osz * (a.Mc * a.Nc if a.out_pre else 0))
-    GEMM_PROFILE.append((e0, e1, 2.0 * a.Mc * a.Nc * a.R * ntap, a.Mc, a.Nc, a.R * ntap, nbytes,
-                         (a.a_kcontig, a.b_kcontig, a.taps, a.shift_operand, a.splitk, a.epi, a.tile)))
+    return 2.0 * a.Mc * a.Nc * a.R * ntap, nbytes
+
+
+def _profile_gemm(a, e0, e1, members=None):
+    """One GEMM_PROFILE entry per LAUNCH; a grouped launch carries its members' summed cost under the first member's shape
+    and a trailing ("grouped", n) in its kind."""
+    ntap = a.taps if a.shift_operand == 1 else 1
+    flops, nbytes = _gemm_cost(a)
+    kind = (a.a_kcontig, a.b_kcontig, a.taps, a.shift_operand, a.splitk, a.epi, a.tile)
+    if members:
+        cost = [_gemm_cost(m) for m in members]
+        flops, nbytes = sum(c[0] for c in cost), sum(c[1] for c in cost)
+        kind += ("grouped", len(members))
+    GEMM_PROFILE.append((e0, e1, flops, a.Mc, a.Nc, a.R * ntap, nbytes, kind))
+
+
+# ---- grouped launches -----------------------------------------------------------------------------------------------
+#: FS2_GEMM_GROUP=0 (measurement aid): ``gemm_group()`` sections launch their GEMMs one by one, as before round 5
+GEMM_GROUP = os.environ.get("FS2_GEMM_GROUP", "1") != "0"
+GROUP_MAX = 8  # FS2_GEMM_GROUP_MAX (include/fs2hip.h)
+#: tiles the grouped kernels are built for, first = default: fp32 core / bf16-storage core (csrc/gemm2.hip, gemm_bf16.hip)
+GROUP_TILES = {0: (7, 8), 4: (23, 26, 22)}
+_GROUP = None
+_GROUP_TILE_CACHE = {}
+#: how many grouped launches / members went out, and how many members fell back to launches of their own (tests, logs)
+GROUP_STATS = {"launches": 0, "members": 0, "single": 0}
+
+
+class gemm_group:
+    """Context manager: the GEMMs the enclosed wrapper calls (``linear_fwd``, ``linear_bwd_data``, ``linear_bwd_weight``)
+    would launch are collected and go out together when the section closes -- members that can share a kernel instance
+    (``fs2hip_gemm_grouped``: same operand orientations and storage type, no conv taps, no epilogue dropout) in ONE launch
+    per up to eight of them, the rest one by one, in call order.  The enclosed calls must be independent of one another
+    (no result of one is read by another inside the section), on one stream, and must not need their result before the
+    section closes; everything else they do (allocations, deferred second-stage sums) happens at the call.  Each member
+    computes exactly what its own launch would: same tile code on the member's own arguments."""
+
+    def __enter__(self):
+        global _GROUP
+        self.entries, self.after, self.outer = [], [], True
+        if GEMM_GROUP and _GROUP is None:
+            _GROUP = self
+        else:  # switched off, or inside another group (the outer one collects)
+            self.outer = False
+        return self
+
+    def __exit__(self, et, ev, tb):
+        global _GROUP
+        if not self.outer:
+            return False
+        _GROUP = None
+        if et is None:
+            _launch_group(self.entries)
+            for fn in self.after:  # (a wrapper's own follow-up launch: the split-K finish of a direct caller)
+                fn()
+        return False
+
+
+def _group_class(a):
+    """Members with the same value can share a grouped launch (None: never grouped)."""
+    if a.taps > 1 or a.counters or a.drop_p > 0 or a.operand_bf16 not in GROUP_TILES:
+        return None
+    return (a.operand_bf16, bool(a.a_kcontig), bool(a.b_kcontig))
+
+
+def _group_tile(arr, n, members, stream):
+    """Tile of a grouped launch: the members' common tuned tile when the grouped kernels carry it, else the best of the
+    grouped tiles by the tuner's own clock (timed once per combination of member signatures), else the default."""
+    tiles = GROUP_TILES[members[0].operand_bf16]
+    if not GEMM_TUNE and not _TILE_CACHE:
+        return 0
+    key = tuple(_tile_key(m) for m in members)
+    t = _GROUP_TILE_CACHE.get(key)
+    if t is not None:
+        return t
+    if not GEMM_TUNE or _REC is not None or torch.cuda.is_current_stream_capturing():
+        common = {m.tile for m in members}
+        return common.pop() if len(common) == 1 and members[0].tile in tiles else 0
+    L, best, best_ms = real_lib(), 0, float("inf")
+    for tile in tiles:
+        arr[0].tile = tile
+        if L.fs2hip_gemm_grouped(arr, n, stream) != 0:
+            continue
+        ms = float("inf")
+        for _ in range(2):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(4):
+                L.fs2hip_gemm_grouped(arr, n, stream)
+            e1.record()
+            e1.synchronize()
+            ms = min(ms, e0.elapsed_time(e1))
+        if ms < best_ms:
+            best, best_ms = tile, ms
+    _GROUP_TILE_CACHE[key] = best
+    TILE_GEN[0] += 1
+    return best
+
+
+def _launch_one(a, algorithmic):
+    GROUP_STATS["single"] += 1
+    if GEMM_PROFILE is None or not algorithmic:
+        _launch_gemm(a)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _launch_gemm(a)
+    e1.record()
+    _profile_gemm(a, e0, e1)
+
+
+def _launch_group(entries):
+    if not entries:
+        return
+    stream = _stream()
+    _req(all(st == stream for _, _, st in entries), "gemm_group: the enclosed calls ran on different streams")
+    # partition in call order: runs of one class, at most GROUP_MAX each; members that cannot be grouped go alone
+    classes = {}
+    order = []
+    for a, alg, _ in entries:
+        c = _group_class(a)
+        if c is None:
+            order.append([(a, alg)])
+            continue
+        run = classes.get(c)
+        if run is None or len(run) >= GROUP_MAX:
+            run = classes[c] = []
+            order.append(run)
+        run.append((a, alg))
+    for run in order:
+        if len(run) == 1:
+            _launch_one(*run[0])
+            continue
+        n = len(run)
+        arr = (GemmArgs * n)()
+        for i, (a, _) in enumerate(run):
+            C.memmove(C.byref(arr[i]), C.byref(a), C.sizeof(GemmArgs))
+        members = [a for a, _ in run]
+        arr[0].tile = _group_tile(arr, n, members, stream)
+        prof = GEMM_PROFILE is not None and all(alg for _, alg in run)
+        if prof:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        rc = lib().fs2hip_gemm_grouped(arr, n, stream)
+        if rc == -22:  # the members cannot share a launch after all (a shape the grouped tiles refuse): one by one
+            for a, alg in run:
+                _launch_one(a, alg)
+            continue
+        _ok(rc, "gemm_grouped")
+        GROUP_STATS["launches"] += 1
+        GROUP_STATS["members"] += n
+        if prof:
+            e1.record()
+            members[0].tile = arr[0].tile
+            _profile_gemm(members[0], e0, e1, members)
 
 
 def linear_fwd(x, w, bias=None, *, epi=EPI_STORE, act=None, resid=None, res_scale=1.0, out_pre=None,
@@ -892,14 +1054,21 @@ def _linear_bwd_weight(dy, x, out, *, taps=1, T=0, n_valid=None, bias_grad=None)
         if in_kernel:  # the last workgroup of every output tile sums the slabs: no second launch
             kw["counters"] = _p(splitk_counters(dy.device))
         defer = _DEFER_SLABS and not in_kernel
-        if defer:  # a buffer of its own, summed with every other pending split at the next flush_grad_reductions()
+        if defer or _GROUP is not None:
+            # a buffer of its own: summed with every other pending split at the next flush_grad_reductions() / not shared
+            # with the other members of a ``gemm_group`` (their launches come before any of their finishes)
             ws = torch.empty(S * n, device=dy.device, dtype=torch.float32)
             kw["workspace"] = _p(ws)
         _gemm(_algorithmic=n_valid is None, **kw)
         if defer:
             _PENDING_SLABS.append((ws, out, n, S))
         elif not in_kernel:
-            _ok(lib().fs2hip_reduce_slabs(_p(ws), _p(out), n, S, n, _stream()), "reduce_slabs")
+            def finish(ws=ws):
+                _ok(lib().fs2hip_reduce_slabs(_p(ws), _p(out), n, S, n, _stream()), "reduce_slabs")
+            if _GROUP is not None:
+                _GROUP.after.append(finish)  # behind the group's launches
+            else:
+                finish()
     else:
         _gemm(_algorithmic=n_valid is None, **kw)
     return out
@@ -928,6 +1097,10 @@ def hold_weight_gradients(on: bool):
     left = _HELD_WGRADS or []
     _HELD_WGRADS = [] if on else None
     return left
+
+
+def holding_weight_gradients() -> bool:
+    return _HELD_WGRADS is not None
 
 
 def held_weight_gradients() -> int:

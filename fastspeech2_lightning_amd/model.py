@@ -59,6 +59,14 @@ PRED_LANES = ({"energy": 1, "pitch": 2, "duration": 3} if _os.environ.get("FS2_P
               else {"energy": 0, "pitch": 0, "duration": 0})
 
 
+#: FS2_PRED_GROUP=0 (measurement aid): the variance predictors of a training step run one after the other on the side
+#: stream, as in rounds 1-4.  Default: predictors that see the same number of rows walk their layers in lockstep and their
+#: pointwise GEMMs -- forward, data gradient, weight gradient -- go out as one grouped launch per layer
+#: (``modules.predictors_fwd``, ``fs2hip_gemm_grouped``); the three chains are independent in training because each
+#: embedding is looked up from the TARGET (fs2/variance_adaptor.py:309-352).
+PRED_GROUP = _os.environ.get("FS2_PRED_GROUP", "1") != "0"
+
+
 class VarianceAdaptor:
     """reference ``fs2/variance_adaptor.py:84-412`` (order of operations ``:309-397``)."""
 
@@ -81,11 +89,35 @@ class VarianceAdaptor:
         S.add_buffer(pre + "energy_bins", torch.linspace(stats.energy.norm_min, stats.energy.norm_max, vp.energy.n_bins - 1))
         self.pre = pre
 
-    def _variance(self, name, x, target, lens, control, inference):
+    def _grouping(self) -> bool:
+        return PRED_GROUP and not any(PRED_LANES.values())
+
+    def _run_predictors(self, jobs, res):
+        """``jobs``: [(name, input, lens)] of a training forward, all inputs made; ``res`` receives name -> (prediction,
+        context).  Predictors with equal ``lockstep_key`` run as one lockstep chain on the side stream; the groups are
+        returned (the backward pass walks the same groups)."""
+        groups = {}
+        for name, x, lens in jobs:
+            groups.setdefault(getattr(self, f"{name}_predictor").lockstep_key(x), []).append((name, x, lens))
+        out = []
+        for members in groups.values():
+            names = [m[0] for m in members]
+            preds = [getattr(self, f"{n}_predictor") for n in names]
+            with self.env.side(*[t for m in members for t in m[1:]]):
+                ps, ctxs = M.predictors_fwd(preds, [m[1] for m in members], [m[2] for m in members])
+            for n, pr, cx in zip(names, ps, ctxs):
+                res[n] = (pr, cx)
+            out.append(names)
+        return out
+
+    def _variance(self, name, x, target, lens, control, inference, jobs=None):
         S, pre = self.S, self.pre
         predictor = getattr(self, f"{name}_predictor")
         if inference:
             pred, pctx = predictor.fwd(x, lens)
+        elif jobs is not None:  # training, grouped: run with the other predictors of this level (``_run_predictors``)
+            jobs.append((name, x, lens))
+            pred = pctx = None
         else:  # training: the prediction feeds only the loss (the embedding uses the target) -> side stream
             with self.env.side(x, lens, lane=PRED_LANES[name]):
                 pred, pctx = predictor.fwd(x, lens)
@@ -128,11 +160,18 @@ class VarianceAdaptor:
                 energy_t = H.avg_variance(energy_t, cum_a)
             if pitch_t is not None and cfg.pitch.level.value == "phone":
                 pitch_t = H.avg_variance(pitch_t, cum_a)
+        # training: the predictors of one level are collected and run as lockstep chains (grouped GEMM launches)
+        jobs = [] if (not inference and self._grouping()) else None
+        res, c["pred_groups"] = {}, []
         if cfg.energy.level.value == "phone":
-            energy_p, x, c["energy"] = self._variance("energy", x, energy_t, src_lens, control.energy, inference)
+            energy_p, x, c["energy"] = self._variance("energy", x, energy_t, src_lens, control.energy, inference, jobs)
         if cfg.pitch.level.value == "phone":
-            pitch_p, x, c["pitch"] = self._variance("pitch", x, pitch_t, src_lens, control.pitch, inference)
-        if dur_aligned is not None or teacher_forcing or not inference:
+            pitch_p, x, c["pitch"] = self._variance("pitch", x, pitch_t, src_lens, control.pitch, inference, jobs)
+        if jobs is not None:
+            jobs.append(("duration", x, src_lens))
+            c["pred_groups"] += self._run_predictors(jobs, res)
+            logd, c["duration"] = res["duration"]
+        elif dur_aligned is not None or teacher_forcing or not inference:
             # durations come from the batch / the aligner: prediction feeds the loss only
             with self.env.side(x, src_lens, lane=PRED_LANES["duration"]):
                 logd, c["duration"] = self.duration_predictor.fwd(x, src_lens)
@@ -151,10 +190,18 @@ class VarianceAdaptor:
         frame_level = cfg.energy.level.value == "frame" or cfg.pitch.level.value == "frame"
         x, cum, tgt_lens = H.length_regulate_fwd(x, dur, Tm, None if frame_level else table(Tm))
         c["cum"] = cum
+        jobs = [] if jobs is not None else None
         if cfg.energy.level.value == "frame":
-            energy_p, x, c["energy"] = self._variance("energy", x, energy_t, tgt_lens, control.energy, inference)
+            energy_p, x, c["energy"] = self._variance("energy", x, energy_t, tgt_lens, control.energy, inference, jobs)
         if cfg.pitch.level.value == "frame":
-            pitch_p, x, c["pitch"] = self._variance("pitch", x, pitch_t, tgt_lens, control.pitch, inference)
+            pitch_p, x, c["pitch"] = self._variance("pitch", x, pitch_t, tgt_lens, control.pitch, inference, jobs)
+        if jobs:
+            c["pred_groups"] += self._run_predictors(jobs, res)
+        for name in ("energy", "pitch"):  # grouped predictors: prediction and context arrive here
+            if name in res:
+                c[name] = (res[name][1], c[name][1])
+        energy_p = res["energy"][0] if "energy" in res else energy_p
+        pitch_p = res["pitch"][0] if "pitch" in res else pitch_p
         if frame_level:
             x = H.add_posenc(x, table(Tm), tgt_lens, B, Tm)
         return dict(output=x, duration_prediction=logd, duration_target=dur if (teacher_forcing or not inference) else None,
@@ -166,11 +213,21 @@ class VarianceAdaptor:
         enqueued on the side stream at the very start of the backward pass (small, latency-bound kernels that then
         run under the PostNet / decoder GEMMs); ``bwd`` joins and adds their input gradients where they belong."""
         env = self.env
-        if not env.side_enabled:
+        if not env.side_enabled and not (self._grouping() and c.get("pred_groups")):
             return
         out = {}
+        grouped = set()
+        for names in c.get("pred_groups", []):  # the lockstep chains of the forward pass, walked back the same way
+            names = [n for n in names if n in c and dpred.get(n) is not None]
+            if len(names) < 2:
+                continue
+            ctxs = [c[n][0] if n != "duration" else c[n] for n in names]
+            with env.side(*[dpred[n] for n in names]):
+                ds = M.predictors_bwd([getattr(self, f"{n}_predictor") for n in names], [dpred[n] for n in names], ctxs)
+            out.update(zip(names, ds))
+            grouped.update(names)
         for name in ("duration", "pitch", "energy"):
-            if name not in c or dpred.get(name) is None:
+            if name in grouped or name not in c or dpred.get(name) is None:
                 continue
             ctx = c[name][0] if name != "duration" else c[name]
             with env.side(dpred[name], lane=PRED_LANES[name]):
@@ -811,7 +868,7 @@ class FastSpeech2(_Base):
         weights = (t.pitch_loss_weight, t.energy_loss_weight, t.duration_loss_weight, t.mel_loss_weight,
                    t.postnet_loss_weight, t.attn_ctc_loss_weight, t.attn_bin_loss_weight)
         return (tuple(geo), self.precision, bool(self.env.side_enabled), tuple(PRED_LANES.values()), id(sync) if sync else 0, bin_w, weights,
-                getattr(self.postnet, "dropout_p", None), M.BF16_CHAIN, M.PRED_STORED, M.POSTNET_IM2COL, FP32_TRANSPOSED, HOLD_WGRADS, EARLY_FLUSH, self.env.seed, H.plan_flags())
+                getattr(self.postnet, "dropout_p", None), M.BF16_CHAIN, M.PRED_STORED, M.POSTNET_IM2COL, FP32_TRANSPOSED, HOLD_WGRADS, EARLY_FLUSH, PRED_GROUP, M.WGRAD_GROUP_ROWS, H.GEMM_GROUP, self.env.seed, H.plan_flags())
 
     def _planned_step(self, batch):
         sig = self._plan_signature(batch)

@@ -74,6 +74,15 @@ class Env:
         run beside one another as well as beside the main chain."""
         return _SideSection(self, tensors, lane)
 
+    def wgrad(self, dy, x, out, **kw):
+        """A layer's weight-gradient GEMM: on the side stream now -- or, while the stack holds its layer's weight gradients
+        back for one grouped launch (``Conformer.bwd``), only noted."""
+        if H.holding_weight_gradients():
+            H.linear_bwd_weight(dy, x, out, **kw)
+            return
+        with self.side(dy, x):
+            H.linear_bwd_weight(dy, x, out, **kw)
+
     def side_streams(self) -> dict:
         """{raw handle: torch.cuda.Stream} of the side streams created so far."""
         return {st.cuda_stream: st for st in getattr(self, "_lanes", {}).values()}
@@ -298,22 +307,18 @@ class FeedForward:
             bf = torch.bfloat16
             if not fused:  # (not reached from ConformerLayer.bwd, which always hands dz down)
                 dz = H.cast_bf16(H.axpby(dy, None, 0.5, 0.0, env.drop(self.p, self.s2)))
-            with env.side(dz, c.a):
-                H.linear_bwd_weight(dz, c.a, S.g(self.w2), bias_grad=None if fused else S.g(self.b2))
+            env.wgrad(dz, c.a, S.g(self.w2), bias_grad=None if fused else S.g(self.b2))
             du = H.linear_bwd_data(dz, S.pb(self.w2), epi=H.EPI_DACT, act="silu", aux=c.u,
                                    drop=env.drop(self.p, self.s1), out_dtype=bf, wt=S.pbt(self.w2))
-            with env.side(du, c.h):
-                H.linear_bwd_weight(du, c.h, S.g(self.w1), bias_grad=S.g(self.b1))
+            env.wgrad(du, c.h, S.g(self.w1), bias_grad=S.g(self.b1))
             dh = H.linear_bwd_data(du, S.pb(self.w1), out_dtype=bf, wt=S.pbt(self.w1))
             return self.ln.bwd(dh, c.ln, dx_add=dy, nxt=nxt, dz_dtype=bf)
         if not fused:
             dz = H.axpby(dy, None, 0.5, 0.0, env.drop(self.p, self.s2))
-        with env.side(dz, c.a):
-            H.linear_bwd_weight(dz, c.a, S.g(self.w2), bias_grad=None if fused else S.g(self.b2))
+        env.wgrad(dz, c.a, S.g(self.w2), bias_grad=None if fused else S.g(self.b2))
         du = H.linear_bwd_data(dz, S.p(self.w2), epi=H.EPI_DACT, act="silu", aux=c.u, drop=env.drop(self.p, self.s1),
                                wt=S.pt(self.w2))
-        with env.side(du, c.h):
-            H.linear_bwd_weight(du, c.h, S.g(self.w1), bias_grad=S.g(self.b1))
+        env.wgrad(du, c.h, S.g(self.w1), bias_grad=S.g(self.b1))
         dh = H.linear_bwd_data(du, S.p(self.w1))
         return self.ln.bwd(dh, c.ln, dx_add=dy, nxt=nxt)
 
@@ -392,27 +397,23 @@ class SelfAttention:
             bf = torch.bfloat16
             if not fused:
                 dz = H.cast_bf16(H.axpby(dy, None, 1.0, 0.0, env.drop(self.p, self.so)))
-            with env.side(dz, c.ob):
-                H.linear_bwd_weight(dz, c.ob, S.g(self.wo), bias_grad=None if fused else S.g(self.bo))
+            env.wgrad(dz, c.ob, S.g(self.wo), bias_grad=None if fused else S.g(self.bo))
             if c.o is None:
                 do = H.linear_bwd_data(dz, S.pb(self.wo), out_dtype=bf, wt=S.pbt(self.wo))
                 dqkv = H.attention_bwd_b(c.qkv, c.lens, c.ob, do, c.lse, B, T, self.heads, env.drop(self.p, self.sa))
             else:
                 do = H.linear_bwd_data(dz, S.pb(self.wo))  # fp32: the attention kernels' input
                 dqkv = H.cast_bf16(H.attention_bwd(c.qkv, c.lens, c.o, do, c.lse, B, T, self.heads, env.drop(self.p, self.sa)))
-            with env.side(dqkv, c.h):
-                H.linear_bwd_weight(dqkv, c.h, S.g(self.wi), bias_grad=S.g(self.bi))
+            env.wgrad(dqkv, c.h, S.g(self.wi), bias_grad=S.g(self.bi))
             dh = H.linear_bwd_data(dqkv, S.pb(self.wi), out_dtype=bf)
             return self.ln.bwd(dh, c.ln, dx_add=dy, nxt=nxt, dz_dtype=bf)
         if not fused:
             d_o = env.drop(self.p, self.so)
             dz = H.axpby(dy, None, 1.0, 0.0, d_o) if d_o.p > 0 else dy
-        with env.side(dz, c.o):
-            H.linear_bwd_weight(dz, c.o, S.g(self.wo), bias_grad=None if fused else S.g(self.bo))
+        env.wgrad(dz, c.o, S.g(self.wo), bias_grad=None if fused else S.g(self.bo))
         do = H.linear_bwd_data(dz, S.p(self.wo), wt=S.pt(self.wo))
         dqkv = H.attention_bwd(c.qkv, c.lens, c.o, do, c.lse, B, T, self.heads, env.drop(self.p, self.sa), scores=c.scores)
-        with env.side(dqkv, c.h):
-            H.linear_bwd_weight(dqkv, c.h, S.g(self.wi), bias_grad=S.g(self.bi))
+        env.wgrad(dqkv, c.h, S.g(self.wi), bias_grad=S.g(self.bi))
         dh = H.linear_bwd_data(dqkv, S.p(self.wi))
         return self.ln.bwd(dh, c.ln, dx_add=dy, nxt=nxt)
 
@@ -478,26 +479,22 @@ class ConvModule:
             bf = torch.bfloat16
             if not fused:
                 dz = H.cast_bf16(H.axpby(dy, None, 1.0, 0.0, env.drop(self.p, self.site)))
-            with env.side(dz, c.s):
-                H.linear_bwd_weight(dz, c.s, S.g(self.w2), bias_grad=None if fused else S.g(self.b2))
+            env.wgrad(dz, c.s, S.g(self.w2), bias_grad=None if fused else S.g(self.b2))
             chain = c.c.dtype == bf
             ds = H.linear_bwd_data(dz, S.pb(self.w2), out_dtype=bf if chain else torch.float32, wt=S.pbt(self.w2))
             dc = H.bn_act_bwd(ds, c.c, c.stats, gg, gb, "silu", training=env.training, bf16_only=chain)
             dg2 = H.dwconv_bwd(dc, c.g2, S.p(self.wd), S.g(self.wd), S.g(self.bd), B, T, glu=True, out_dtype=bf)
-            with env.side(dg2, c.h):
-                H.linear_bwd_weight(dg2, c.h, S.g(self.w1), bias_grad=S.g(self.b1))
+            env.wgrad(dg2, c.h, S.g(self.w1), bias_grad=S.g(self.b1))
             dh = H.linear_bwd_data(dg2, S.pb(self.w1), out_dtype=bf)
             return self.ln.bwd(dh, c.ln, dx_add=dy, nxt=nxt, dz_dtype=bf)
         if not fused:
             d_o = env.drop(self.p, self.site)
             dz = H.axpby(dy, None, 1.0, 0.0, d_o) if d_o.p > 0 else dy
-        with env.side(dz, c.s):
-            H.linear_bwd_weight(dz, c.s, S.g(self.w2), bias_grad=None if fused else S.g(self.b2))
+        env.wgrad(dz, c.s, S.g(self.w2), bias_grad=None if fused else S.g(self.b2))
         ds = H.linear_bwd_data(dz, S.p(self.w2), wt=S.pt(self.w2))
         dc = H.bn_act_bwd(ds, c.c, c.stats, gg, gb, "silu", training=env.training)
         dg2 = H.dwconv_bwd(dc, c.g2, S.p(self.wd), S.g(self.wd), S.g(self.bd), B, T, glu=True)
-        with env.side(dg2, c.h):
-            H.linear_bwd_weight(dg2, c.h, S.g(self.w1), bias_grad=S.g(self.b1))
+        env.wgrad(dg2, c.h, S.g(self.w1), bias_grad=S.g(self.b1))
         dh = H.linear_bwd_data(dg2, S.p(self.w1))
         return self.ln.bwd(dh, c.ln, dx_add=dy, nxt=nxt)
 
@@ -532,10 +529,18 @@ class ConformerLayer:
         return self.ffn1.bwd(d, c1, dz)
 
 
+#: FS2_WGRAD_GROUP_ROWS (default 16384, 0 = off): a Conformer stack whose activations have at most this many rows -- the
+#: encoder, B x Ts = 4096 rows at the benchmark shape -- holds each layer's eight weight-gradient GEMMs back and enqueues
+#: them as ONE grouped launch on the side stream when the layer's backward is through (``fs2hip_gemm_grouped``): alone each
+#: is 13-25 us of mostly launch and first-tile latency on a fraction of the chip.  The decoder's (B x Tm rows) fill it.
+WGRAD_GROUP_ROWS = int(os.environ.get("FS2_WGRAD_GROUP_ROWS", "16384"))
+
+
 class Conformer:
     def __init__(self, S, env, prefix, cfg):
         """Every layer but the first opens a new gradient bucket (data-parallel exchange granularity): ``buckets[i]``
         is the bucket layer i's parameters belong to; layer 0 shares the bucket that is open when the stack is declared."""
+        self.env = env
         self.layers, self.buckets = [], []
         for i in range(cfg.layers):
             if i > 0:
@@ -554,8 +559,18 @@ class Conformer:
     def bwd(self, dy, saved, layer_done=None):
         """``layer_done(bucket)`` is called after the backward of every layer whose bucket is complete with it (all
         but layer 0, whose bucket also holds what was declared before the stack)."""
+        env = self.env
+        group = H.GEMM_GROUP and 0 < dy.shape[0] * dy.shape[1] <= WGRAD_GROUP_ROWS and not H.holding_weight_gradients()
         for i in range(len(self.layers) - 1, -1, -1):
+            if group:
+                H.hold_weight_gradients(True)
             dy = self.layers[i].bwd(dy, saved[i])
+            if group:  # the layer's weight gradients: one grouped launch, behind everything enqueued so far
+                jobs = H.hold_weight_gradients(False)
+                with env.side(*[t for j in jobs for t in j[:2]]):
+                    with H.gemm_group():
+                        for dy_, x_, out_, kw_ in jobs:
+                            H.linear_bwd_weight(dy_, x_, out_, **kw_)
             if layer_done is not None and i > 0:
                 layer_done(self.buckets[i])
         return dy
@@ -596,52 +611,108 @@ class VariancePredictor:
         rounds 1-4 multiplied, without the fp32 tiles."""
         return self.env.stored and self.depthwise and PRED_STORED and self.c % 8 == 0 and L["cin"] % 8 == 0
 
+    # One layer = three phases, so that several predictors can walk their layers in lockstep (``predictors_fwd`` /
+    # ``predictors_bwd``) with the middle phase -- the GEMMs -- of all of them inside one ``H.gemm_group()``.
+    def _fwd_conv(self, L, x, B, T):
+        """Depthwise convolution in front of the pointwise GEMM (None: the layer is one k-tap convolution GEMM)."""
+        S = self.S
+        if self._stored(L):
+            return H.dwconv_fwd(x, S.p(L["wd"]), S.p(L["bd"]), B, T, out_dtype=torch.bfloat16)[0]
+        if self.depthwise:
+            return H.dwconv_fwd(x, S.p(L["wd"]), S.p(L["bd"]), B, T)[0]
+        return None
+
+    def _fwd_gemm(self, L, x, c, T):
+        S = self.S
+        if c is not None and c.dtype == torch.bfloat16:
+            return H.linear_fwd(c, S.pb(L["wp"]), S.p(L["bp"]), epi=H.EPI_ACT, act="relu")
+        if c is not None:
+            return H.linear_fwd(c, S.p(L["wp"]), S.p(L["bp"]), epi=H.EPI_ACT, act="relu")
+        return H.linear_fwd(x, S.p(L["wc"]), S.p(L["bc"]), epi=H.EPI_ACT, act="relu", taps=self.k, T=T)
+
+    def _fwd_norm(self, L, r):
+        # LayerNorm + Dropout in one launch; the backward takes Dropout, LayerNorm and ReLU in one (norm.hip)
+        ln = L["ln"]
+        return H.layernorm_fwd_drop(r, self.S.p(ln.w), self.S.p(ln.b), self.env.drop(self.p, L["site"]))
+
     def fwd(self, x, lens):
-        S, env = self.S, self.env
-        B, T, _ = x.shape
-        saved = []
-        for L in self.layers:
-            if self._stored(L):
-                c, _ = H.dwconv_fwd(x, S.p(L["wd"]), S.p(L["bd"]), B, T, out_dtype=torch.bfloat16)
-                r = H.linear_fwd(c, S.pb(L["wp"]), S.p(L["bp"]), epi=H.EPI_ACT, act="relu")
-            elif self.depthwise:
-                c, _ = H.dwconv_fwd(x, S.p(L["wd"]), S.p(L["bd"]), B, T)
-                r = H.linear_fwd(c, S.p(L["wp"]), S.p(L["bp"]), epi=H.EPI_ACT, act="relu")
-            else:
-                c = None
-                r = H.linear_fwd(x, S.p(L["wc"]), S.p(L["bc"]), epi=H.EPI_ACT, act="relu", taps=self.k, T=T)
-            # LayerNorm + Dropout in one launch; the backward takes Dropout, LayerNorm and ReLU in one (norm.hip)
-            ln = L["ln"]
-            out, mean, rstd = H.layernorm_fwd_drop(r, S.p(ln.w), S.p(ln.b), env.drop(self.p, L["site"]))
-            saved.append((x, c, r, (r, mean, rstd)))
-            x = out
-        pred = H.rowdot_fwd(x, S.p(self.wl), S.p(self.bl), lens, B, T)
-        return pred, (saved, x, lens)
+        (pred,), (ctx,) = predictors_fwd([self], [x], [lens])
+        return pred, ctx
+
+    def _head_fwd(self, x, lens, B, T):
+        return H.rowdot_fwd(x, self.S.p(self.wl), self.S.p(self.bl), lens, B, T)
+
+    def _head_bwd(self, dpred, xl, lens, B, T):
+        S = self.S
+        return H.rowdot_bwd(dpred, xl, S.p(self.wl), lens, S.g(self.wl), S.g(self.bl), B, T)
+
+    def _bwd_norm(self, L, d, c, r, ln_saved):
+        """Dropout, LayerNorm and ReLU backward in one launch: the gradient of the GEMM's result (bf16 under operand
+        storage, ``_stored``)."""
+        S, ln = self.S, L["ln"]
+        stored = c is not None and c.dtype == torch.bfloat16
+        return H.layernorm_bwd_pred(d, r, S.p(ln.w), ln_saved[1], ln_saved[2], S.g(ln.w), S.g(ln.b),
+                                    self.env.drop(self.p, L["site"]), out_dtype=torch.bfloat16 if stored else torch.float32)
+
+    def _bwd_gemm(self, L, d, x, c, T):
+        """Weight (+ bias) gradient and data gradient of the layer's GEMM; returns the data gradient."""
+        S = self.S
+        if c is not None and c.dtype == torch.bfloat16:
+            H.linear_bwd_weight(d, c, S.g(L["wp"]), bias_grad=S.g(L["bp"]))
+            return H.linear_bwd_data(d, S.pb(L["wp"]))
+        if self.depthwise:
+            H.linear_bwd_weight(d, c, S.g(L["wp"]), bias_grad=S.g(L["bp"]))
+            return H.linear_bwd_data(d, S.p(L["wp"]))
+        H.linear_bwd_weight(d, x, S.g(L["wc"]), taps=self.k, T=T, bias_grad=S.g(L["bc"]))
+        return H.linear_bwd_data(d, S.p(L["wc"]), taps=self.k, T=T)
+
+    def _bwd_conv(self, L, dc, x, B, T):
+        if not self.depthwise:
+            return dc
+        S = self.S
+        return H.dwconv_bwd(dc, x, S.p(L["wd"]), S.g(L["wd"]), S.g(L["bd"]), B, T)
 
     def bwd(self, dpred, ctx):
-        S, env = self.S, self.env
-        saved, xl, lens = ctx
-        B, T, _ = xl.shape
-        d = H.rowdot_bwd(dpred, xl, S.p(self.wl), lens, S.g(self.wl), S.g(self.bl), B, T)
-        for L, (x, c, r, ln_saved) in zip(reversed(self.layers), reversed(saved)):
-            ln = L["ln"]
-            if c is not None and c.dtype == torch.bfloat16:  # bf16 operand storage (``_stored``)
-                d = H.layernorm_bwd_pred(d, r, S.p(ln.w), ln_saved[1], ln_saved[2], S.g(ln.w), S.g(ln.b),
-                                         env.drop(self.p, L["site"]), out_dtype=torch.bfloat16)
-                H.linear_bwd_weight(d, c, S.g(L["wp"]), bias_grad=S.g(L["bp"]))
-                dc = H.linear_bwd_data(d, S.pb(L["wp"]))
-                d = H.dwconv_bwd(dc, x, S.p(L["wd"]), S.g(L["wd"]), S.g(L["bd"]), B, T)
-                continue
-            d = H.layernorm_bwd_pred(d, r, S.p(ln.w), ln_saved[1], ln_saved[2], S.g(ln.w), S.g(ln.b),
-                                     env.drop(self.p, L["site"]))
-            if self.depthwise:
-                H.linear_bwd_weight(d, c, S.g(L["wp"]), bias_grad=S.g(L["bp"]))
-                dc = H.linear_bwd_data(d, S.p(L["wp"]))
-                d = H.dwconv_bwd(dc, x, S.p(L["wd"]), S.g(L["wd"]), S.g(L["bd"]), B, T)
-            else:
-                H.linear_bwd_weight(d, x, S.g(L["wc"]), taps=self.k, T=T, bias_grad=S.g(L["bc"]))
-                d = H.linear_bwd_data(d, S.p(L["wc"]), taps=self.k, T=T)
-        return d
+        return predictors_bwd([self], [dpred], [ctx])[0]
+
+    def lockstep_key(self, x):
+        """Predictors with equal keys can share ``predictors_fwd`` / ``predictors_bwd`` (same layer count and row count;
+        widths may differ: a grouped launch takes members of any shape)."""
+        return (len(self.layers), tuple(x.shape[:2]))
+
+
+def predictors_fwd(preds, xs, lens):
+    """Forward of several independent VariancePredictors (a training step feeds each its own input, built from TARGET
+    embeddings: fs2/variance_adaptor.py:309-352) with equal ``lockstep_key``: layer by layer, the pointwise GEMMs of one
+    layer in ONE grouped launch (``H.gemm_group``).  Alone, each of those launches is a quarter of a workgroup round
+    (B x Ts rows = 256 workgroups of 64 x 64 at the benchmark shape) that takes ~13 us whatever its width.
+    Returns ([prediction], [context]) in the order given; every tensor is what ``VariancePredictor.fwd`` alone computes."""
+    B, T, _ = xs[0].shape
+    cur, saved = list(xs), [[] for _ in preds]
+    for li in range(len(preds[0].layers)):
+        cs = [p._fwd_conv(p.layers[li], x, B, T) for p, x in zip(preds, cur)]
+        with H.gemm_group():
+            rs = [p._fwd_gemm(p.layers[li], x, c, T) for p, x, c in zip(preds, cur, cs)]
+        for i, p in enumerate(preds):
+            out, mean, rstd = p._fwd_norm(p.layers[li], rs[i])
+            saved[i].append((cur[i], cs[i], rs[i], (rs[i], mean, rstd)))
+            cur[i] = out
+    out = [p._head_fwd(x, l, B, T) for p, x, l in zip(preds, cur, lens)]
+    return out, [(sv, x, l) for sv, x, l in zip(saved, cur, lens)]
+
+
+def predictors_bwd(preds, dpreds, ctxs):
+    """Backward of ``predictors_fwd``: per layer the members' weight gradients in one grouped launch and their data
+    gradients in another.  Returns the input gradients in the order given."""
+    B, T, _ = ctxs[0][1].shape
+    ds = [p._head_bwd(dp, xl, lens, B, T) for p, dp, (_, xl, lens) in zip(preds, dpreds, ctxs)]
+    for li in range(len(preds[0].layers) - 1, -1, -1):
+        lay = [(p.layers[li],) + ctx[0][li] for p, ctx in zip(preds, ctxs)]   # (L, x, c, r, ln_saved)
+        ds = [p._bwd_norm(L, d, c, r, lns) for p, d, (L, x, c, r, lns) in zip(preds, ds, lay)]
+        with H.gemm_group():
+            dcs = [p._bwd_gemm(L, d, x, c, T) for p, d, (L, x, c, r, lns) in zip(preds, ds, lay)]
+        ds = [p._bwd_conv(L, dc, x, B, T) for p, dc, (L, x, c, r, lns) in zip(preds, dcs, lay)]
+    return ds
 
 
 # ------------------------------------------------------------------------------------------------
@@ -912,8 +983,7 @@ class PostNet:
             x_b = x.dtype == torch.bfloat16
             if not (nxt_b or x_b):
                 draw = H.bn_act_bwd(dy, raw, stats, gg, gb, act, drop, training=env.training)
-                with env.side(draw, x):
-                    H.linear_bwd_weight(draw, x, S.g(w), taps=self.k, T=T, bias_grad=S.g(b))
+                env.wgrad(draw, x, S.g(w), taps=self.k, T=T, bias_grad=S.g(b))
                 if need:
                     dy = H.linear_bwd_data(draw, S.p(w), taps=self.k, T=T)
                 continue

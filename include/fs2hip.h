@@ -127,6 +127,19 @@ typedef struct {
 
 int fs2hip_gemm(const Fs2GemmArgs* args, void* stream);
 
+/* Up to FS2_GEMM_GROUP_MAX independent GEMMs in ONE launch: args[0 .. n) as for fs2hip_gemm, each with its own shapes,
+ * pointers, split-K and epilogue.  Replaces runs of small launches that leave most of the chip idle one at a time: the
+ * three variance predictors' pointwise convolutions of one layer (independent in a training step -- their inputs add
+ * TARGET embeddings, fs2/variance_adaptor.py:309-352 -- forward, data and weight gradients; fs2/blocks.py:14-16) and the
+ * eight weight gradients of one encoder Conformer layer (fs2/model.py:95-107: B x Ts rows, a quarter of a CU round each).
+ * Every member computes exactly what fs2hip_gemm would (the member's workgroups run the same tile code on the member's own
+ * arguments: same bits).  Members must share one kernel instance: the same operand orientations (a_kcontig, b_kcontig)
+ * and operand_bf16 in {0, 4}, taps == 1, counters == NULL, drop_p == 0; `tile` (args[0].tile) is 0 or one of 7 / 8 (fp32)
+ * and 22 / 23 / 26 (bf16 storage), the other members' `tile` is ignored.  n == 1 is fs2hip_gemm.  FS2HIP_EINVAL: the
+ * members cannot share a launch (the caller launches them one by one); nothing has been enqueued then. */
+#define FS2_GEMM_GROUP_MAX 8
+int fs2hip_gemm_grouped(const Fs2GemmArgs* args, int n, void* stream);
+
 /* Several row reductions in one launch: out0[c] (c < n0) / out1[c - n0] = sum over `rows` rows of src[r * stride + c],
  * c < n.  Finishes the partial sums of fs2hip_colsum (out == NULL) and fs2hip_layernorm_bwd (dgamma == dbeta == NULL),
  * i.e. the bias and LayerNorm parameter gradients (torch autograd's sum-to-size in the reference), whose only

@@ -15,7 +15,7 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from bench import build_parser, config_signature, kernel_source_hash  # noqa: E402
 
-GEMM = re.compile(r"\b(gemm2_kernel|gemm2p_kernel|gemm_kernel|gemmws32_kernel|gemmb_kernel|gemmbp_kernel|gemmws_kernel|gemmws4_kernel)\b")
+GEMM = re.compile(r"\b(gemm2_kernel|gemm2g_kernel|gemm2p_kernel|gemm_kernel|gemmws32_kernel|gemmb_kernel|gemmbg_kernel|gemmbp_kernel|gemmws_kernel|gemmws4_kernel)\b")
 rows = list(csv.DictReader(open(sys.argv[1])))
 back = int(sys.argv[2])
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
