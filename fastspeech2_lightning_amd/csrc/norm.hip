@@ -1,11 +1,23 @@
 // LayerNorm forward/backward: one 64-lane wavefront per row, float4 loads, wavefront-shuffle
 // reductions (no LDS on the row statistics).  HBM-bound: forward reads x once and writes y once.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
 
 constexpr int LN_MAX_CH = 4;           // C <= 1024: at most 4 float4 chunks per lane
-constexpr int LN_BWD_ROWS = 32;        // rows per workgroup in the backward (4 waves x 8 rows)
+constexpr int LN_BWD_ROWS = 32;        // rows per workgroup in the backward (4 waves x 8 rows) -- of LONG matrices:
+// a wavefront walks its rows one after the other (load, two wave reductions, store: a dependent chain of ~1.5 us per row),
+// so with 32 rows per workgroup the 4 096 rows of the encoder / the variance predictors are 128 workgroups on 256 CUs,
+// each wavefront 8 rows deep: 13 us for a kernel whose bytes take 3.  Short matrices take fewer rows per workgroup
+// (more workgroups, shallower chains); the price is more partial rows for the batched second stage, bounded at 512.
+// FS2_LN_BWD_ROWS=8|16|32 (measurement aid): one value for every row count
+static inline int ln_bwd_rows(int M) {
+  static const int forced = getenv("FS2_LN_BWD_ROWS") ? atoi(getenv("FS2_LN_BWD_ROWS")) : 0;
+  if (forced == 8 || forced == 16 || forced == 32) return forced;
+  return M > 16384 ? LN_BWD_ROWS : (M > 4096 ? 16 : 8);
+}
 
 __device__ __forceinline__ uint2 ln_pack_bf16(float4 o) {
   typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -93,7 +105,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                       const float* __restrict__ gamma, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, const float* __restrict__ dx_add,
                                                       void* __restrict__ dx, float* __restrict__ partial, int M, int C,
-                                                      void* __restrict__ dz, float dz_scale, Fs2Drop drop_in) {
+                                                      void* __restrict__ dz, float dz_scale, Fs2Drop drop_in,
+                                                      const int rows_per_wg) {
   constexpr int NP = DZ ? 3 : 2;
   __shared__ float red[4][NP][LN_MAX_CH * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -108,8 +121,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     db[j] = make_float4(0, 0, 0, 0);
     if constexpr (DZ) dzs[j] = make_float4(0, 0, 0, 0);
   }
-  const int row0 = blockIdx.x * LN_BWD_ROWS;
-  for (int rr = wave; rr < LN_BWD_ROWS; rr += 4) {
+  const int row0 = blockIdx.x * rows_per_wg;
+  for (int rr = wave; rr < rows_per_wg; rr += 4) {
     const int row = row0 + rr;
     if (row >= M) break;
     const float mu = mean[row], rs = rstd[row];
@@ -243,7 +256,7 @@ extern "C" int fs2hip_layernorm_bwd_pred(const float* dy, const float* x, const 
   hipStream_t s = (hipStream_t)stream;
   const Fs2Drop drop = fs2_make_drop(drop_p, drop_seed, drop_step);  // (p = 0: every factor is 1)
   const int nch = (C / 4 + 63) / 64;
-#define LN_PRED(N_, XOB_) ln_bwd_kernel<N_, false, false, false, true, XOB_><<<dim3(nblk), dim3(256), 0, s>>>(dy, x, gamma, mean, rstd, nullptr, dx, partial, M, C, nullptr, 0.f, drop)
+#define LN_PRED(N_, XOB_) ln_bwd_kernel<N_, false, false, false, true, XOB_><<<dim3(nblk), dim3(256), 0, s>>>(dy, x, gamma, mean, rstd, nullptr, dx, partial, M, C, nullptr, 0.f, drop, ln_bwd_rows(M))
   if (dx_bf16) {
     switch (nch) {
       case 1: LN_PRED(1, true); break;
@@ -278,7 +291,10 @@ extern "C" int fs2hip_layernorm_fwd_b(const float* x, const float* gamma, const 
   return 0;
 }
 
-extern "C" int fs2hip_layernorm_bwd_blocks(int M) { return (M + LN_BWD_ROWS - 1) / LN_BWD_ROWS; }
+extern "C" int fs2hip_layernorm_bwd_blocks(int M) {
+  const int rows = ln_bwd_rows(M);
+  return (M + rows - 1) / rows;
+}
 
 extern "C" int fs2hip_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                                     const float* rstd, const float* dx_add, float* dx, float* partial,
@@ -291,9 +307,9 @@ extern "C" int fs2hip_layernorm_bwd(const float* dy, const float* x, const float
   const int nch = (C / 4 + 63) / 64;
   const Fs2Drop nodrop = fs2_make_drop(0.f, 0);
   switch (nch) {
-    case 1: ln_bwd_kernel<1, false><<<dim3(nblk), dim3(256), 0, s>>>(dy, x, gamma, mean, rstd, dx_add, dx, partial, M, C, nullptr, 0.f, nodrop); break;
-    case 2: ln_bwd_kernel<2, false><<<dim3(nblk), dim3(256), 0, s>>>(dy, x, gamma, mean, rstd, dx_add, dx, partial, M, C, nullptr, 0.f, nodrop); break;
-    default: ln_bwd_kernel<4, false><<<dim3(nblk), dim3(256), 0, s>>>(dy, x, gamma, mean, rstd, dx_add, dx, partial, M, C, nullptr, 0.f, nodrop); break;
+    case 1: ln_bwd_kernel<1, false><<<dim3(nblk), dim3(256), 0, s>>>(dy, x, gamma, mean, rstd, dx_add, dx, partial, M, C, nullptr, 0.f, nodrop, ln_bwd_rows(M)); break;
+    case 2: ln_bwd_kernel<2, false><<<dim3(nblk), dim3(256), 0, s>>>(dy, x, gamma, mean, rstd, dx_add, dx, partial, M, C, nullptr, 0.f, nodrop, ln_bwd_rows(M)); break;
+    default: ln_bwd_kernel<4, false><<<dim3(nblk), dim3(256), 0, s>>>(dy, x, gamma, mean, rstd, dx_add, dx, partial, M, C, nullptr, 0.f, nodrop, ln_bwd_rows(M)); break;
   }
   FS2_LAUNCH_CHECK();
   // partial is [nblk][2][C]: columns [0, C) -> dgamma, [C, 2C) -> dbeta
@@ -314,9 +330,9 @@ extern "C" int fs2hip_layernorm_bwd_dz(const float* dy, const float* x, const fl
   const Fs2Drop drop = fs2_make_drop(drop_p, drop_seed, drop_step);
   const int nch = (C / 4 + 63) / 64;
   switch (nch) {
-    case 1: ln_bwd_kernel<1, true><<<dim3(nblk), dim3(256), 0, s>>>(dy, x, gamma, mean, rstd, dx_add, dx, partial, M, C, dz, dz_scale, drop); break;
-    case 2: ln_bwd_kernel<2, true><<<dim3(nblk), dim3(256), 0, s>>>(dy, x, gamma, mean, rstd, dx_add, dx, partial, M, C, dz, dz_scale, drop); break;
-    default: ln_bwd_kernel<4, true><<<dim3(nblk), dim3(256), 0, s>>>(dy, x, gamma, mean, rstd, dx_add, dx, partial, M, C, dz, dz_scale, drop); break;
+    case 1: ln_bwd_kernel<1, true><<<dim3(nblk), dim3(256), 0, s>>>(dy, x, gamma, mean, rstd, dx_add, dx, partial, M, C, dz, dz_scale, drop, ln_bwd_rows(M)); break;
+    case 2: ln_bwd_kernel<2, true><<<dim3(nblk), dim3(256), 0, s>>>(dy, x, gamma, mean, rstd, dx_add, dx, partial, M, C, dz, dz_scale, drop, ln_bwd_rows(M)); break;
+    default: ln_bwd_kernel<4, true><<<dim3(nblk), dim3(256), 0, s>>>(dy, x, gamma, mean, rstd, dx_add, dx, partial, M, C, dz, dz_scale, drop, ln_bwd_rows(M)); break;
   }
   FS2_LAUNCH_CHECK();
   return 0;  // partial is [nblk][3][C]; the caller finishes it with fs2hip_reduce_rows_multi
@@ -338,7 +354,7 @@ extern "C" int fs2hip_layernorm_bwd_x(const void* dy, const float* x, const floa
   const Fs2Drop drop = fs2_make_drop(dz ? drop_p : 0.f, drop_seed, drop_step);
   const int nch = (C / 4 + 63) / 64;
 #define FS2_LNB(N_, DZ_, DYB_, ZB_) \
-  ln_bwd_kernel<N_, DZ_, DYB_, ZB_><<<dim3(nblk), dim3(256), 0, s>>>(dy, x, gamma, mean, rstd, dx_add, dx, partial, M, C, dz, dz_scale, drop)
+  ln_bwd_kernel<N_, DZ_, DYB_, ZB_><<<dim3(nblk), dim3(256), 0, s>>>(dy, x, gamma, mean, rstd, dx_add, dx, partial, M, C, dz, dz_scale, drop, ln_bwd_rows(M))
 #define FS2_LNB_N(N_)                                      \
   do {                                                     \
     if (!dz) {                                             \

@@ -529,11 +529,13 @@ class ConformerLayer:
         return self.ffn1.bwd(d, c1, dz)
 
 
-#: FS2_WGRAD_GROUP_ROWS (default 16384, 0 = off): a Conformer stack whose activations have at most this many rows -- the
-#: encoder, B x Ts = 4096 rows at the benchmark shape -- holds each layer's eight weight-gradient GEMMs back and enqueues
-#: them as ONE grouped launch on the side stream when the layer's backward is through (``fs2hip_gemm_grouped``): alone each
-#: is 13-25 us of mostly launch and first-tile latency on a fraction of the chip.  The decoder's (B x Tm rows) fill it.
-WGRAD_GROUP_ROWS = int(os.environ.get("FS2_WGRAD_GROUP_ROWS", "16384"))
+#: FS2_WGRAD_GROUP_ROWS=16384 (measurement aid; default 0 = off): a Conformer stack whose activations have at most this
+#: many rows -- the encoder, B x Ts = 4096 rows at the benchmark shape -- holds each layer's eight weight-gradient GEMMs
+#: back and enqueues them as ONE grouped launch on the side stream when the layer's backward is through
+#: (``fs2hip_gemm_grouped``).  Measured (same box, alternating, profiles/r05_ab_group.log): fp32 18.49-18.54 ms per step with
+#: it against 18.44-18.48 without, bf16-mixed batch 64 10.73 against 10.71 -- one large launch at the end of a layer fills
+#: the side stream less well than eight small ones spread under the layer's main chain: off.
+WGRAD_GROUP_ROWS = int(os.environ.get("FS2_WGRAD_GROUP_ROWS", "0"))
 
 
 class Conformer:
