@@ -76,18 +76,16 @@ def inject(model, oracle, B: int, Ts: int, Tm: int) -> dict:
 class ReluCapture:
     """Sign patterns of the variance predictors' Conv -> ReLU layers on both sides of a parity step: the CPU oracle's
     pre-activations (forward hooks on its ``nn.ReLU`` modules) and the HIP step's ReLU outputs (the input of each
-    ``hip.layernorm_fwd_drop`` call, in the order the model runs its predictors).  ``flips()`` names every element where
+    ``hip.layernorm_fwd_drop`` call, told apart by the LayerNorm weight it is handed: the predictors of a training step
+    walk their layers in lockstep, ``modules.predictors_fwd``).  ``flips()`` names every element where
     the two disagree -- a pre-activation within rounding of zero that fell on different sides of it under the two
     summation orders, which switches that (token, channel)'s gradient path on in one model and off in the other
     (tools/relu_flip_diag.py is the stand-alone form, with a float64 run for scale)."""
 
     def __init__(self, model, oracle):
         self.model, self.oracle = model, oracle
-        self.pre, self.hip, self._hooks, self._real = {}, [], [], None
-        cfg = model.config.model.variance_predictors
-        phone = [n for n in ("energy", "pitch") if getattr(cfg, n).level.value == "phone"]
-        frame = [n for n in ("energy", "pitch") if getattr(cfg, n).level.value == "frame"]
-        self.order = [(n, li) for n in phone + ["duration"] + frame
+        self.pre, self.hip, self._hooks, self._real = {}, {}, [], None
+        self.order = [(n, li) for n in ("energy", "pitch", "duration")
                       for li in range(len(getattr(model.variance_adaptor, f"{n}_predictor").layers))]
 
     def __enter__(self):
@@ -98,10 +96,17 @@ class ReluCapture:
                     self.pre[key] = inp[0].detach().clone()
                 self._hooks.append(layer.layers[1].register_forward_hook(hook))
         self._real = H.layernorm_fwd_drop
+        S = self.model.store
+        which = {}  # LayerNorm weight (address in the flat parameter) -> (predictor, layer)
+        for name, li in self.order:
+            L = getattr(self.model.variance_adaptor, f"{name}_predictor").layers[li]
+            which[S.p(L["ln"].w).data_ptr()] = (name, li)
 
-        def wrapped(r, *a, **k):
-            self.hip.append((r > 0).cpu())
-            return self._real(r, *a, **k)
+        def wrapped(r, gamma, *a, **k):
+            key = which[gamma.data_ptr()]
+            assert key not in self.hip, key
+            self.hip[key] = (r > 0).cpu()
+            return self._real(r, gamma, *a, **k)
         H.layernorm_fwd_drop = wrapped
         return self
 
@@ -114,8 +119,8 @@ class ReluCapture:
     def flips(self):
         assert len(self.hip) == len(self.order) == len(self.pre), (len(self.hip), len(self.order), len(self.pre))
         out = []
-        for key, pat in zip(self.order, self.hip):
-            pre = self.pre[key]
+        for key in self.order:
+            pat, pre = self.hip[key], self.pre[key]
             for b, t, ch in (pat.view_as(pre) != (pre > 0)).nonzero().tolist():
                 out.append((f"{key[0]}_predictor.conv.{key[1]}", b, t, ch, float(pre[b, t, ch])))
         return out
