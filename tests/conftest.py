@@ -45,7 +45,7 @@ def golden_dir():
 POISON_BY_DEFAULT = {"test_attention_gpu.py", "test_attention_bf16_storage_gpu.py", "test_gemm_bf16_gpu.py",
                      "test_gemm_norm_gpu.py", "test_gemm_ws_gpu.py", "test_gemm_split_gpu.py",
                      "test_gemm_bf16_storage_gpu.py", "test_kernels_gpu.py", "test_conv_bn_bf16_gpu.py",
-                     "test_aligner_gpu.py", "test_reduce_deferred_gpu.py", "test_plan_gpu.py"}
+                     "test_aligner_gpu.py", "test_reduce_deferred_gpu.py", "test_plan_gpu.py", "test_gemm_group_gpu.py"}
 
 
 @pytest.fixture(autouse=True)
