@@ -477,6 +477,8 @@ def tile_table() -> dict:
     ``save_tile_cache`` or broadcast it so that every rank of a data-parallel job sums in the same order."""
     t = {repr(k): int(v) for k, v in _TILE_CACHE.items()}
     t["__format__"] = TILE_KEY_FORMAT
+    if _GROUP_TILE_CACHE:  # tiles of grouped launches (``gemm_group``), keyed by their members' signatures
+        t["__groups__"] = {repr(k): int(v) for k, v in _GROUP_TILE_CACHE.items()}
     return t
 
 
@@ -508,6 +510,10 @@ def load_tile_table(table: dict) -> None:
         return
     for k, v in table.items():
         if k == "__format__":
+            continue
+        if k == "__groups__":
+            for gk, gv in v.items():
+                _GROUP_TILE_CACHE[ast.literal_eval(gk)] = int(gv)
             continue
         _TILE_CACHE[ast.literal_eval(k) if isinstance(k, str) else tuple(k)] = int(v)
     TILE_GEN[0] += 1

@@ -81,13 +81,13 @@ def share_tile_table(src: int = 0, process_group=None) -> int:
     lost the timing race elsewhere.  Returns the number of signatures in the table."""
     from . import hip as H
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
-        return len(H.tile_table()) - 1  # (the table carries its format stamp)
+        return sum(1 for k in H.tile_table() if not k.startswith("__"))  # (not the format stamp / the grouped-launch tiles)
     box = [(H.tile_table(), H.tile_timings()) if dist.get_rank(process_group) == src else None]
     dist.broadcast_object_list(box, src=src, group=process_group)
     if dist.get_rank(process_group) != src:
         H.load_tile_table(box[0][0])
         H.load_tile_timings(box[0][1])  # (the in-step refinement's candidate lists: the same trials on every rank)
-    return len(box[0][0]) - 1
+    return sum(1 for k in box[0][0] if not k.startswith("__"))
 
 
 def host_budget(local_world: int) -> dict:

@@ -136,3 +136,28 @@ def test_a_recorded_plan_keeps_its_own_copy_of_the_member_table():
     op, st, slots = rec.cmds[-1]
     kept = C.cast(slots[0], C.POINTER(H.GemmArgs * 3)).contents
     assert [(m.Mc, m.Nc, m.R) for m in kept] == [(1, 2, 3), (4, 5, 6), (7, 8, 9)] and slots[1] == 3
+
+
+def test_group_tiles_travel_with_the_tile_table(monkeypatch):
+    """``hip.tile_table`` / ``load_tile_table`` (FS2_GEMM_TILE_CACHE files, ``parallel.share_tile_table``): the tiles of
+    grouped launches are part of the table, under a key of their own that old readers of single signatures never see."""
+    import json
+    monkeypatch.setattr(H, "_current_device", lambda: 0)   # (a signature names its device: no GPU on this box)
+    saved, saved_g = dict(H._TILE_CACHE), dict(H._GROUP_TILE_CACHE)
+    try:
+        H._TILE_CACHE.clear(); H._GROUP_TILE_CACHE.clear()
+        members = [args(4096, 256, 256) for _ in range(3)]
+        key = tuple(H._tile_key(m) for m in members)
+        H._TILE_CACHE[H._tile_key(members[0])] = 7
+        assert "__groups__" not in H.tile_table()
+        H._GROUP_TILE_CACHE[key] = 8
+        t = json.loads(json.dumps(H.tile_table()))          # as a file / a broadcast object would carry it
+        assert sum(1 for k in t if not k.startswith("__")) == 1 and len(t["__groups__"]) == 1
+        H._TILE_CACHE.clear(); H._GROUP_TILE_CACHE.clear()
+        H.load_tile_table(t)
+        assert H._GROUP_TILE_CACHE == {key: 8} and list(H._TILE_CACHE.values()) == [7]
+        arr = (H.GemmArgs * 3)(*members)
+        assert H._group_tile(arr, 3, members, 7) == 8       # replayed without the tuner (GEMM_TUNE off in tests)
+    finally:
+        H._TILE_CACHE.clear(); H._TILE_CACHE.update(saved)
+        H._GROUP_TILE_CACHE.clear(); H._GROUP_TILE_CACHE.update(saved_g)
