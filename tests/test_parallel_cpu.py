@@ -179,7 +179,11 @@ def _tiles_rank(rank, world, port, q):
     H._TILE_CACHE[key] = 7 if rank == 0 else 12          # each rank "tuned" its own tile ...
     if rank == 1:
         H._TILE_CACHE[(4096, 256, 256, 1, 1, 1, 0, 1, 0, 0, 0, 17, 0)] = 9
+    H._GROUP_TILE_CACHE.clear()
+    if rank == 0:  # ... and rank 0 the tile of a grouped launch (three members of one signature)
+        H._GROUP_TILE_CACHE[(key, key, key)] = 8
     n = share_tile_table(0)
+    assert H._GROUP_TILE_CACHE == {(key, key, key): 8}, (rank, H._GROUP_TILE_CACHE)
     q.put((rank, n, H._TILE_CACHE[key]))
     dist.destroy_process_group()
 
